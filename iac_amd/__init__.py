@@ -1,0 +1,26 @@
+"""iac_amd — MI355X-native IAMF post-decode renderer.
+
+The product is the C-ABI shared library ``iac_amd/lib/libiamf_hip.so`` (HIP kernels for gfx950
+plus a plain-C host side; headers in ``include/``).  This Python package is only a ctypes
+binding used by the tests and bench.py: it holds no arithmetic and no CPU fallback.  Importing
+it never touches ``oracle/``.
+"""
+from .hipabi import (  # noqa: F401
+    FMT_F32,
+    FMT_S16,
+    FMT_S24,
+    FMT_S32,
+    KIND_H2M,
+    KIND_M2M,
+    SS,
+    Batch,
+    BatchConfig,
+    IamfHipError,
+    Matrix,
+    build,
+    get_h2m_matrix,
+    get_m2m_matrix,
+    layout_channels,
+    lib,
+    lib_path,
+)

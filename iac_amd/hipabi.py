@@ -1,0 +1,163 @@
+"""ctypes binding of include/iamf_hip.h (libiamf_hip.so).  No arithmetic lives here.
+
+If the shared library is missing or cannot be loaded this module raises: there is no CPU path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "iac_amd", "csrc")
+
+FMT_S16, FMT_S24, FMT_S32, FMT_F32 = 16, 24, 32, -32
+KIND_H2M, KIND_M2M = 0, 1
+SS = dict(A=0x020, B=0x050, C=0x250, D=0x450, E=0x451, F=0x370, G=0x490, H=0x9A3, I=0x070,
+          J=0x470, STEREO=0x200, L51=0x510, L512=0x512, L514=0x514, L71=0x710, L714=0x714,
+          MONO=0x100, L712=0x712, L312=0x312, BINAURAL=0x1020)
+
+FP = C.POINTER(C.c_float)
+
+
+class IamfHipError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__("%s failed with IAMF_HIP error %d" % (what, code))
+        self.code = code
+
+
+class Matrix(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("in_id", C.c_int32), ("out_id", C.c_int32),
+                ("channels", C.c_int32), ("lfe1", C.c_int32), ("lfe2", C.c_int32),
+                ("m", C.c_int32), ("n", C.c_int32), ("mat", FP)]
+
+
+class BatchConfig(C.Structure):
+    _fields_ = [("n_streams", C.c_int32), ("frame_size", C.c_int32), ("sample_rate", C.c_int32),
+                ("out_channels", C.c_int32), ("out_format", C.c_int32), ("matrix", Matrix),
+                ("limiter_enable", C.c_int32), ("limiter_threshold_db", C.c_float),
+                ("loudness_enable", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+def lib_path():
+    return os.path.join(ROOT, "iac_amd", "lib", "libiamf_hip.so")
+
+
+def build(force=False):
+    """Compile every HIP/C source for gfx950 into iac_amd/lib/libiamf_hip.so (hipcc cross-compiles
+    without a GPU)."""
+    args = ["make", "-C", CSRC]
+    if force:
+        subprocess.check_call(args + ["clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return lib_path()
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError("libiamf_hip.so is not built (run __graft_entry__.build()); "
+                              "iac_amd has no CPU fallback")
+        L = C.CDLL(path)
+        L.iamf_hip_get_h2m_matrix.argtypes = [C.c_int, C.c_int, C.POINTER(Matrix)]
+        L.iamf_hip_get_m2m_matrix.argtypes = [C.c_int, C.c_int, C.POINTER(Matrix)]
+        L.iamf_hip_layout_channels.argtypes = [C.c_int]
+        L.iamf_hip_batch_create.argtypes = [C.POINTER(BatchConfig), C.POINTER(C.c_void_p)]
+        L.iamf_hip_batch_destroy.argtypes = [C.c_void_p]
+        L.iamf_hip_batch_destroy.restype = None
+        L.iamf_hip_batch_set_gains.argtypes = [C.c_void_p, FP, FP, FP]
+        L.iamf_hip_batch_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                            C.c_void_p, C.c_int64, C.c_void_p]
+        L.iamf_hip_batch_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.iamf_hip_batch_reset.argtypes = [C.c_void_p]
+        L.iamf_hip_format_bytes.argtypes = [C.c_int]
+        L.iamf_hip_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def get_h2m_matrix(order, out_id):
+    m = Matrix()
+    if lib().iamf_hip_get_h2m_matrix(order, out_id, C.byref(m)) != 0:
+        raise KeyError((order, hex(out_id)))
+    return m
+
+
+def get_m2m_matrix(in_id, out_id):
+    m = Matrix()
+    if lib().iamf_hip_get_m2m_matrix(in_id, out_id, C.byref(m)) != 0:
+        raise KeyError((hex(in_id), hex(out_id)))
+    return m
+
+
+def layout_channels(out_id):
+    return lib().iamf_hip_layout_channels(out_id)
+
+
+def _fparr(a):
+    if a is None:
+        return None
+    arr = (C.c_float * len(a))(*[float(v) for v in a])
+    return arr
+
+
+class Batch:
+    """Thin handle on iamf_hip_batch_*; pointers are raw device addresses (ints)."""
+
+    def __init__(self, n_streams, matrix, out_channels, frame_size=1024, sample_rate=48000,
+                 out_format=FMT_S16, limiter=True, threshold_db=-1.0, loudness=False):
+        cfg = BatchConfig()
+        cfg.n_streams = n_streams
+        cfg.frame_size = frame_size
+        cfg.sample_rate = sample_rate
+        cfg.out_channels = out_channels
+        cfg.out_format = out_format
+        cfg.matrix = matrix
+        cfg.limiter_enable = 1 if limiter else 0
+        cfg.limiter_threshold_db = threshold_db
+        cfg.loudness_enable = 1 if loudness else 0
+        self.cfg = cfg
+        self.bytes_per_sample = lib().iamf_hip_format_bytes(out_format)
+        h = C.c_void_p()
+        r = lib().iamf_hip_batch_create(C.byref(cfg), C.byref(h))
+        if r != 0:
+            raise IamfHipError(r, "iamf_hip_batch_create")
+        self.h = h
+
+    def set_gains(self, element=None, output=None, loudness=None):
+        r = lib().iamf_hip_batch_set_gains(self.h, _fparr(element), _fparr(output), _fparr(loudness))
+        if r != 0:
+            raise IamfHipError(r, "iamf_hip_batch_set_gains")
+
+    def render(self, d_in, in_stream_stride, in_frame_stride, n_frames, d_pcm, pcm_stream_stride_bytes,
+               stream=None):
+        r = lib().iamf_hip_batch_render(self.h, d_in, in_stream_stride, in_frame_stride, n_frames,
+                                        d_pcm, pcm_stream_stride_bytes, stream)
+        if r < 0:
+            raise IamfHipError(r, "iamf_hip_batch_render")
+        return r
+
+    def flush(self, d_pcm, pcm_stream_stride_bytes, stream=None):
+        r = lib().iamf_hip_batch_flush(self.h, d_pcm, pcm_stream_stride_bytes, stream)
+        if r < 0:
+            raise IamfHipError(r, "iamf_hip_batch_flush")
+        return r
+
+    def reset(self):
+        r = lib().iamf_hip_batch_reset(self.h)
+        if r != 0:
+            raise IamfHipError(r, "iamf_hip_batch_reset")
+
+    def close(self):
+        if self.h:
+            lib().iamf_hip_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,142 @@
+/*
+ * iamf_hip.h — C ABI of the MI355X-native IAMF post-decode renderer (libiamf_hip.so).
+ *
+ * Plain C: pointers, sizes and PODs only.  Every entry point names the reference interface
+ * (Samsung/iac, paths relative to the reference tree) it stands in for.  The reference renders
+ * one decoder handle, one frame at a time on the CPU; this ABI renders a BATCH of independent
+ * streams x frames per call on one GPU, with the same per-stream arithmetic and stage order
+ * (render -> element gain -> mix -> output gain -> loudness -> limiter -> PCM pack,
+ * src/iamf_dec/IAMF_decoder.c:3335-3500).  There is no CPU fallback: every call fails with
+ * IAMF_HIP_ERR_DEVICE if HIP is unusable.
+ *
+ * Pointers named d_* are DEVICE pointers owned by the caller (any allocator: hipMalloc, a
+ * torch tensor's data_ptr ...).  `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  Calls are asynchronous on that stream unless stated otherwise.
+ */
+#ifndef IAMF_HIP_H
+#define IAMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes: same numeric values as IAMF_defines.h:181-190, plus one for the device */
+enum {
+  IAMF_HIP_OK = 0,
+  IAMF_HIP_ERR_BAD_ARG = -1,
+  IAMF_HIP_ERR_BUFFER_TOO_SMALL = -2,
+  IAMF_HIP_ERR_INTERNAL = -3,
+  IAMF_HIP_ERR_INVALID_STATE = -5,
+  IAMF_HIP_ERR_UNIMPLEMENTED = -6,
+  IAMF_HIP_ERR_ALLOC_FAIL = -7,
+  IAMF_HIP_ERR_DEVICE = -100
+};
+
+/* rendering ids of loudspeaker layouts, same values as src/iamf_dec/ae_rdr.h:40-61 */
+enum {
+  IAMF_HIP_SS_A = 0x020, IAMF_HIP_SS_B = 0x050, IAMF_HIP_SS_C = 0x250, IAMF_HIP_SS_D = 0x450,
+  IAMF_HIP_SS_E = 0x451, IAMF_HIP_SS_F = 0x370, IAMF_HIP_SS_G = 0x490, IAMF_HIP_SS_H = 0x9A3,
+  IAMF_HIP_SS_I = 0x070, IAMF_HIP_SS_J = 0x470,
+  IAMF_HIP_L_STEREO = 0x200, IAMF_HIP_L_51 = 0x510, IAMF_HIP_L_512 = 0x512,
+  IAMF_HIP_L_514 = 0x514, IAMF_HIP_L_71 = 0x710, IAMF_HIP_L_714 = 0x714,
+  IAMF_HIP_L_MONO = 0x100, IAMF_HIP_L_712 = 0x712, IAMF_HIP_L_312 = 0x312,
+  IAMF_HIP_L_BINAURAL = 0x1020
+};
+
+enum { IAMF_HIP_KIND_H2M = 0, IAMF_HIP_KIND_M2M = 1 };
+
+/* output sample formats.  16/24/32 = interleaved little-endian integer PCM exactly as
+ * iamf_decoder_plane2stride_out writes it (IAMF_decoder.c:121-167).  F32 = the limiter output
+ * as interleaved float, unscaled: a stage tap for parity tests, not a reference format. */
+enum { IAMF_HIP_FMT_S16 = 16, IAMF_HIP_FMT_S24 = 24, IAMF_HIP_FMT_S32 = 32, IAMF_HIP_FMT_F32 = -32 };
+
+/* A static rendering matrix: what IAMF_element_renderer_get_H2M_matrix (h2m_rdr.c:1070-1081,
+ * struct h2m_rdr_t ae_rdr.h:142-151) or _get_M2M_matrix (m2m_rdr.c:1786-1804, struct m2m_rdr_t
+ * ae_rdr.h:134-140) return.  `mat` points into the library's table (host memory, m*n floats,
+ * H2M: mat[n*m_size+m], M2M: mat[m*n_size+n]) and stays valid for the process lifetime. */
+typedef struct {
+  int32_t kind;     /* IAMF_HIP_KIND_* */
+  int32_t in_id;    /* H2M: ambisonics order 0..3 ; M2M: rendering id of the input layout */
+  int32_t out_id;   /* rendering id of the output layout */
+  int32_t channels; /* H2M: table `channels` field ; M2M: n */
+  int32_t lfe1, lfe2;
+  int32_t m, n;
+  const float *mat;
+} iamf_hip_matrix;
+
+/* replaces IAMF_element_renderer_get_H2M_matrix, src/iamf_dec/h2m_rdr.c:1070 (0 or -1) */
+int iamf_hip_get_h2m_matrix(int order, int out_id, iamf_hip_matrix *out);
+/* replaces IAMF_element_renderer_get_M2M_matrix, src/iamf_dec/m2m_rdr.c:1786 (0 or -1) */
+int iamf_hip_get_m2m_matrix(int in_id, int out_id, iamf_hip_matrix *out);
+/* channels of an output layout by rendering id (IAMF_decoder.c:3998-4008); 0 if unknown */
+int iamf_hip_layout_channels(int out_id);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched renderer: N independent streams that share one topology (same element layout, same
+ * output layout, same frame size, bit depth and limiter settings) and keep separate state.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct iamf_hip_batch iamf_hip_batch;
+
+typedef struct {
+  int32_t n_streams;
+  int32_t frame_size;     /* samples per frame of element PCM (e.g. 1024) */
+  int32_t sample_rate;    /* Hz; limiter time constants depend on it */
+  int32_t out_channels;   /* channels of the output layout = PCM stride (IAMF_decoder.c:3497-3499) */
+  int32_t out_format;     /* IAMF_HIP_FMT_* (IAMF_decoder_set_bit_depth, IAMF_decoder.h:161) */
+  iamf_hip_matrix matrix; /* element renderer; `mat` may also be a caller-owned host array */
+  int32_t limiter_enable; /* IAMF_decoder_peak_limiter_enable, IAMF_decoder.h:170 */
+  float limiter_threshold_db; /* IAMF_decoder_peak_limiter_set_threshold, IAMF_decoder.h:179;
+                                 attack 1 ms, release 200 ms, look-ahead 240 are the reference's
+                                 constants (common/audio_defines.h:38-41) */
+  int32_t loudness_enable; /* normalization_loudness != 0 (IAMF_decoder.c:3480) */
+  int32_t reserved[7];
+} iamf_hip_batch_config;
+
+/* Creates device state for cfg->n_streams streams on the CURRENT HIP device.  Synchronous.
+ * Replaces, per stream: iamf_stream_renderer_open (IAMF_decoder.c:2480),
+ * audio_effect_peak_limiter_create/_init (audio_effect_peak_limiter.c:50,73). */
+int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out);
+void iamf_hip_batch_destroy(iamf_hip_batch *b);
+
+/* Per-stream linear gains (host arrays of n_streams floats, NULL = leave unchanged):
+ * element mix gain and output mix gain as iamf_frame_gain applies a constant gain
+ * (IAMF_decoder.c:1392-1397: only if != 1 and > 0), and the loudness gain
+ * db2lin(target - loudness) of iamf_loudness_process (IAMF_decoder.c:3206-3221).  Synchronous. */
+int iamf_hip_batch_set_gains(iamf_hip_batch *b, const float *element_gain,
+                             const float *output_gain, const float *loudness_gain);
+
+/* Renders n_frames frames of every stream.
+ *   d_in : planar f32 element PCM, sample i of channel c of frame f of stream s at
+ *          d_in[s*in_stream_stride + f*in_frame_stride + c*frame_size + i]   (strides in floats)
+ *   d_pcm: packed output; the k-th sample-frame this call emits for stream s starts at byte
+ *          s*pcm_stream_stride_bytes + k*out_channels*bytes_per_sample
+ * Returns the number of sample-frames emitted PER STREAM (>= 0; the limiter withholds the
+ * first 240 of a stream's life exactly like audio_effect_peak_limiter_process_block :185-201)
+ * or a negative IAMF_HIP_ERR_*.  This is the batched form of the render..pack section of
+ * iamf_decoder_internal_decode (IAMF_decoder.c:3374-3500) i.e. of iamf_stream_render,
+ * iamf_frame_gain, iamf_mixer_mix, iamf_loudness_process,
+ * audio_effect_peak_limiter_process_block and iamf_decoder_plane2stride_out. */
+int iamf_hip_batch_render(iamf_hip_batch *b, const float *d_in, int64_t in_stream_stride,
+                          int64_t in_frame_stride, int32_t n_frames, void *d_pcm,
+                          int64_t pcm_stream_stride_bytes, void *stream);
+
+/* End of stream: pushes 240 zero samples through each stream's limiter and emits the withheld
+ * tail (iamf_delay_buffer_handle, IAMF_decoder.c:3250-3301).  Returns sample-frames per stream. */
+int iamf_hip_batch_flush(iamf_hip_batch *b, void *d_pcm, int64_t pcm_stream_stride_bytes,
+                         void *stream);
+
+/* Forgets all stream state (new IA sequence: limiter re-initialised as in
+ * iamf_decoder_internal_configure, IAMF_decoder.c:3809-3815).  Synchronous. */
+int iamf_hip_batch_reset(iamf_hip_batch *b);
+
+/* bytes one output sample occupies for a format (2, 3, 4) */
+int iamf_hip_format_bytes(int out_format);
+/* library / build identification string (static storage) */
+const char *iamf_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IAMF_HIP_H */
