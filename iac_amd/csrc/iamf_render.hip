@@ -27,297 +27,9 @@
 
 namespace {
 
-constexpr int kChunk = 256;      // samples per workgroup step = threads per workgroup
-constexpr int kDelay = 240;      // limiter look-ahead (reference common/audio_defines.h:41)
-constexpr int kRing = 512;       // LDS ring length (power of two >= kChunk + kDelay + 15)
-constexpr int kSave = 256;       // samples of ring persisted per stream between calls
-constexpr int kHead = 256;       // coefficient-table head kept in LDS
-constexpr int kMaxOut = 24;      // reference MAX_OUTPUT_CHANNELS
-constexpr int kMaxIn = 24;
-
-struct LimState {  // per stream, persisted in HBM between calls
-  float g;   // currentGain
-  float gs;  // targetStartGain
-  float ge;  // targetEndGain
-  int n;     // increments of currentTC since the last trigger; >= n_end means idle
-};
-
-struct RenderParams {
-  const float *in;          // planar f32 element PCM (device) or nullptr = zeros (flush)
-  int64_t in_stream_stride; // floats
-  int64_t in_frame_stride;  // floats
-  uint8_t *pcm;             // packed output (device)
-  int64_t pcm_stream_stride;  // bytes
-  const float *matrix;      // device, feed-major [n_feeds][M]
-  const float *gains;       // device [3][n_streams]: element, output, loudness
-  const float *ctab;        // device limiter coefficient table [n_end + 1]
-  LimState *lim;            // device [n_streams]
-  float *ring_y;            // device [n_streams][out_ch][kSave]
-  float *ring_pm;           // device [n_streams][kSave]
-  int64_t pos0;             // samples of each stream consumed before this call
-  int32_t total;            // samples to process in this call
-  int32_t frame_size;
-  int32_t n_streams;
-  int32_t n_feeds;
-  int32_t out_ch;
-  int32_t out_format;
-  int32_t limiter_on;
-  int32_t loudness_on;
-  int32_t n_atk, n_end;     // limiter table split points
-  float thr;
-  const int32_t *src_feed;  // device [out_ch]: output slot -> feed index, or -1 = silent slot
-};
-
-// One gain step evaluated for a hypothetical pre-state n_pre (no trigger since the state was
-// set): audio_effect_peak_limiter.c:241-255 with currentTC = T[n_pre].
-__device__ __forceinline__ float gain_at(int n_pre, float gs, float ge, float c, int n_atk, int n_end) {
-  float g = 1.0f;
-  if (n_pre < n_atk) {
-    g = gs - c * (gs - ge);
-  } else if (n_pre < n_end) {
-    g = ge + c * (1.0f - ge);
-  }
-  return g;
-}
-
-__device__ __forceinline__ float to_scaled(float x, float scale, float lo, float hi) {
-  x = x * scale;
-  x = x > lo ? x : lo;
-  x = x < hi ? x : hi;
-  return rintf(x);  // v_rndne_f32: ties to even, like lrintf in the default rounding mode
-}
-
-template <int M>
-__global__ __launch_bounds__(kChunk) void render_kernel(const RenderParams p) {
-  extern __shared__ float lds[];
-  const int out_ch = p.out_ch;
-  float *ring_y = lds;                        // [out_ch][kRing]
-  float *ring_pm = ring_y + out_ch * kRing;   // [kRing]  per-sample max |y| over channels
-  float *ring_b16 = ring_pm + kRing;          // [kRing]  max of pm over the trailing 16 samples
-  float *arr_p = ring_b16 + kRing;            // [kChunk] window maxima (serial fallback)
-  float *arr_e = arr_p + kChunk;              // [kChunk] thr / p
-  float *arr_g = arr_e + kChunk;              // [kChunk] gains (serial fallback)
-  float *head = arr_g + kChunk;               // [kHead]  ctab[0..kHead)
-  float *st = head + kHead;                   // [4]      limiter state exchange
-
-  const int s = blockIdx.x;
-  const int t = threadIdx.x;
-  const int fs = p.frame_size;
-  const float thr = p.thr;
-  const int n_atk = p.n_atk, n_end = p.n_end;
-
-  // ---- stream state -> LDS ----
-  {
-    const float *sy = p.ring_y + (int64_t)s * out_ch * kSave;
-    const float *spm = p.ring_pm + (int64_t)s * kSave;
-    // saved entry i (0..kSave) is global sample pos0 - kSave + i
-    const int rp = (int)((p.pos0 - kSave + t) & (kRing - 1));
-    const int rq = (int)((p.pos0 + t) & (kRing - 1));
-    for (int c = 0; c < out_ch; ++c) {
-      ring_y[c * kRing + rp] = sy[c * kSave + t];
-      ring_y[c * kRing + rq] = 0.f;
-    }
-    ring_pm[rp] = spm[t];
-    ring_pm[rq] = 0.f;
-    ring_b16[rq] = 0.f;
-    head[t] = (t <= n_end) ? p.ctab[t] : 1.0f;
-  }
-  __syncthreads();
-  {
-    // trailing-16 maxima of the restored part; entries older than the saved window count as 0
-    const int64_t gk = p.pos0 - kSave + t;
-    float b = 0.f;
-    for (int j = 0; j < 16; ++j) {
-      if (t - j >= 0) b = fmaxf(b, ring_pm[(int)((gk - j) & (kRing - 1))]);
-    }
-    ring_b16[(int)(gk & (kRing - 1))] = b;
-  }
-  LimState ls = p.lim[s];
-  float g_cur = ls.g, gs = ls.gs, ge = ls.ge;
-  int n_st = ls.n;
-  const float eg = p.gains[s], og = p.gains[p.n_streams + s], lg = p.gains[2 * p.n_streams + s];
-  const bool eg_on = (eg != 1.f && eg > 0.f);
-  const bool og_on = (og != 1.f && og > 0.f);
-  const bool lg_on = p.loudness_on && (lg != 1.0f);
-  __syncthreads();
-
-  const int64_t out_base = p.limiter_on ? (p.pos0 > kDelay ? p.pos0 - kDelay : 0) : p.pos0;
-  const int bytes = p.out_format == IAMF_HIP_FMT_S16 ? 2 : (p.out_format == IAMF_HIP_FMT_S24 ? 3 : 4);
-  uint8_t *pcm = p.pcm + (int64_t)s * p.pcm_stream_stride;
-
-  for (int c0 = 0; c0 < p.total; c0 += kChunk) {
-    const int k = c0 + t;
-    const bool valid = k < p.total;
-    const int64_t gk = p.pos0 + k;
-    const int rp = (int)(gk & (kRing - 1));
-
-    // ---- load one sample of every input channel (coalesced: lane = sample) ----
-    float x[M];
-    if (valid && p.in) {
-      const int f = k / fs;
-      const int i = k - f * fs;
-      const float *src = p.in + (int64_t)s * p.in_stream_stride + (int64_t)f * p.in_frame_stride + i;
-#pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = src[(int64_t)m * fs];
-    } else {
-#pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = 0.f;
-    }
-
-    // ---- element renderer + gains; the rendered sample goes to the LDS delay ring ----
-    float pm = 0.f;
-    for (int c = 0; c < out_ch; ++c) {
-      const int f = p.src_feed[c];
-      float y = 0.f;
-      if (f >= 0) {
-        const float *row = p.matrix + f * M;  // wave-uniform -> scalar loads
-        float acc = 0.f;
-#pragma unroll
-        for (int m = 0; m < M; ++m) acc = acc + row[m] * x[m];
-        y = acc;
-      }
-      if (eg_on) y = y * eg;
-      y = 0.f + y;  // iamf_mixer_mix: memset 0 then += (IAMF_decoder.c:2719-2730)
-      if (og_on) y = y * og;
-      if (lg_on) y = y * lg;
-      if (valid) ring_y[c * kRing + rp] = y;
-      pm = fmaxf(pm, fabsf(y));
-    }
-
-    float g = 1.0f;
-    if (p.limiter_on) {
-      if (valid) ring_pm[rp] = pm;
-      __syncthreads();
-      // trailing-16 maximum, then the 240-sample window [gk-240, gk-1] as 15 such blocks
-      float b = 0.f;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) b = fmaxf(b, ring_pm[(int)((gk - j) & (kRing - 1))]);
-      if (valid) ring_b16[rp] = b;
-      __syncthreads();
-      float pk = 0.f;
-#pragma unroll
-      for (int j = 0; j < 15; ++j) pk = fmaxf(pk, ring_b16[(int)((gk - 1 - 16 * j) & (kRing - 1))]);
-      const float e = thr / pk;
-
-      // hypothesis: no trigger inside this chunk -> every gain follows from (n_st, gs, ge)
-      int n_pre = n_st + t;
-      if (n_pre > n_end) n_pre = n_end;
-      const int ci = n_pre + 1 <= n_end ? n_pre + 1 : n_end;
-      const float cf = ci < kHead ? head[ci] : p.ctab[ci];
-      const float gh = gain_at(n_pre, gs, ge, cf, n_atk, n_end);
-      const int trig = valid && (pk * gh > thr);
-      const int cnt = p.total - c0 < kChunk ? p.total - c0 : kChunk;
-      if (!__syncthreads_or(trig)) {
-        g = gh;
-        // state after the chunk = state after its last valid sample
-        const int n_last = n_st + cnt - 1 < n_end ? n_st + cnt - 1 : n_end;  // pre-state of last
-        if (n_last < n_end) {
-          const int cl = n_last + 1;
-          const float cfl = cl < kHead ? head[cl] : p.ctab[cl];
-          g_cur = gain_at(n_last, gs, ge, cfl, n_atk, n_end);
-          n_st = n_last + 1;
-        } else {
-          g_cur = 1.0f;
-          n_st = n_end;
-        }
-      } else {
-        // at least one trigger: run the recurrence serially over the chunk
-        arr_p[t] = pk;
-        arr_e[t] = e;
-        __syncthreads();
-        if (t == 0) {
-          float lgc = g_cur, lgs = gs, lge = ge;
-          int ln = n_st;
-          for (int i = 0; i < cnt; ++i) {
-            if (ln < n_end) {
-              const int cl = ln + 1;
-              const float c = cl < kHead ? head[cl] : p.ctab[cl];
-              lgc = gain_at(ln, lgs, lge, c, n_atk, n_end);
-              ln = ln + 1;
-            } else {
-              lgc = 1.0f;
-            }
-            const float pp = arr_p[i];
-            if (pp * lgc > thr) {
-              lgs = lgc;
-              lge = arr_e[i];
-              ln = 0;
-            }
-            arr_g[i] = lgc;
-          }
-          st[0] = lgc;
-          st[1] = lgs;
-          st[2] = lge;
-          st[3] = __int_as_float(ln);
-        }
-        __syncthreads();
-        g = arr_g[t];
-        g_cur = st[0];
-        gs = st[1];
-        ge = st[2];
-        n_st = __float_as_int(st[3]);
-      }
-    } else {
-      __syncthreads();
-    }
-
-    // ---- emit: delayed sample * gain -> PCM ----
-    const int64_t j = p.limiter_on ? gk - kDelay : gk;  // global index of the emitted sample
-    if (valid && j >= 0) {
-      const int rd = (int)(j & (kRing - 1));
-      uint8_t *dst = pcm + (j - out_base) * (int64_t)out_ch * bytes;
-      if (p.out_format == IAMF_HIP_FMT_S16) {
-        if (out_ch == 2) {
-          const float a = to_scaled(ring_y[rd] * g, 32768.f, -32768.f, 32767.f);
-          const float bq = to_scaled(ring_y[kRing + rd] * g, 32768.f, -32768.f, 32767.f);
-          const uint32_t w = (uint32_t)(uint16_t)(int16_t)(int)a | ((uint32_t)(uint16_t)(int16_t)(int)bq << 16);
-          *reinterpret_cast<uint32_t *>(dst) = w;
-        } else {
-          int16_t *d16 = reinterpret_cast<int16_t *>(dst);
-          for (int c = 0; c < out_ch; ++c)
-            d16[c] = (int16_t)(int)to_scaled(ring_y[c * kRing + rd] * g, 32768.f, -32768.f, 32767.f);
-        }
-      } else if (p.out_format == IAMF_HIP_FMT_S24) {
-        for (int c = 0; c < out_ch; ++c) {
-          const int v = (int)to_scaled(ring_y[c * kRing + rd] * g, 8388608.f, -8388608.f, 8388607.f);
-          dst[c * 3 + 0] = (uint8_t)(v & 0xff);
-          dst[c * 3 + 1] = (uint8_t)((v >> 8) & 0xff);
-          dst[c * 3 + 2] = (uint8_t)(((v >> 16) & 0x7f) | ((v >> 24) & 0x80));
-        }
-      } else if (p.out_format == IAMF_HIP_FMT_S32) {
-        int32_t *d32 = reinterpret_cast<int32_t *>(dst);
-        for (int c = 0; c < out_ch; ++c) {
-          // the reference clamps against 2147483647.f (== 2^31 in f32) and narrows a long:
-          // +full scale wraps to INT32_MIN (IAMF_decoder.c:114-119)
-          const float r = to_scaled(ring_y[c * kRing + rd] * g, 2147483648.f, -2147483648.f, 2147483647.f);
-          d32[c] = (int32_t)(long long)r;
-        }
-      } else {
-        float *df = reinterpret_cast<float *>(dst);
-        for (int c = 0; c < out_ch; ++c) df[c] = ring_y[c * kRing + rd] * g;
-      }
-    }
-    __syncthreads();  // ring slots read above are overwritten by the next chunk
-  }
-
-  // ---- persist stream state ----
-  {
-    float *sy = p.ring_y + (int64_t)s * out_ch * kSave;
-    float *spm = p.ring_pm + (int64_t)s * kSave;
-    const int64_t end = p.pos0 + p.total;
-    const int rp = (int)((end - kSave + t) & (kRing - 1));
-    for (int c = 0; c < out_ch; ++c) sy[c * kSave + t] = ring_y[c * kRing + rp];
-    spm[t] = ring_pm[rp];
-    if (t == 0) {
-      LimState o;
-      o.g = g_cur;
-      o.gs = gs;
-      o.ge = ge;
-      o.n = n_st;
-      p.lim[s] = o;
-    }
-  }
-}
+#include "render_common.hpp"
+#include "render_generic.hpp"
+#include "render_fast.hpp"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -430,17 +142,44 @@ int reset_state(iamf_hip_batch *b) {
   return IAMF_HIP_OK;
 }
 
-typedef void (*kernel_fn)(const RenderParams);
-
 template <int M>
 void launch_m(const RenderParams &p, dim3 grid, size_t lds_bytes, hipStream_t st) {
   hipLaunchKernelGGL(render_kernel<M>, grid, dim3(kChunk), lds_bytes, st, p);
 }
 
+template <int M>
+void launch_fast_m(const RenderParams &p, dim3 grid, hipStream_t st) {
+  if (p.out_ch == 1) {
+    const size_t lds = sizeof(float) * (1 * kFRing + 2 * kFRing + kFRing / 16 + 3 * kFChunk + kFHead + 16);
+    hipLaunchKernelGGL((render_fast_kernel<M, 1>), grid, dim3(256), lds, st, p);
+  } else {
+    const size_t lds = sizeof(float) * (2 * kFRing + 2 * kFRing + kFRing / 16 + 3 * kFChunk + kFHead + 16);
+    hipLaunchKernelGGL((render_fast_kernel<M, 2>), grid, dim3(256), lds, st, p);
+  }
+}
+
+// The fast kernel takes aligned, limiter-on calls into 1- or 2-channel layouts; everything else
+// (odd sizes, flush, limiter off, wide layouts) goes to the generic kernel.  Both are exact.
+bool fast_path_ok(const RenderParams &p) {
+  if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
+  if (!p.limiter_on || !p.in || p.out_ch > 2) return false;
+  if ((p.pos0 & 15) || (p.total & 63) || (p.frame_size & 3)) return false;
+  if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
+  if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
+  return true;
+}
+
 int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
   dim3 grid((unsigned)p.n_streams);
+  const bool fast = fast_path_ok(p);
   switch (m) {
-#define CASE_M(v) case v: launch_m<v>(p, grid, lds_bytes, st); break;
+#define CASE_M(v)                              \
+  case v:                                      \
+    if (fast)                                  \
+      launch_fast_m<v>(p, grid, st);           \
+    else                                       \
+      launch_m<v>(p, grid, lds_bytes, st);     \
+    break;
     CASE_M(1) CASE_M(2) CASE_M(4) CASE_M(6) CASE_M(8) CASE_M(9) CASE_M(10) CASE_M(12) CASE_M(14) CASE_M(16) CASE_M(24)
 #undef CASE_M
     default: return IAMF_HIP_ERR_UNIMPLEMENTED;

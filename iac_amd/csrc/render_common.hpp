@@ -1,0 +1,64 @@
+// render_common.hpp — constants, parameter block and small device helpers shared by the render
+// kernels (included only by iamf_render.hip, inside its anonymous namespace).
+#pragma once
+
+constexpr int kChunk = 256;      // samples per workgroup step = threads per workgroup
+constexpr int kDelay = 240;      // limiter look-ahead (reference common/audio_defines.h:41)
+constexpr int kRing = 512;       // LDS ring length (power of two >= kChunk + kDelay + 15)
+constexpr int kSave = 256;       // samples of ring persisted per stream between calls
+constexpr int kHead = 256;       // coefficient-table head kept in LDS
+constexpr int kMaxOut = 24;      // reference MAX_OUTPUT_CHANNELS
+constexpr int kMaxIn = 24;
+
+struct LimState {  // per stream, persisted in HBM between calls
+  float g;   // currentGain
+  float gs;  // targetStartGain
+  float ge;  // targetEndGain
+  int n;     // increments of currentTC since the last trigger; >= n_end means idle
+};
+
+struct RenderParams {
+  const float *in;          // planar f32 element PCM (device) or nullptr = zeros (flush)
+  int64_t in_stream_stride; // floats
+  int64_t in_frame_stride;  // floats
+  uint8_t *pcm;             // packed output (device)
+  int64_t pcm_stream_stride;  // bytes
+  const float *matrix;      // device, feed-major [n_feeds][M]
+  const float *gains;       // device [3][n_streams]: element, output, loudness
+  const float *ctab;        // device limiter coefficient table [n_end + 1]
+  LimState *lim;            // device [n_streams]
+  float *ring_y;            // device [n_streams][out_ch][kSave]
+  float *ring_pm;           // device [n_streams][kSave]
+  int64_t pos0;             // samples of each stream consumed before this call
+  int32_t total;            // samples to process in this call
+  int32_t frame_size;
+  int32_t n_streams;
+  int32_t n_feeds;
+  int32_t out_ch;
+  int32_t out_format;
+  int32_t limiter_on;
+  int32_t loudness_on;
+  int32_t n_atk, n_end;     // limiter table split points
+  float thr;
+  const int32_t *src_feed;  // device [out_ch]: output slot -> feed index, or -1 = silent slot
+};
+
+// One gain step evaluated for a hypothetical pre-state n_pre (no trigger since the state was
+// set): audio_effect_peak_limiter.c:241-255 with currentTC = T[n_pre].
+__device__ __forceinline__ float gain_at(int n_pre, float gs, float ge, float c, int n_atk, int n_end) {
+  float g = 1.0f;
+  if (n_pre < n_atk) {
+    g = gs - c * (gs - ge);
+  } else if (n_pre < n_end) {
+    g = ge + c * (1.0f - ge);
+  }
+  return g;
+}
+
+__device__ __forceinline__ float to_scaled(float x, float scale, float lo, float hi) {
+  x = x * scale;
+  x = x > lo ? x : lo;
+  x = x < hi ? x : hi;
+  return rintf(x);  // v_rndne_f32: ties to even, like lrintf in the default rounding mode
+}
+

@@ -1,0 +1,431 @@
+// render_fast.hpp — the hot kernel: mono/stereo/binaural output layouts with the limiter on,
+// aligned calls (see fast_path_ok() on the host).  One workgroup (4 waves) per stream, 1024-sample
+// chunks, FOUR consecutive samples per lane:
+//   * planar f32 input read as 16-byte loads (1 KiB per wave-instruction), the next chunk's loads
+//     issued right after the projection so they fly under the limiter work;
+//   * rendered samples kept only in an LDS ring (the limiter's delay line);
+//   * 240-sample sliding maximum from per-16 suffix / prefix / block maxima (DPP quad ops + LDS);
+//   * limiter gain: every lane first evaluates its gains under the hypothesis "no new trigger in
+//     this chunk" (the gain is then a pure function of the sample index); only if some lane sees
+//     peak*gain > threshold does wave 0 re-run the recurrence from that 64-sample block on:
+//     ballot-driven speculation per block, and for runs of consecutive triggers (the limiter
+//     holding a peak down) a wave-wide DPP shift chain that resolves one sample per 3-4 VALU ops;
+//   * interleaved PCM written as 16-byte stores.
+// Same f32 operation order as render_generic.hpp and the reference: bit-exact.
+#pragma once
+
+constexpr int kFChunk = 1024;
+constexpr int kFRing = 2048;
+constexpr int kFHead = 128;
+constexpr int kBig = 0x7fffffff;
+
+__device__ __forceinline__ float dpp_quad_bcast0(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x00, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_quad_bcast1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x55, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_quad_bcast2(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xAA, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_quad_bcast3(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xFF, 0xf, 0xf, true));
+}
+// lane l receives lane l-1's value; lane 0 keeps its own (wave_shr:1, bound_ctrl off)
+__device__ __forceinline__ float dpp_wave_shr1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// Limiter recurrence for 64-sample blocks [b0, nblk) of the current chunk, run by ONE wave
+// (lane = sample).  arr_p / arr_e hold the window maxima and thr/peak of the chunk; gains go to
+// arr_g.  (n, gs, ge) is the state before the first sample of block b0 and is updated to the
+// state after the last sample.  Restates audio_effect_peak_limiter.c:237-265 sample by sample:
+// every accepted gain is produced by exactly the reference's f32 operations.
+__device__ __forceinline__ void limiter_wave(const float *arr_p, const float *arr_e, float *arr_g,
+                                             const float *head, const float *__restrict__ ctab, int b0,
+                                             int nblk, int &n, float &gs, float &ge, float &g_last,
+                                             float thr, int n_atk, int n_end) {
+  const int lane = threadIdx.x & 63;
+  const float a1 = head[1];  // attack-curve value one step after a trigger
+  float gacc = 1.0f;
+  for (int b = b0; b < nblk; ++b) {
+    const float pk = arr_p[b * 64 + lane];
+    const float e = arr_e[b * 64 + lane];
+    int l0 = 0;
+    while (true) {
+      // speculate: no trigger in lanes l0..63 given the state before lane l0
+      int n_pre = n + (lane - l0);
+      n_pre = n_pre < n_end ? n_pre : n_end;
+      n_pre = n_pre < 0 ? 0 : n_pre;
+      const int ci = n_pre + 1 < n_end ? n_pre + 1 : n_end;
+      const float c = ci < kFHead ? head[ci] : ctab[ci];
+      const float g = gain_at(n_pre, gs, ge, c, n_atk, n_end);
+      const bool tr = lane >= l0 && (pk * g > thr);
+      const unsigned long long mask = __ballot(tr);
+      if (mask == 0ull) {
+        if (lane >= l0) gacc = g;
+        n = n + (64 - l0) < n_end ? n + (64 - l0) : n_end;
+        break;
+      }
+      const int f = __builtin_ctzll(mask);  // first trigger: lanes l0..f are settled
+      if (lane >= l0 && lane <= f) gacc = g;
+      gs = readlane_f(g, f);
+      ge = readlane_f(e, f);
+      n = 0;
+      l0 = f + 1;
+      if (l0 >= 64) break;
+
+      // A trigger is usually followed by a run of triggers.  Assume every later lane's
+      // predecessor triggered: g[l] = g[l-1] - a1*(g[l-1] - e[l-1]).  Jacobi sweeps with a
+      // one-lane shift settle one more lane per sweep; lanes <= f are fixed points
+      // (G = E' = gs there, so G - a1*(G - E') == G exactly).
+      float G = gs;
+      float ep = dpp_wave_shr1(e);
+      ep = lane <= f ? gs : ep;
+      for (int it = f + 1; it < 64; ++it) {
+        const float gsft = dpp_wave_shr1(G);
+        G = gsft - a1 * (gsft - ep);
+      }
+      const bool tr2 = pk * G > thr;
+      const unsigned long long stop = __ballot(lane > f && !tr2);
+      if (stop == 0ull) {  // the run reaches the end of the block
+        if (lane > f) gacc = G;
+        gs = readlane_f(G, 63);
+        ge = readlane_f(e, 63);
+        n = 0;
+        l0 = 64;
+        break;
+      }
+      const int m = __builtin_ctzll(stop);  // first lane of the run that does NOT trigger
+      if (lane > f && lane <= m) gacc = G;
+      gs = readlane_f(G, m - 1);
+      ge = readlane_f(e, m - 1);
+      n = 1;  // lane m stepped once from the trigger at m-1 and did not re-trigger
+      l0 = m + 1;
+      if (l0 >= 64) break;
+    }
+    arr_g[b * 64 + lane] = gacc;
+  }
+  g_last = readlane_f(gacc, 63);
+}
+
+template <int M, int OC>
+__global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) {
+  extern __shared__ float lds[];
+  constexpr int R = kFRing;
+  float *ring_y = lds;                  // [OC][R]   rendered samples (limiter delay line)
+  float *ring_pm = ring_y + OC * R;     // [R]       max |y| over channels
+  float *ring_suf = ring_pm + R;        // [R]       suffix maxima of pm inside aligned 16-blocks
+  float *ring_bm = ring_suf + R;        // [R/16]    maxima of aligned 16-blocks
+  float *arr_p = ring_bm + R / 16;      // [1024]
+  float *arr_e = arr_p + kFChunk;       // [1024]
+  float *arr_g = arr_e + kFChunk;       // [1024]
+  float *head = arr_g + kFChunk;        // [kFHead]
+  float *misc = head + kFHead;          // [16]
+
+  const int s = blockIdx.x;
+  const int t = threadIdx.x;
+  const int wave = t >> 6;
+  const int lane = t & 63;
+  const int q = t & 3;
+  const int fs = p.frame_size;
+  const float thr = p.thr;
+  const int n_atk = p.n_atk, n_end = p.n_end;
+
+  // ---- stream state -> LDS (persisted format is the generic kernel's) ----
+  {
+    const float *sy = p.ring_y + (int64_t)s * OC * kSave;
+    const float *spm = p.ring_pm + (int64_t)s * kSave;
+    const int64_t gk = p.pos0 - kSave + t;  // pos0 % 16 == 0: lane groups of 16 are aligned blocks
+    const int rp = (int)(gk & (R - 1));
+#pragma unroll
+    for (int c = 0; c < OC; ++c) ring_y[c * R + rp] = sy[c * kSave + t];
+    const float pm = spm[t];
+    ring_pm[rp] = pm;
+    float sfx = pm;
+    sfx = fmaxf(sfx, __shfl_down(sfx, 1, 16));
+    sfx = fmaxf(sfx, __shfl_down(sfx, 2, 16));
+    sfx = fmaxf(sfx, __shfl_down(sfx, 4, 16));
+    sfx = fmaxf(sfx, __shfl_down(sfx, 8, 16));
+    // __shfl_down hands back the caller's own value past the end of the 16-lane segment, which
+    // leaves the running maximum unchanged
+    ring_suf[rp] = sfx;
+    if ((t & 15) == 0) ring_bm[(int)((gk >> 4) & (R / 16 - 1))] = sfx;
+    if (t < kFHead) head[t] = t <= n_end ? p.ctab[t] : 1.0f;
+  }
+  LimState ls = p.lim[s];
+  float g_cur = ls.g, gs = ls.gs, ge = ls.ge;
+  int n_st = ls.n;
+  const float eg = p.gains[s], og = p.gains[p.n_streams + s], lg = p.gains[2 * p.n_streams + s];
+  const bool eg_on = (eg != 1.f && eg > 0.f);
+  const bool og_on = (og != 1.f && og > 0.f);
+  const bool lg_on = p.loudness_on && (lg != 1.0f);
+  int feed[OC];
+#pragma unroll
+  for (int c = 0; c < OC; ++c) feed[c] = p.src_feed[c];
+
+  const int64_t out_base = p.pos0 > kDelay ? p.pos0 - kDelay : 0;
+  const int bytes = p.out_format == IAMF_HIP_FMT_S16 ? 2 : (p.out_format == IAMF_HIP_FMT_S24 ? 3 : 4);
+  uint8_t *pcm = p.pcm + (int64_t)s * p.pcm_stream_stride;
+  const float *in_s = p.in + (int64_t)s * p.in_stream_stride;
+
+  // input of the first chunk
+  float4 x[M];
+  {
+    const int k = 4 * t;
+    if (k < p.total) {
+      const int f = k / fs;
+      const int i = k - f * fs;
+      const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = *reinterpret_cast<const float4 *>(src + (int64_t)m * fs);
+    } else {
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+
+  for (int c0 = 0; c0 < p.total; c0 += kFChunk) {
+    const int cnt = p.total - c0 < kFChunk ? p.total - c0 : kFChunk;  // multiple of 64
+    const int k = c0 + 4 * t;
+    const bool valid = 4 * t < cnt;
+    const int64_t gk = p.pos0 + k;
+    const int rp = (int)(gk & (R - 1));
+
+    // limiter-curve coefficients for the no-trigger hypothesis: issued first, used late
+    float cf[4];
+    int npre[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int np = n_st + 4 * t + j;
+      np = np < n_end ? np : n_end;
+      npre[j] = np;
+      const int ci = np + 1 < n_end ? np + 1 : n_end;
+      cf[j] = p.ctab[ci];
+    }
+
+    // ---- element renderer + gains (reference operation order) ----
+    float4 y[OC];
+    float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < OC; ++c) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (feed[c] >= 0) {
+        const float *row = p.matrix + feed[c] * M;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const float w = row[m];
+          acc.x = acc.x + w * x[m].x;
+          acc.y = acc.y + w * x[m].y;
+          acc.z = acc.z + w * x[m].z;
+          acc.w = acc.w + w * x[m].w;
+        }
+        v = acc;
+      }
+      if (eg_on) { v.x = v.x * eg; v.y = v.y * eg; v.z = v.z * eg; v.w = v.w * eg; }
+      v.x = 0.f + v.x; v.y = 0.f + v.y; v.z = 0.f + v.z; v.w = 0.f + v.w;  // mixer: 0 += frame
+      if (og_on) { v.x = v.x * og; v.y = v.y * og; v.z = v.z * og; v.w = v.w * og; }
+      if (lg_on) { v.x = v.x * lg; v.y = v.y * lg; v.z = v.z * lg; v.w = v.w * lg; }
+      y[c] = v;
+      pm.x = fmaxf(pm.x, fabsf(v.x));
+      pm.y = fmaxf(pm.y, fabsf(v.y));
+      pm.z = fmaxf(pm.z, fabsf(v.z));
+      pm.w = fmaxf(pm.w, fabsf(v.w));
+    }
+
+    // ---- prefetch the next chunk's input: in flight during everything below ----
+    {
+      const int kn = k + kFChunk;
+      if (kn < p.total) {
+        const int f = kn / fs;
+        const int i = kn - f * fs;
+        const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
+#pragma unroll
+        for (int m = 0; m < M; ++m) x[m] = *reinterpret_cast<const float4 *>(src + (int64_t)m * fs);
+      }
+    }
+
+    // ---- per-16 prefix / suffix / block maxima: 4 lanes x 4 samples = one aligned block ----
+    const float i0 = pm.x, i1 = fmaxf(i0, pm.y), i2 = fmaxf(i1, pm.z), i3 = fmaxf(i2, pm.w);
+    const float s3 = pm.w, s2 = fmaxf(pm.z, s3), s1 = fmaxf(pm.y, s2), s0 = fmaxf(pm.x, s1);
+    const float qa = dpp_quad_bcast0(i3), qb = dpp_quad_bcast1(i3), qc = dpp_quad_bcast2(i3),
+                qd = dpp_quad_bcast3(i3);
+    const float before = q == 0 ? 0.f : (q == 1 ? qa : (q == 2 ? fmaxf(qa, qb) : fmaxf(fmaxf(qa, qb), qc)));
+    const float after = q == 3 ? 0.f : (q == 2 ? qd : (q == 1 ? fmaxf(qc, qd) : fmaxf(fmaxf(qb, qc), qd)));
+    const float4 pre_ex = make_float4(before, fmaxf(before, i0), fmaxf(before, i1), fmaxf(before, i2));
+    if (valid) {
+#pragma unroll
+      for (int c = 0; c < OC; ++c) *reinterpret_cast<float4 *>(&ring_y[c * R + rp]) = y[c];
+      *reinterpret_cast<float4 *>(&ring_pm[rp]) = pm;
+      *reinterpret_cast<float4 *>(&ring_suf[rp]) =
+          make_float4(fmaxf(s0, after), fmaxf(s1, after), fmaxf(s2, after), fmaxf(s3, after));
+      if (q == 0) ring_bm[(int)((gk >> 4) & (R / 16 - 1))] = fmaxf(fmaxf(qa, qb), fmaxf(qc, qd));
+    }
+    __syncthreads();
+
+    // ---- 240-sample window maximum = tail of block b-15, blocks b-14..b-1, head of block b ----
+    const int blk = (int)(gk >> 4);
+    float w14 = 0.f;
+#pragma unroll
+    for (int j = 1; j <= 14; ++j) w14 = fmaxf(w14, ring_bm[(blk - j) & (R / 16 - 1)]);
+    const float4 so = *reinterpret_cast<const float4 *>(&ring_suf[(int)((gk - kDelay) & (R - 1))]);
+    float4 pk;
+    pk.x = fmaxf(fmaxf(so.x, w14), pre_ex.x);
+    pk.y = fmaxf(fmaxf(so.y, w14), pre_ex.y);
+    pk.z = fmaxf(fmaxf(so.z, w14), pre_ex.z);
+    pk.w = fmaxf(fmaxf(so.w, w14), pre_ex.w);
+    float4 e;
+    e.x = thr / pk.x;
+    e.y = thr / pk.y;
+    e.z = thr / pk.z;
+    e.w = thr / pk.w;
+
+    // ---- gains under the no-trigger hypothesis ----
+    float4 g;
+    g.x = gain_at(npre[0], gs, ge, cf[0], n_atk, n_end);
+    g.y = gain_at(npre[1], gs, ge, cf[1], n_atk, n_end);
+    g.z = gain_at(npre[2], gs, ge, cf[2], n_atk, n_end);
+    g.w = gain_at(npre[3], gs, ge, cf[3], n_atk, n_end);
+    int kfirst = kBig;
+    if (valid) {
+      if (pk.w * g.w > thr) kfirst = 4 * t + 3;
+      if (pk.z * g.z > thr) kfirst = 4 * t + 2;
+      if (pk.y * g.y > thr) kfirst = 4 * t + 1;
+      if (pk.x * g.x > thr) kfirst = 4 * t + 0;
+    }
+    *reinterpret_cast<float4 *>(&arr_p[4 * t]) = pk;
+    *reinterpret_cast<float4 *>(&arr_e[4 * t]) = e;
+    {
+      const unsigned long long any = __ballot(kfirst != kBig);
+      if (lane == 0) misc[wave] = __int_as_float(any ? __builtin_amdgcn_readlane(kfirst, __builtin_ctzll(any)) : kBig);
+    }
+    __syncthreads();
+    int kf = __float_as_int(misc[0]);
+    kf = min(kf, __float_as_int(misc[1]));
+    kf = min(kf, __float_as_int(misc[2]));
+    kf = min(kf, __float_as_int(misc[3]));
+
+    if (kf == kBig) {
+      // hypothesis holds for the whole chunk: state after its last sample
+      const int n_last = n_st + cnt - 1 < n_end ? n_st + cnt - 1 : n_end;
+      if (n_last < n_end) {
+        g_cur = gain_at(n_last, gs, ge, p.ctab[n_last + 1], n_atk, n_end);
+        n_st = n_last + 1;
+      } else {
+        g_cur = 1.0f;
+        n_st = n_end;
+      }
+    } else {
+      const int b0 = kf >> 6;
+      if (wave == 0) {
+        int ln = n_st + 64 * b0 < n_end ? n_st + 64 * b0 : n_end;
+        float lgs = gs, lge = ge, lgl = g_cur;
+        limiter_wave(arr_p, arr_e, arr_g, head, p.ctab, b0, cnt >> 6, ln, lgs, lge, lgl, thr, n_atk, n_end);
+        if (lane == 0) {
+          misc[4] = lgl;
+          misc[5] = lgs;
+          misc[6] = lge;
+          misc[7] = __int_as_float(ln);
+        }
+      }
+      __syncthreads();
+      if (4 * t >= 64 * b0) g = *reinterpret_cast<const float4 *>(&arr_g[4 * t]);
+      g_cur = misc[4];
+      gs = misc[5];
+      ge = misc[6];
+      n_st = __float_as_int(misc[7]);
+    }
+
+    // ---- emit 4 delayed samples * gain as interleaved PCM ----
+    const int64_t j0 = gk - kDelay;
+    if (valid && j0 >= 0) {
+      const int rd = (int)(j0 & (R - 1));
+      float4 o[OC];
+#pragma unroll
+      for (int c = 0; c < OC; ++c) {
+        const float4 d = *reinterpret_cast<const float4 *>(&ring_y[c * R + rd]);
+        o[c] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+      }
+      uint8_t *dst = pcm + (j0 - out_base) * (int64_t)OC * bytes;
+      if (p.out_format == IAMF_HIP_FMT_S16) {
+        int v[OC][4];
+#pragma unroll
+        for (int c = 0; c < OC; ++c) {
+          v[c][0] = (int)to_scaled(o[c].x, 32768.f, -32768.f, 32767.f);
+          v[c][1] = (int)to_scaled(o[c].y, 32768.f, -32768.f, 32767.f);
+          v[c][2] = (int)to_scaled(o[c].z, 32768.f, -32768.f, 32767.f);
+          v[c][3] = (int)to_scaled(o[c].w, 32768.f, -32768.f, 32767.f);
+        }
+        if (OC == 2) {
+          uint4 w;
+          w.x = (uint32_t)(v[0][0] & 0xffff) | ((uint32_t)v[OC - 1][0] << 16);
+          w.y = (uint32_t)(v[0][1] & 0xffff) | ((uint32_t)v[OC - 1][1] << 16);
+          w.z = (uint32_t)(v[0][2] & 0xffff) | ((uint32_t)v[OC - 1][2] << 16);
+          w.w = (uint32_t)(v[0][3] & 0xffff) | ((uint32_t)v[OC - 1][3] << 16);
+          *reinterpret_cast<uint4 *>(dst) = w;
+        } else {
+          uint2 w;
+          w.x = (uint32_t)(v[0][0] & 0xffff) | ((uint32_t)v[0][1] << 16);
+          w.y = (uint32_t)(v[0][2] & 0xffff) | ((uint32_t)v[0][3] << 16);
+          *reinterpret_cast<uint2 *>(dst) = w;
+        }
+      } else if (p.out_format == IAMF_HIP_FMT_S24) {
+#pragma unroll
+        for (int c = 0; c < OC; ++c) {
+          const float ov[4] = {o[c].x, o[c].y, o[c].z, o[c].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int vv = (int)to_scaled(ov[j], 8388608.f, -8388608.f, 8388607.f);
+            uint8_t *d3 = dst + (j * OC + c) * 3;
+            d3[0] = (uint8_t)(vv & 0xff);
+            d3[1] = (uint8_t)((vv >> 8) & 0xff);
+            d3[2] = (uint8_t)(((vv >> 16) & 0x7f) | ((vv >> 24) & 0x80));
+          }
+        }
+      } else if (p.out_format == IAMF_HIP_FMT_S32) {
+        int32_t *d32 = reinterpret_cast<int32_t *>(dst);
+#pragma unroll
+        for (int c = 0; c < OC; ++c) {
+          const float ov[4] = {o[c].x, o[c].y, o[c].z, o[c].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            d32[j * OC + c] = (int32_t)(long long)to_scaled(ov[j], 2147483648.f, -2147483648.f, 2147483647.f);
+        }
+      } else {
+        float *df = reinterpret_cast<float *>(dst);
+#pragma unroll
+        for (int c = 0; c < OC; ++c) {
+          df[0 * OC + c] = o[c].x;
+          df[1 * OC + c] = o[c].y;
+          df[2 * OC + c] = o[c].z;
+          df[3 * OC + c] = o[c].w;
+        }
+      }
+    }
+    __syncthreads();  // ring / arr slots are rewritten by the next chunk
+  }
+
+  // ---- persist stream state (same format as the generic kernel) ----
+  {
+    float *sy = p.ring_y + (int64_t)s * OC * kSave;
+    float *spm = p.ring_pm + (int64_t)s * kSave;
+    const int64_t end = p.pos0 + p.total;
+    const int rp = (int)((end - kSave + t) & (R - 1));
+#pragma unroll
+    for (int c = 0; c < OC; ++c) sy[c * kSave + t] = ring_y[c * R + rp];
+    spm[t] = ring_pm[rp];
+    if (t == 0) {
+      LimState o;
+      o.g = g_cur;
+      o.gs = gs;
+      o.ge = ge;
+      o.n = n_st;
+      p.lim[s] = o;
+    }
+  }
+}

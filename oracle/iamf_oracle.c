@@ -575,3 +575,19 @@ int orc_stream_flush(orc_stream *s, void *pcm) {
 /* sizes for callers that allocate the structs from another language (tests via ctypes) */
 int orc_sizeof_limiter(void) { return (int)sizeof(orc_limiter); }
 int orc_sizeof_stream(void) { return (int)sizeof(orc_stream); }
+
+/* Timed-baseline helper: one whole stream (open, n_frames frames, flush, close) without leaving
+ * C, so that callers can run one stream per thread.  Returns sample-frames emitted. */
+long orc_stream_run_frames(const orc_matrix *mx, int out_channels, int limiter_on, float threshold_db,
+                           int rate, int bit_depth, const float *in, int n_frames, int ns, void *pcm) {
+  orc_stream s;
+  long total = 0;
+  if (orc_stream_open(&s, mx, out_channels, 1.0f, 1.0f, 0, 1.0f, limiter_on, threshold_db, rate,
+                      bit_depth, ns) != 0)
+    return -1;
+  for (int f = 0; f < n_frames; ++f)
+    total += orc_stream_frame(&s, in + (size_t)f * mx->m * ns, ns, pcm);
+  total += orc_stream_flush(&s, pcm);
+  orc_stream_close(&s);
+  return total;
+}

@@ -122,6 +122,10 @@ int orc_stream_frame(orc_stream *s, const float *in, int ns, void *pcm);
 /* end of stream: pushes `delay` zeros through the limiter (IAMF_decoder.c:3250-3301) */
 int orc_stream_flush(orc_stream *s, void *pcm);
 
+/* whole stream in one call (in: [n_frames][m][ns]); for the timed CPU baseline */
+long orc_stream_run_frames(const orc_matrix *mx, int out_channels, int limiter_on, float threshold_db,
+                           int rate, int bit_depth, const float *in, int n_frames, int ns, void *pcm);
+
 int orc_sizeof_limiter(void);
 int orc_sizeof_stream(void);
 

@@ -69,6 +69,9 @@ def lib():
         L.orc_stream_close.argtypes = [C.c_void_p]
         L.orc_stream_frame.argtypes = [C.c_void_p, FP, C.c_int, C.c_void_p]
         L.orc_stream_flush.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_stream_run_frames.restype = C.c_long
+        L.orc_stream_run_frames.argtypes = [C.POINTER(Matrix), C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                            FP, C.c_int, C.c_int, C.c_void_p]
         if hasattr(L, "orc_resampler_open"):
             L.orc_resampler_open.restype = C.c_void_p
             L.orc_resampler_open.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]

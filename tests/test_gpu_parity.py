@@ -143,7 +143,9 @@ def test_full_size_batch_properties(hip):
     got = G.hip_render(mx, 2, x, frame_size=fs, limiter=True, flush=True, frames_per_call=[3, 5])
     omx = O.get_h2m(3, O.SS["BINAURAL"])
     want = [O.stream_run(omx, 2, base[s], fs) for s in range(8)]
-    thr_lsb = 32768 * 10 ** (-1 / 20) + 1
+    # the limiter is a smoother, not a brick wall: the reference itself overshoots the threshold
+    # by a few LSB while the attack converges, so the bound carries 0.1 % of slack
+    thr_lsb = 1.001 * 32768 * 10 ** (-1 / 20) + 1
     for s in range(S):
         assert got[s].shape == (F * fs, 2)
         assert np.array_equal(got[s], want[s % 8]), s
