@@ -50,6 +50,23 @@ def synth_hot_device(n_streams, in_ch, frames, fs, seed, device):
     return x.contiguous()
 
 
+def measured_traffic(kernel_tag, sf_per_step):
+    """HBM bytes per launch from the newest committed PMC summary (profiles/*_pmc.json, made by
+    tools/prof_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    same command), scaled to this run's launch size; None if no summary covers the kernel."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for name, v in d.get("pmc", {}).items():
+            if kernel_tag in name and "hbm_bytes_per_sample_frame" in v:
+                best = (v["hbm_bytes_per_sample_frame"] * sf_per_step, os.path.basename(f))
+    return best
+
+
 def cpu_baseline(workload, fs, seconds_target=12.0):
     """The oracle (oracle/liboracle.so: scalar C port of the reference loops) timed on this box's
     host cores on a bounded sample of the same workload: one stream per thread."""
@@ -189,6 +206,8 @@ def main():
         total_sf = sf_per_step * args.steps * world
         value = total_sf / elapsed / 1e6
         achieved = bytes_per_sf * sf_per_step / (kernel_ms * 1e-3) / 1e9
+        ktag = "render_fast_kernel<%d, %d>" % (in_ch, out_ch) if out_ch <= 2 else "render_kernel<%d>" % in_ch
+        traffic = measured_traffic(ktag, sf_per_step)
         out = {
             "metric": "Msamples/s rendered (3rd-order HOA->binaural, 48 kHz)",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -202,8 +221,12 @@ def main():
                        "signal": "hot (sigma 0.25 + 1.5 bursts)" if args.signal == "hot" else "quiet (sigma 0.05)", "parallelism": "streams sharded, dp%d" % world,
                        "gather": bool(gather_on)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": round(traffic[0]) if traffic else None,
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                         "traffic_source": traffic[1] if traffic else None,
+                         "algorithmic_bytes_per_launch": bytes_per_sf * sf_per_step,
+                         "kernel": ktag, "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_sample_frame": bytes_per_sf,
                          "frac_of_measured_copy_6290": round(achieved / 6290.0, 4)},
         }

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories (gpurun_out/prof/{trace,pmc_fetch,pmc_write}) into the
+small, committed summaries under profiles/.
+
+  python tools/prof_summary.py gpurun_out/prof profiles/r01_<tag>
+
+writes <out>_kernel_stats.csv (the --stats table, our kernels + top others), and <out>_pmc.json
+with per-launch FETCH_SIZE / WRITE_SIZE of the render kernels, corrected as
+/opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: both counters are in KiB; on gfx950
+FETCH_SIZE counts half of the bytes of 16-B-per-lane streaming reads, so read bytes = 2 x.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    summary = {}
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        keep = [r for r in rows if "render" in r["Name"] or "iamf" in r["Name"]]
+        keep += [r for r in rows if r not in keep][:4]
+        with open(out + "_kernel_stats.csv", "w") as f:
+            w = csv.DictWriter(f, fieldnames=rows[0].keys())
+            w.writeheader()
+            for r in keep:
+                r = dict(r)
+                r["Name"] = r["Name"][:120]
+                w.writerow(r)
+        for r in keep:
+            if "render" in r["Name"]:
+                summary.setdefault("kernels", {})[r["Name"][:80]] = {
+                    "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": int(r["MinNs"]),
+                    "max_ns": int(r["MaxNs"])}
+    pmc = {}
+    for kind, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        files = glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))
+        if not files:
+            continue
+        agg = collections.defaultdict(list)
+        meta = {}
+        for r in csv.DictReader(open(files[0])):
+            if "render" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                agg[r["Kernel_Name"][:80]].append(float(r["Counter_Value"]))
+                meta[r["Kernel_Name"][:80]] = {"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]),
+                                               "lds_block_bytes": int(r["LDS_Block_Size"]),
+                                               "workgroup": int(r["Workgroup_Size"]), "grid": int(r["Grid_Size"])}
+        for k, v in agg.items():
+            pmc.setdefault(k, {}).update(meta[k])
+            pmc[k][ctr + "_KiB_per_launch"] = sum(v) / len(v)
+            pmc[k][ctr + "_launches"] = len(v)
+    for k, v in pmc.items():
+        rd = 2.0 * 1024 * v.get("FETCH_SIZE_KiB_per_launch", 0.0)
+        wr = 1024 * v.get("WRITE_SIZE_KiB_per_launch", 0.0)
+        v["hbm_read_bytes_per_launch"] = rd
+        v["hbm_write_bytes_per_launch"] = wr
+        v["hbm_bytes_per_launch"] = rd + wr
+    summary["pmc"] = pmc
+    if len(sys.argv) > 3:
+        summary["command"] = sys.argv[3]
+    if len(sys.argv) > 4:  # sample-frames one launch processes: gives HBM bytes per sample-frame
+        sf = float(sys.argv[4])
+        summary["sample_frames_per_launch"] = sf
+        for v in pmc.values():
+            v["hbm_bytes_per_sample_frame"] = v["hbm_bytes_per_launch"] / sf
+    with open(out + "_pmc.json", "w") as f:
+        json.dump(summary, f, indent=1, sort_keys=True)
+    print(json.dumps(summary, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
