@@ -142,32 +142,23 @@ def main():
     stride_bytes = F * fs * out_ch * 2
     pcm = [torch.zeros((S, stride_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
     gather_on = world > 1 and not args.no_gather
-    gathered = None
-    if gather_on and rank == 0:
-        gathered = [[torch.empty_like(pcm[0]) for _ in range(world)] for _ in range(2)]
-    pending = [None, None]
+    from iac_amd.sharding import GatherPipeline
+    pipe = GatherPipeline(pcm, world, rank, enabled=gather_on)
     stream = torch.cuda.current_stream().cuda_stream
     stream_stride, frame_stride = F * in_ch * fs, in_ch * fs
 
-    def step(i):
-        b = i % 2
-        if pending[b] is not None:   # the gather that last read pcm[b] must be done
-            pending[b].wait()
-            pending[b] = None
-        n = batch.render(x.data_ptr(), stream_stride, frame_stride, F, pcm[b].data_ptr(), stride_bytes, stream)
-        if gather_on:
-            pending[b] = dist.gather(pcm[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
+    def render_into(buf, ev_pair=None):
+        # events bracket only the render kernel: the gather runs on RCCL's own stream
+        if ev_pair:
+            ev_pair[0].record()
+        n = batch.render(x.data_ptr(), stream_stride, frame_stride, F, buf.data_ptr(), stride_bytes, stream)
+        if ev_pair:
+            ev_pair[1].record()
         return n
 
-    def drain():
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
-
     for i in range(args.warmup):
-        step(i)
-    drain()
+        pipe.step(render_into)
+    pipe.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -177,23 +168,14 @@ def main():
     emitted = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # events bracket only the render kernel: the gather runs on RCCL's own stream
-        b = i % 2
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
-        ev[i][0].record()
-        n = batch.render(x.data_ptr(), stream_stride, frame_stride, F, pcm[b].data_ptr(), stride_bytes, stream)
-        ev[i][1].record()
-        if gather_on:
-            pending[b] = dist.gather(pcm[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
-        emitted += n
-    drain()
+        emitted += pipe.step(lambda buf, i=i: render_into(buf, ev[i]))
+    pipe.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    assert emitted == args.steps * F * fs, "every step must emit F*fs sample-frames per stream"
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
