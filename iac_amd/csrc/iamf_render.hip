@@ -149,20 +149,27 @@ void launch_m(const RenderParams &p, dim3 grid, size_t lds_bytes, hipStream_t st
 
 template <int M>
 void launch_fast_m(const RenderParams &p, dim3 grid, hipStream_t st) {
-  if (p.out_ch == 1) {
-    const size_t lds = sizeof(float) * (1 * kFRing + 2 * kFRing + kFRing / 16 + 3 * kFChunk + kFHead + 16);
-    hipLaunchKernelGGL((render_fast_kernel<M, 1>), grid, dim3(256), lds, st, p);
-  } else {
-    const size_t lds = sizeof(float) * (2 * kFRing + 2 * kFRing + kFRing / 16 + 3 * kFChunk + kFHead + 16);
-    hipLaunchKernelGGL((render_fast_kernel<M, 2>), grid, dim3(256), lds, st, p);
+  const size_t lds = sizeof(float) * (size_t)fast_lds_floats(p.out_ch, M, p.n_end + 1);
+  // more than 64 KiB of dynamic LDS has to be opted into per kernel (gfx950 has 160 KiB per CU)
+  static bool opted = false;
+  if (!opted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    opted = true;
   }
+  if (p.out_ch == 1)
+    hipLaunchKernelGGL((render_fast_kernel<M, 1>), grid, dim3(256), lds, st, p);
+  else
+    hipLaunchKernelGGL((render_fast_kernel<M, 2>), grid, dim3(256), lds, st, p);
 }
 
 // The fast kernel takes aligned, limiter-on calls into 1- or 2-channel layouts; everything else
 // (odd sizes, flush, limiter off, wide layouts) goes to the generic kernel.  Both are exact.
 bool fast_path_ok(const RenderParams &p) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
-  if (!p.limiter_on || !p.in || p.out_ch > 2) return false;
+  if (!p.limiter_on || !p.in || p.out_ch > 2 || p.n_end + 1 > kFTabMax) return false;
   if ((p.pos0 & 15) || (p.total & 63) || (p.frame_size & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;

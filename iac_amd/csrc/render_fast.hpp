@@ -15,8 +15,8 @@
 #pragma once
 
 constexpr int kFChunk = 1024;
-constexpr int kFRing = 2048;
-constexpr int kFHead = 128;
+constexpr int kFRing = 1280;   // >= chunk + look-ahead, multiple of 16 (not a power of two)
+constexpr int kFTabMax = 9984; // largest limiter table kept in LDS (48 kHz needs 9650 entries)
 constexpr int kBig = 0x7fffffff;
 
 __device__ __forceinline__ float dpp_quad_bcast0(float v) {
@@ -45,11 +45,10 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 // state after the last sample.  Restates audio_effect_peak_limiter.c:237-265 sample by sample:
 // every accepted gain is produced by exactly the reference's f32 operations.
 __device__ __forceinline__ void limiter_wave(const float *arr_p, const float *arr_e, float *arr_g,
-                                             const float *head, const float *__restrict__ ctab, int b0,
-                                             int nblk, int &n, float &gs, float &ge, float &g_last,
-                                             float thr, int n_atk, int n_end) {
+                                             const float *ctab, int b0, int nblk, int &n, float &gs,
+                                             float &ge, float &g_last, float thr, int n_atk, int n_end) {
   const int lane = threadIdx.x & 63;
-  const float a1 = head[1];  // attack-curve value one step after a trigger
+  const float a1 = ctab[1];  // attack-curve value one step after a trigger
   float gacc = 1.0f;
   for (int b = b0; b < nblk; ++b) {
     const float pk = arr_p[b * 64 + lane];
@@ -61,7 +60,7 @@ __device__ __forceinline__ void limiter_wave(const float *arr_p, const float *ar
       n_pre = n_pre < n_end ? n_pre : n_end;
       n_pre = n_pre < 0 ? 0 : n_pre;
       const int ci = n_pre + 1 < n_end ? n_pre + 1 : n_end;
-      const float c = ci < kFHead ? head[ci] : ctab[ci];
+      const float c = ctab[ci];
       const float g = gain_at(n_pre, gs, ge, c, n_atk, n_end);
       const bool tr = lane >= l0 && (pk * g > thr);
       const unsigned long long mask = __ballot(tr);
@@ -112,19 +111,34 @@ __device__ __forceinline__ void limiter_wave(const float *arr_p, const float *ar
   g_last = readlane_f(gacc, 63);
 }
 
+// LDS floats the fast kernel needs for an OC-channel layout, M inputs and a limiter table of
+// `tab` entries (host and device use the same carve-up)
+__host__ __device__ constexpr int fast_lds_floats(int oc, int m, int tab) {
+  return oc * kFRing + 2 * kFRing + kFRing / 16 + 3 * kFChunk + ((tab + 15) & ~15) + ((oc * m + 15) & ~15) + 16;
+}
+
+__device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
+  i = i < 0 ? i + kFRing : i;
+  return i >= kFRing ? i - kFRing : i;
+}
+
 template <int M, int OC>
 __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) {
   extern __shared__ float lds[];
   constexpr int R = kFRing;
+  constexpr int NB = R / 16;
+  const int n_atk = p.n_atk, n_end = p.n_end;
+  const int tab = (n_end + 1 + 15) & ~15;
   float *ring_y = lds;                  // [OC][R]   rendered samples (limiter delay line)
   float *ring_pm = ring_y + OC * R;     // [R]       max |y| over channels
   float *ring_suf = ring_pm + R;        // [R]       suffix maxima of pm inside aligned 16-blocks
   float *ring_bm = ring_suf + R;        // [R/16]    maxima of aligned 16-blocks
-  float *arr_p = ring_bm + R / 16;      // [1024]
-  float *arr_e = arr_p + kFChunk;       // [1024]
-  float *arr_g = arr_e + kFChunk;       // [1024]
-  float *head = arr_g + kFChunk;        // [kFHead]
-  float *misc = head + kFHead;          // [16]
+  float *arr_p = ring_bm + NB;          // [1024]    window maxima of the chunk
+  float *arr_e = arr_p + kFChunk;       // [1024]    thr / window maximum
+  float *arr_g = arr_e + kFChunk;       // [1024]    gains from the limiter wave
+  float *ctl = arr_g + kFChunk;         // [tab]     limiter curve table
+  float *mat = ctl + tab;               // [OC*M]    feed-major matrix rows of the OC slots
+  float *misc = mat + ((OC * M + 15) & ~15);  // [16]
 
   const int s = blockIdx.x;
   const int t = threadIdx.x;
@@ -133,19 +147,18 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
   const int q = t & 3;
   const int fs = p.frame_size;
   const float thr = p.thr;
-  const int n_atk = p.n_atk, n_end = p.n_end;
+  int base = (int)(p.pos0 % R);  // ring position of the chunk's first sample; multiple of 16
 
-  // ---- stream state -> LDS (persisted format is the generic kernel's) ----
+  // ---- stream state and constants -> LDS (persisted format is the generic kernel's) ----
   {
     const float *sy = p.ring_y + (int64_t)s * OC * kSave;
     const float *spm = p.ring_pm + (int64_t)s * kSave;
-    const int64_t gk = p.pos0 - kSave + t;  // pos0 % 16 == 0: lane groups of 16 are aligned blocks
-    const int rp = (int)(gk & (R - 1));
+    const int rp = ring_wrap(base - kSave + t);  // saved entry t is sample pos0 - 256 + t
 #pragma unroll
     for (int c = 0; c < OC; ++c) ring_y[c * R + rp] = sy[c * kSave + t];
     const float pm = spm[t];
     ring_pm[rp] = pm;
-    float sfx = pm;
+    float sfx = pm;  // pos0 % 16 == 0: 16-lane groups are aligned 16-blocks
     sfx = fmaxf(sfx, __shfl_down(sfx, 1, 16));
     sfx = fmaxf(sfx, __shfl_down(sfx, 2, 16));
     sfx = fmaxf(sfx, __shfl_down(sfx, 4, 16));
@@ -153,8 +166,13 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     // __shfl_down hands back the caller's own value past the end of the 16-lane segment, which
     // leaves the running maximum unchanged
     ring_suf[rp] = sfx;
-    if ((t & 15) == 0) ring_bm[(int)((gk >> 4) & (R / 16 - 1))] = sfx;
-    if (t < kFHead) head[t] = t <= n_end ? p.ctab[t] : 1.0f;
+    if ((t & 15) == 0) ring_bm[rp >> 4] = sfx;
+    for (int i = t; i <= n_end; i += 256) ctl[i] = p.ctab[i];
+    if (t < OC * M) {
+      const int c = t / M, m = t - c * M;
+      const int f = p.src_feed[c];
+      mat[t] = f >= 0 ? p.matrix[f * M + m] : 0.f;
+    }
   }
   LimState ls = p.lim[s];
   float g_cur = ls.g, gs = ls.gs, ge = ls.ge;
@@ -163,9 +181,9 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
   const bool eg_on = (eg != 1.f && eg > 0.f);
   const bool og_on = (og != 1.f && og > 0.f);
   const bool lg_on = p.loudness_on && (lg != 1.0f);
-  int feed[OC];
+  bool live[OC];
 #pragma unroll
-  for (int c = 0; c < OC; ++c) feed[c] = p.src_feed[c];
+  for (int c = 0; c < OC; ++c) live[c] = p.src_feed[c] >= 0;
 
   const int64_t out_base = p.pos0 > kDelay ? p.pos0 - kDelay : 0;
   const int bytes = p.out_format == IAMF_HIP_FMT_S16 ? 2 : (p.out_format == IAMF_HIP_FMT_S24 ? 3 : 4);
@@ -194,19 +212,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     const int k = c0 + 4 * t;
     const bool valid = 4 * t < cnt;
     const int64_t gk = p.pos0 + k;
-    const int rp = (int)(gk & (R - 1));
-
-    // limiter-curve coefficients for the no-trigger hypothesis: issued first, used late
-    float cf[4];
-    int npre[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int np = n_st + 4 * t + j;
-      np = np < n_end ? np : n_end;
-      npre[j] = np;
-      const int ci = np + 1 < n_end ? np + 1 : n_end;
-      cf[j] = p.ctab[ci];
-    }
+    const int rp = ring_wrap(base + 4 * t);
 
     // ---- element renderer + gains (reference operation order) ----
     float4 y[OC];
@@ -214,12 +220,11 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
 #pragma unroll
     for (int c = 0; c < OC; ++c) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (feed[c] >= 0) {
-        const float *row = p.matrix + feed[c] * M;
+      if (live[c]) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-          const float w = row[m];
+          const float w = mat[c * M + m];
           acc.x = acc.x + w * x[m].x;
           acc.y = acc.y + w * x[m].y;
           acc.z = acc.z + w * x[m].z;
@@ -238,7 +243,8 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
       pm.w = fmaxf(pm.w, fabsf(v.w));
     }
 
-    // ---- prefetch the next chunk's input: in flight during everything below ----
+    // ---- prefetch the next chunk's input: the ONLY vector-memory loads of the loop, so they
+    //      stay in flight under everything below (the in-order vmcnt never has to drain them) ----
     {
       const int kn = k + kFChunk;
       if (kn < p.total) {
@@ -264,16 +270,21 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
       *reinterpret_cast<float4 *>(&ring_pm[rp]) = pm;
       *reinterpret_cast<float4 *>(&ring_suf[rp]) =
           make_float4(fmaxf(s0, after), fmaxf(s1, after), fmaxf(s2, after), fmaxf(s3, after));
-      if (q == 0) ring_bm[(int)((gk >> 4) & (R / 16 - 1))] = fmaxf(fmaxf(qa, qb), fmaxf(qc, qd));
+      if (q == 0) ring_bm[rp >> 4] = fmaxf(fmaxf(qa, qb), fmaxf(qc, qd));
     }
     __syncthreads();
 
     // ---- 240-sample window maximum = tail of block b-15, blocks b-14..b-1, head of block b ----
-    const int blk = (int)(gk >> 4);
+    const int bpos = rp >> 4;
     float w14 = 0.f;
 #pragma unroll
-    for (int j = 1; j <= 14; ++j) w14 = fmaxf(w14, ring_bm[(blk - j) & (R / 16 - 1)]);
-    const float4 so = *reinterpret_cast<const float4 *>(&ring_suf[(int)((gk - kDelay) & (R - 1))]);
+    for (int j = 1; j <= 14; ++j) {
+      int bi = bpos - j;
+      bi = bi < 0 ? bi + NB : bi;
+      w14 = fmaxf(w14, ring_bm[bi]);
+    }
+    const int rd = ring_wrap(base + 4 * t - kDelay);  // ring position of sample gk - 240
+    const float4 so = *reinterpret_cast<const float4 *>(&ring_suf[rd]);
     float4 pk;
     pk.x = fmaxf(fmaxf(so.x, w14), pre_ex.x);
     pk.y = fmaxf(fmaxf(so.y, w14), pre_ex.y);
@@ -285,12 +296,16 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     e.z = thr / pk.z;
     e.w = thr / pk.w;
 
-    // ---- gains under the no-trigger hypothesis ----
-    float4 g;
-    g.x = gain_at(npre[0], gs, ge, cf[0], n_atk, n_end);
-    g.y = gain_at(npre[1], gs, ge, cf[1], n_atk, n_end);
-    g.z = gain_at(npre[2], gs, ge, cf[2], n_atk, n_end);
-    g.w = gain_at(npre[3], gs, ge, cf[3], n_atk, n_end);
+    // ---- gains under the hypothesis "no trigger in this chunk" ----
+    float gh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int np = n_st + 4 * t + j;
+      np = np < n_end ? np : n_end;
+      const int ci = np + 1 < n_end ? np + 1 : n_end;
+      gh[j] = gain_at(np, gs, ge, ctl[ci], n_atk, n_end);
+    }
+    float4 g = make_float4(gh[0], gh[1], gh[2], gh[3]);
     int kfirst = kBig;
     if (valid) {
       if (pk.w * g.w > thr) kfirst = 4 * t + 3;
@@ -303,6 +318,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     {
       const unsigned long long any = __ballot(kfirst != kBig);
       if (lane == 0) misc[wave] = __int_as_float(any ? __builtin_amdgcn_readlane(kfirst, __builtin_ctzll(any)) : kBig);
+      if (4 * t + 4 == cnt) misc[8] = g.w;  // gain of the chunk's last sample under the hypothesis
     }
     __syncthreads();
     int kf = __float_as_int(misc[0]);
@@ -311,21 +327,15 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     kf = min(kf, __float_as_int(misc[3]));
 
     if (kf == kBig) {
-      // hypothesis holds for the whole chunk: state after its last sample
-      const int n_last = n_st + cnt - 1 < n_end ? n_st + cnt - 1 : n_end;
-      if (n_last < n_end) {
-        g_cur = gain_at(n_last, gs, ge, p.ctab[n_last + 1], n_atk, n_end);
-        n_st = n_last + 1;
-      } else {
-        g_cur = 1.0f;
-        n_st = n_end;
-      }
+      // the hypothesis holds for the whole chunk
+      g_cur = misc[8];
+      n_st = n_st + cnt < n_end ? n_st + cnt : n_end;
     } else {
       const int b0 = kf >> 6;
       if (wave == 0) {
         int ln = n_st + 64 * b0 < n_end ? n_st + 64 * b0 : n_end;
         float lgs = gs, lge = ge, lgl = g_cur;
-        limiter_wave(arr_p, arr_e, arr_g, head, p.ctab, b0, cnt >> 6, ln, lgs, lge, lgl, thr, n_atk, n_end);
+        limiter_wave(arr_p, arr_e, arr_g, ctl, b0, cnt >> 6, ln, lgs, lge, lgl, thr, n_atk, n_end);
         if (lane == 0) {
           misc[4] = lgl;
           misc[5] = lgs;
@@ -344,7 +354,6 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     // ---- emit 4 delayed samples * gain as interleaved PCM ----
     const int64_t j0 = gk - kDelay;
     if (valid && j0 >= 0) {
-      const int rd = (int)(j0 & (R - 1));
       float4 o[OC];
 #pragma unroll
       for (int c = 0; c < OC; ++c) {
@@ -407,6 +416,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
         }
       }
     }
+    base = base + cnt >= R ? base + cnt - R : base + cnt;
     __syncthreads();  // ring / arr slots are rewritten by the next chunk
   }
 
@@ -414,8 +424,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
   {
     float *sy = p.ring_y + (int64_t)s * OC * kSave;
     float *spm = p.ring_pm + (int64_t)s * kSave;
-    const int64_t end = p.pos0 + p.total;
-    const int rp = (int)((end - kSave + t) & (R - 1));
+    const int rp = ring_wrap(base - kSave + t);  // base = ring position of sample pos0 + total
 #pragma unroll
     for (int c = 0; c < OC; ++c) sy[c * kSave + t] = ring_y[c * R + rp];
     spm[t] = ring_pm[rp];
