@@ -30,6 +30,7 @@ namespace {
 #include "render_common.hpp"
 #include "render_generic.hpp"
 #include "render_fast.hpp"
+#include "render_wide.hpp"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -165,6 +166,18 @@ void launch_fast_m(const RenderParams &p, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((render_fast_kernel<M, 2>), grid, dim3(256), lds, st, p);
 }
 
+template <int M>
+void launch_wide_m(const RenderParams &p, dim3 grid, hipStream_t st) {
+  const size_t lds = sizeof(float) * (size_t)wide_lds_floats(p.out_ch, M);
+  static bool opted = false;
+  if (!opted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide_kernel<M>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    opted = true;
+  }
+  hipLaunchKernelGGL((render_wide_kernel<M>), grid, dim3(256), lds, st, p);
+}
+
 // The fast kernel takes aligned, limiter-on calls into 1- or 2-channel layouts; everything else
 // (odd sizes, flush, limiter off, wide layouts) goes to the generic kernel.  Both are exact.
 bool fast_path_ok(const RenderParams &p) {
@@ -176,14 +189,26 @@ bool fast_path_ok(const RenderParams &p) {
   return true;
 }
 
+// The wide kernel: 3..24 output channels, limiter on, aligned calls.
+bool wide_path_ok(const RenderParams &p, int m) {
+  if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
+  if (!p.limiter_on || !p.in || p.out_ch <= 2 || p.out_ch > kMaxOut || p.n_end < kWWin) return false;
+  if ((p.pos0 & 15) || (p.total & 63)) return false;
+  if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
+  return sizeof(float) * (size_t)wide_lds_floats(p.out_ch, m) <= 80 * 1024;
+}
+
 int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
   dim3 grid((unsigned)p.n_streams);
   const bool fast = fast_path_ok(p);
+  const bool wide = !fast && wide_path_ok(p, m);
   switch (m) {
 #define CASE_M(v)                              \
   case v:                                      \
     if (fast)                                  \
       launch_fast_m<v>(p, grid, st);           \
+    else if (wide)                             \
+      launch_wide_m<v>(p, grid, st);           \
     else                                       \
       launch_m<v>(p, grid, lds_bytes, st);     \
     break;

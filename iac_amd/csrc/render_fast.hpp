@@ -44,11 +44,12 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 // arr_g.  (n, gs, ge) is the state before the first sample of block b0 and is updated to the
 // state after the last sample.  Restates audio_effect_peak_limiter.c:237-265 sample by sample:
 // every accepted gain is produced by exactly the reference's f32 operations.
+template <typename Lookup>
 __device__ __forceinline__ void limiter_wave(const float *arr_p, const float *arr_e, float *arr_g,
-                                             const float *ctab, int b0, int nblk, int &n, float &gs,
+                                             Lookup ctab, int b0, int nblk, int &n, float &gs,
                                              float &ge, float &g_last, float thr, int n_atk, int n_end) {
   const int lane = threadIdx.x & 63;
-  const float a1 = ctab[1];  // attack-curve value one step after a trigger
+  const float a1 = ctab(1);  // attack-curve value one step after a trigger
   float gacc = 1.0f;
   for (int b = b0; b < nblk; ++b) {
     const float pk = arr_p[b * 64 + lane];
@@ -60,7 +61,7 @@ __device__ __forceinline__ void limiter_wave(const float *arr_p, const float *ar
       n_pre = n_pre < n_end ? n_pre : n_end;
       n_pre = n_pre < 0 ? 0 : n_pre;
       const int ci = n_pre + 1 < n_end ? n_pre + 1 : n_end;
-      const float c = ctab[ci];
+      const float c = ctab(ci);
       const float g = gain_at(n_pre, gs, ge, c, n_atk, n_end);
       const bool tr = lane >= l0 && (pk * g > thr);
       const unsigned long long mask = __ballot(tr);
@@ -335,7 +336,8 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
       if (wave == 0) {
         int ln = n_st + 64 * b0 < n_end ? n_st + 64 * b0 : n_end;
         float lgs = gs, lge = ge, lgl = g_cur;
-        limiter_wave(arr_p, arr_e, arr_g, ctl, b0, cnt >> 6, ln, lgs, lge, lgl, thr, n_atk, n_end);
+        limiter_wave(arr_p, arr_e, arr_g, [ctl](int ci) { return ctl[ci]; }, b0, cnt >> 6, ln, lgs, lge, lgl,
+                     thr, n_atk, n_end);
         if (lane == 0) {
           misc[4] = lgl;
           misc[5] = lgs;
