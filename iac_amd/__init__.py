@@ -12,6 +12,9 @@ from .hipabi import (  # noqa: F401
     FMT_S32,
     KIND_H2M,
     KIND_M2M,
+    PROJ_AUTO,
+    PROJ_EXACT,
+    PROJ_MFMA,
     SS,
     Batch,
     BatchConfig,

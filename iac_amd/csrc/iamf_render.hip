@@ -171,11 +171,16 @@ void launch_wide_m(const RenderParams &p, dim3 grid, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)wide_lds_floats(p.out_ch, M);
   static bool opted = false;
   if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide_kernel<M>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide_kernel<M, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide_kernel<M, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     opted = true;
   }
-  hipLaunchKernelGGL((render_wide_kernel<M>), grid, dim3(256), lds, st, p);
+  if (p.use_mfma)
+    hipLaunchKernelGGL((render_wide_kernel<M, true>), grid, dim3(256), lds, st, p);
+  else
+    hipLaunchKernelGGL((render_wide_kernel<M, false>), grid, dim3(256), lds, st, p);
 }
 
 // The fast kernel takes aligned, limiter-on calls into 1- or 2-channel layouts; everything else
@@ -244,6 +249,14 @@ int render_call(iamf_hip_batch *b, const float *d_in, int64_t ss, int64_t fsr, i
   p.out_format = b->cfg.out_format;
   p.limiter_on = b->cfg.limiter_enable ? 1 : 0;
   p.loudness_on = b->cfg.loudness_enable ? 1 : 0;
+  {
+    const int proj = b->cfg.projection;
+    const char *env = getenv("IAMF_HIP_PROJECTION");  // "exact" / "mfma" override for experiments
+    bool mf = proj == IAMF_HIP_PROJ_MFMA || (proj == IAMF_HIP_PROJ_AUTO && b->cfg.matrix.kind == IAMF_HIP_KIND_H2M);
+    if (env && !strcmp(env, "exact")) mf = false;
+    if (env && !strcmp(env, "mfma")) mf = true;
+    p.use_mfma = (mf && b->n_feeds <= 32) ? 1 : 0;
+  }
   p.n_atk = b->n_atk;
   p.n_end = b->n_end;
   p.thr = b->thr;
@@ -307,7 +320,8 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
   const iamf_hip_matrix &mx = cfg->matrix;
   if (cfg->n_streams <= 0 || cfg->frame_size <= 0 || cfg->sample_rate <= 0 || !mx.mat ||
       mx.m <= 0 || mx.m > kMaxIn || mx.n <= 0 || mx.n > kMaxOut || cfg->out_channels <= 0 ||
-      cfg->out_channels > kMaxOut || !iamf_hip_format_bytes(cfg->out_format))
+      cfg->out_channels > kMaxOut || !iamf_hip_format_bytes(cfg->out_format) || cfg->projection < 0 ||
+      cfg->projection > IAMF_HIP_PROJ_MFMA)
     return IAMF_HIP_ERR_BAD_ARG;
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));

@@ -38,6 +38,7 @@ struct RenderParams {
   int32_t out_format;
   int32_t limiter_on;
   int32_t loudness_on;
+  int32_t use_mfma;         // wide kernel: projection on v_mfma_f32_32x32x2_f32 instead of VALU
   int32_t n_atk, n_end;     // limiter table split points
   float thr;
   const int32_t *src_feed;  // device [out_ch]: output slot -> feed index, or -1 = silent slot

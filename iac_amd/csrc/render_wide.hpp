@@ -1,11 +1,21 @@
 // render_wide.hpp — multi-channel output layouts (3..24 channels) with the limiter on, aligned
-// calls.  One workgroup (4 waves) per stream, 256-sample chunks, lane = sample.
+// calls.  One workgroup (4 waves) per stream, 256-sample chunks; everything after the
+// projection runs lane = sample.
 //   * rendered samples live in an LDS ring laid out exactly like the interleaved output
 //     ([position][channel], no padding), so the emit stage is a linear copy: 32-byte LDS reads,
-//     gain, round, 16-byte coalesced global stores — no 2-byte scattered stores;
-//   * projection on VALU in the reference's operation order (bit-exact), four output slots at a
-//     time with their weights fetched as one 16-byte LDS broadcast per input channel;
+//     gain, round, 16-byte coalesced global stores;
+//   * projection, two variants:
+//       MFMA = false : VALU in the reference's operation order (bit-exact), four output slots at
+//                      a time, weights fetched as one 16-byte LDS broadcast per input channel;
+//       MFMA = true  : v_mfma_f32_32x32x2_f32, D[slot][sample] = W[slot][in] * X[in][sample]; the
+//                      weights sit in KS registers for the whole call, the planar input is loaded
+//                      straight in the B-operand layout (2 channel rows x 128 B per instruction),
+//                      each lane ends up with 4-slot groups it writes to the ring as 16-byte
+//                      stores.  Exact f32 products accumulated as a k-ordered fma chain: differs
+//                      from the reference's separate mul/add roundings by <= 1 ulp per term
+//                      (within +-1 LSB of the PCM, see tests/test_gpu_mfma.py);
 //   * the next chunk's input loads are issued right after the projection;
+//   * 240-sample sliding maximum from DPP row scans (a 16-lane row = one aligned 16-block);
 //   * limiter gains as in render_fast.hpp: no-trigger hypothesis for the whole chunk, otherwise
 //     wave 0 re-runs the recurrence (speculation + DPP trigger-run chain).  The curve table is too
 //     big to sit in LDS next to a 24-channel ring, so each chunk stages the 320-entry window it
@@ -16,24 +26,38 @@ constexpr int kWChunk = 256;
 constexpr int kWPos = 512;   // ring positions (power of two >= chunk + look-ahead + 15)
 constexpr int kWWin = 320;   // staged table window / head length (> chunk + 1)
 
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
 __host__ __device__ constexpr int wide_lds_floats(int c, int m) {
-  return kWPos * c + 2 * kWPos + 3 * kWChunk + 2 * kWWin + ((c + 3) & ~3) * m + 16;
+  return kWPos * c + 2 * kWPos + kWPos / 16 + 3 * kWChunk + 2 * kWWin + ((c + 3) & ~3) * m + 16;
 }
 
-template <int M>
+// DPP helpers inside a 16-lane row; lanes shifted in from outside the row read 0
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float v) {  // lane i <- lane i+N
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
+}
+template <int N>
+__device__ __forceinline__ float dpp_row_shr(float v) {  // lane i <- lane i-N
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xf, 0xf, true));
+}
+
+template <int M, bool MFMA>
 __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) {
   extern __shared__ float lds[];
+  constexpr int KS = (M + 1) / 2;  // k-steps of the 32x32x2 MFMA
   const int C = p.out_ch;
   const int C4 = (C + 3) & ~3;
   float *ring = lds;                      // [kWPos][C]  rendered samples, interleaved like the output
   float *ring_pm = ring + kWPos * C;      // [kWPos]     max |y| over channels
-  float *ring_b16 = ring_pm + kWPos;      // [kWPos]     max of pm over the trailing 16 samples
-  float *arr_p = ring_b16 + kWPos;        // [256]
+  float *ring_suf = ring_pm + kWPos;      // [kWPos]     suffix maxima of pm inside aligned 16-blocks
+  float *ring_bm = ring_suf + kWPos;      // [kWPos/16]  maxima of aligned 16-blocks
+  float *arr_p = ring_bm + kWPos / 16;    // [256]
   float *arr_e = arr_p + kWChunk;         // [256]
   float *arr_g = arr_e + kWChunk;         // [256]
   float *win = arr_g + kWChunk;           // [kWWin]     ctab[n_st + i] for this chunk
   float *head = win + kWWin;              // [kWWin]     ctab[i]
-  float *mat = head + kWWin;              // [M][C4]     weights, input-major
+  float *mat = head + kWWin;              // [M][C4]     weights, input-major (VALU variant)
   float *misc = mat + C4 * M;             // [16]
 
   const int s = blockIdx.x;
@@ -48,23 +72,36 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
   {
     const float *sy = p.ring_y + (int64_t)s * C * kSave;
     const float *spm = p.ring_pm + (int64_t)s * kSave;
-    const int rp = (int)((p.pos0 - kSave + t) & (kWPos - 1));
+    const int rp = (int)((p.pos0 - kSave + t) & (kWPos - 1));  // pos0 % 16 == 0
     for (int c = 0; c < C; ++c) ring[rp * C + c] = sy[c * kSave + t];
-    ring_pm[rp] = spm[t];
+    const float pm = spm[t];
+    ring_pm[rp] = pm;
+    float sfx = pm;
+    sfx = fmaxf(sfx, dpp_row_shl<1>(sfx));
+    sfx = fmaxf(sfx, dpp_row_shl<2>(sfx));
+    sfx = fmaxf(sfx, dpp_row_shl<4>(sfx));
+    sfx = fmaxf(sfx, dpp_row_shl<8>(sfx));
+    ring_suf[rp] = sfx;
+    if ((t & 15) == 0) ring_bm[rp >> 4] = sfx;
     for (int i = t; i < kWWin; i += 256) head[i] = p.ctab[i < n_end ? i : n_end];
-    for (int i = t; i < C4 * M; i += 256) {
-      const int m = i / C4, c = i - m * C4;
-      const int f = c < C ? p.src_feed[c] : -1;
-      mat[i] = f >= 0 ? p.matrix[f * M + m] : 0.f;
+    if (!MFMA) {
+      for (int i = t; i < C4 * M; i += 256) {
+        const int m = i / C4, c = i - m * C4;
+        const int f = c < C ? p.src_feed[c] : -1;
+        mat[i] = f >= 0 ? p.matrix[f * M + m] : 0.f;
+      }
     }
   }
-  __syncthreads();
-  {
-    const int64_t gk = p.pos0 - kSave + t;
-    float b = 0.f;
-    for (int j = 0; j < 16; ++j)
-      if (t - j >= 0) b = fmaxf(b, ring_pm[(int)((gk - j) & (kWPos - 1))]);
-    ring_b16[(int)(gk & (kWPos - 1))] = b;
+  // MFMA A operand: lane l holds W[slot = l & 31][in = 2*ks + (l >> 5)]
+  float aw[KS];
+  if (MFMA) {
+    const int slot = lane & 31;
+    const int f = slot < C ? p.src_feed[slot] : -1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int m = 2 * ks + (lane >> 5);
+      aw[ks] = (f >= 0 && m < M) ? p.matrix[f * M + m] : 0.f;
+    }
   }
   LimState ls = p.lim[s];
   float g_cur = ls.g, gs = ls.gs, ge = ls.ge;
@@ -78,20 +115,42 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
   const int bytes = p.out_format == IAMF_HIP_FMT_S16 ? 2 : (p.out_format == IAMF_HIP_FMT_S24 ? 3 : 4);
   uint8_t *pcm = p.pcm + (int64_t)s * p.pcm_stream_stride;
   const float *in_s = p.in + (int64_t)s * p.in_stream_stride;
+  // flat element index -> sample: srel = (f * inv_c) >> 20 is exact for f < 256*24 and c <= 24
+  const uint32_t inv_c = ((1u << 20) + C - 1) / C;
 
-  float x[M];
-  {
-    if (t < p.total) {
-      const int f = t / fs;
-      const int i = t - f * fs;
-      const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
+  // input registers: VALU variant x[m] = channel m of this lane's sample;
+  // MFMA variant x[tt*KS + ks] = B operand of tile tt, k-step ks
+  constexpr int NX = MFMA ? 2 * KS : M;
+  float x[NX];
+  auto load_chunk = [&](int cbase) {
+    if (MFMA) {
 #pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = src[(int64_t)m * fs];
+      for (int tt = 0; tt < 2; ++tt) {
+        const int k = cbase + 64 * wave + 32 * tt + (lane & 31);
+        const int f = k / fs;
+        const int i = k - f * fs;
+        const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int m = 2 * ks + (lane >> 5);
+          x[tt * KS + ks] = (k < p.total && m < M) ? src[(int64_t)m * fs] : 0.f;
+        }
+      }
     } else {
+      const int k = cbase + t;
+      if (k < p.total) {
+        const int f = k / fs;
+        const int i = k - f * fs;
+        const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
 #pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = 0.f;
+        for (int m = 0; m < M; ++m) x[m] = src[(int64_t)m * fs];
+      } else {
+#pragma unroll
+        for (int m = 0; m < M; ++m) x[m] = 0.f;
+      }
     }
-  }
+  };
+  load_chunk(0);
   __syncthreads();
 
   for (int c0 = 0; c0 < p.total; c0 += kWChunk) {
@@ -110,64 +169,112 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
       if (t < kWWin - 256) wv1 = p.ctab[i1 < n_end ? i1 : n_end];
     }
 
-    // ---- element renderer + gains, four output slots at a time ----
+    // ---- element renderer + gains -> ring; pm = max |y| of this lane's sample ----
     float pm = 0.f;
-    for (int cb = 0; cb < C4; cb += 4) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (MFMA) {
+      float pmt[2];
 #pragma unroll
-      for (int m = 0; m < M; ++m) {
-        const float4 w = *reinterpret_cast<const float4 *>(&mat[m * C4 + cb]);
-        a0 = a0 + w.x * x[m];
-        a1 = a1 + w.y * x[m];
-        a2 = a2 + w.z * x[m];
-        a3 = a3 + w.w * x[m];
+      for (int tt = 0; tt < 2; ++tt) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[ks], x[tt * KS + ks], acc, 0, 0, 0);
+        // lane l: column = sample 32*tt + (l & 31); register r: slot (r&3) + 8*(r>>2) + 4*(l>>5)
+        const int ksmp = 64 * wave + 32 * tt + (lane & 31);
+        const int pos = (int)((p.pos0 + c0 + ksmp) & (kWPos - 1));
+        float pmv = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int slot0 = 8 * gq + 4 * (lane >> 5);
+          float y[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = acc[4 * gq + i];
+            if (eg_on) v = v * eg;
+            v = 0.f + v;  // mixer: 0 += frame
+            if (og_on) v = v * og;
+            if (lg_on) v = v * lg;
+            y[i] = v;
+            if (slot0 + i < C) pmv = fmaxf(pmv, fabsf(v));
+          }
+          if (ksmp < cnt) {
+            if ((C & 3) == 0) {
+              if (slot0 < C) *reinterpret_cast<float4 *>(&ring[pos * C + slot0]) = make_float4(y[0], y[1], y[2], y[3]);
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (slot0 + i < C) ring[pos * C + slot0 + i] = y[i];
+            }
+          }
+        }
+        pmt[tt] = fmaxf(pmv, __shfl_xor(pmv, 32));  // the sample's other 12 slots live in lane ^ 32
       }
-      float y[4] = {a0, a1, a2, a3};
+      pm = lane < 32 ? pmt[0] : pmt[1];
+    } else {
+      for (int cb = 0; cb < C4; cb += 4) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = y[i];
-        if (eg_on) v = v * eg;
-        v = 0.f + v;  // mixer: 0 += frame
-        if (og_on) v = v * og;
-        if (lg_on) v = v * lg;
-        y[i] = v;
-        if (cb + i < C) pm = fmaxf(pm, fabsf(v));
-      }
-      if (valid) {
-        if ((C & 3) == 0) {
-          *reinterpret_cast<float4 *>(&ring[rp * C + cb]) = make_float4(y[0], y[1], y[2], y[3]);
-        } else {
+        for (int m = 0; m < M; ++m) {
+          const float4 w = *reinterpret_cast<const float4 *>(&mat[m * C4 + cb]);
+          a0 = a0 + w.x * x[m];
+          a1 = a1 + w.y * x[m];
+          a2 = a2 + w.z * x[m];
+          a3 = a3 + w.w * x[m];
+        }
+        float y[4] = {a0, a1, a2, a3};
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (cb + i < C) ring[rp * C + cb + i] = y[i];
+        for (int i = 0; i < 4; ++i) {
+          float v = y[i];
+          if (eg_on) v = v * eg;
+          v = 0.f + v;  // mixer: 0 += frame
+          if (og_on) v = v * og;
+          if (lg_on) v = v * lg;
+          y[i] = v;
+          if (cb + i < C) pm = fmaxf(pm, fabsf(v));
+        }
+        if (valid) {
+          if ((C & 3) == 0) {
+            *reinterpret_cast<float4 *>(&ring[rp * C + cb]) = make_float4(y[0], y[1], y[2], y[3]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (cb + i < C) ring[rp * C + cb + i] = y[i];
+          }
         }
       }
     }
 
     // ---- prefetch the next chunk's input ----
-    {
-      const int kn = k + kWChunk;
-      if (kn < p.total) {
-        const int f = kn / fs;
-        const int i = kn - f * fs;
-        const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
-#pragma unroll
-        for (int m = 0; m < M; ++m) x[m] = src[(int64_t)m * fs];
-      }
-    }
+    if (c0 + kWChunk < p.total) load_chunk(c0 + kWChunk);
 
-    if (valid) ring_pm[rp] = pm;
+    // ---- per-16 suffix / exclusive prefix / block maxima by DPP row scans ----
+    float sfx = pm;
+    sfx = fmaxf(sfx, dpp_row_shl<1>(sfx));
+    sfx = fmaxf(sfx, dpp_row_shl<2>(sfx));
+    sfx = fmaxf(sfx, dpp_row_shl<4>(sfx));
+    sfx = fmaxf(sfx, dpp_row_shl<8>(sfx));
+    float pre = dpp_row_shr<1>(pm);
+    pre = fmaxf(pre, dpp_row_shr<1>(pre));
+    pre = fmaxf(pre, dpp_row_shr<2>(pre));
+    pre = fmaxf(pre, dpp_row_shr<4>(pre));
+    pre = fmaxf(pre, dpp_row_shr<8>(pre));
+    if (valid) {
+      ring_pm[rp] = pm;
+      ring_suf[rp] = sfx;
+      if ((t & 15) == 0) ring_bm[rp >> 4] = sfx;
+    }
     win[t] = wv0;
     if (t < kWWin - 256) win[t + 256] = wv1;
     __syncthreads();
-    float b = 0.f;
+
+    // ---- 240-sample window maximum = tail of block b-15, blocks b-14..b-1, head of block b ----
+    const int bpos = rp >> 4;
+    float w14 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) b = fmaxf(b, ring_pm[(int)((gk - j) & (kWPos - 1))]);
-    if (valid) ring_b16[rp] = b;
-    __syncthreads();
-    float pk = 0.f;
-#pragma unroll
-    for (int j = 0; j < 15; ++j) pk = fmaxf(pk, ring_b16[(int)((gk - 1 - 16 * j) & (kWPos - 1))]);
+    for (int j = 1; j <= 14; ++j) w14 = fmaxf(w14, ring_bm[(bpos - j) & (kWPos / 16 - 1)]);
+    const float pk = fmaxf(fmaxf(ring_suf[(int)((gk - kDelay) & (kWPos - 1))], w14), pre);
     const float e = thr / pk;
 
     // ---- gains under the no-trigger hypothesis ----
@@ -188,12 +295,11 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
     kf = min(kf, __float_as_int(misc[2]));
     kf = min(kf, __float_as_int(misc[3]));
     if (kf == kBig) {
-      arr_g[t] = g;
+      arr_g[t] = g * 32768.f;  // exact power-of-two scaling, folded into the emit multiply
       g_cur = misc[8];
       n_st = n_st + cnt < n_end ? n_st + cnt : n_end;
     } else {
       const int b0 = kf >> 6;
-      if (t < 64 * b0) arr_g[t] = g;
       if (wave == 0) {
         const int n_chunk = n_st;
         int ln = n_st + 64 * b0 < n_end ? n_st + 64 * b0 : n_end;
@@ -211,12 +317,13 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
         }
       }
       __syncthreads();
+      arr_g[t] = (t < 64 * b0 ? g : arr_g[t]) * 32768.f;
       g_cur = misc[4];
       gs = misc[5];
       ge = misc[6];
       n_st = __float_as_int(misc[7]);
     }
-    __syncthreads();  // arr_g complete for the emit stage
+    __syncthreads();  // arr_g (gain * 2^15) complete for the emit stage
 
     // ---- emit: the chunk's 256 delayed samples are one contiguous run of the ring ----
     const int64_t jc = p.pos0 + c0 - kDelay;  // first emitted sample of the chunk (may be < 0)
@@ -226,7 +333,7 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
       const int ring_flat = kWPos * C;
       for (int q = t; q < np; q += 256) {
         const int f0 = 8 * q;
-        int srel = f0 / C;
+        int srel = (int)(((uint32_t)f0 * inv_c) >> 20);
         int r = f0 - srel * C;
         if (jc + srel < 0) continue;  // withheld look-ahead samples; 240*C is a multiple of 8
         int rf = epos * C + f0;
@@ -238,26 +345,27 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
         float gq = arr_g[srel];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          o[i] = (int)to_scaled(vv[i] * gq, 32768.f, -32768.f, 32767.f);
+          // rint then saturate == the reference's clamp then lrintf (the bounds are integers)
+          o[i] = (int)rintf(vv[i] * gq);
           ++r;
-          if (r == C) {
+          if (r == C) {  // next sample-frame: next gain
             r = 0;
             ++srel;
             gq = arr_g[srel < kWChunk ? srel : kWChunk - 1];
           }
         }
         uint4 w;
-        w.x = (uint32_t)(o[0] & 0xffff) | ((uint32_t)o[1] << 16);
-        w.y = (uint32_t)(o[2] & 0xffff) | ((uint32_t)o[3] << 16);
-        w.z = (uint32_t)(o[4] & 0xffff) | ((uint32_t)o[5] << 16);
-        w.w = (uint32_t)(o[6] & 0xffff) | ((uint32_t)o[7] << 16);
+        w.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(o[0], o[1]));
+        w.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(o[2], o[3]));
+        w.z = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(o[4], o[5]));
+        w.w = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(o[6], o[7]));
         *reinterpret_cast<uint4 *>(pcm + ((jc - out_base) * (int64_t)C + f0) * 2) = w;
       }
     } else {
       const int64_t j = gk - kDelay;
       if (valid && j >= 0) {
         const int rd = (int)(j & (kWPos - 1));
-        const float gq = arr_g[t];
+        const float gq = arr_g[t] * (1.0f / 32768.f);  // exact: undo the power-of-two scaling
         uint8_t *dst = pcm + (j - out_base) * (int64_t)C * bytes;
         if (p.out_format == IAMF_HIP_FMT_S24) {
           for (int c = 0; c < C; ++c) {

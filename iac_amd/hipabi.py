@@ -11,6 +11,7 @@ CSRC = os.path.join(ROOT, "iac_amd", "csrc")
 
 FMT_S16, FMT_S24, FMT_S32, FMT_F32 = 16, 24, 32, -32
 KIND_H2M, KIND_M2M = 0, 1
+PROJ_AUTO, PROJ_EXACT, PROJ_MFMA = 0, 1, 2
 SS = dict(A=0x020, B=0x050, C=0x250, D=0x450, E=0x451, F=0x370, G=0x490, H=0x9A3, I=0x070,
           J=0x470, STEREO=0x200, L51=0x510, L512=0x512, L514=0x514, L71=0x710, L714=0x714,
           MONO=0x100, L712=0x712, L312=0x312, BINAURAL=0x1020)
@@ -34,7 +35,7 @@ class BatchConfig(C.Structure):
     _fields_ = [("n_streams", C.c_int32), ("frame_size", C.c_int32), ("sample_rate", C.c_int32),
                 ("out_channels", C.c_int32), ("out_format", C.c_int32), ("matrix", Matrix),
                 ("limiter_enable", C.c_int32), ("limiter_threshold_db", C.c_float),
-                ("loudness_enable", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("loudness_enable", C.c_int32), ("projection", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 def lib_path():
@@ -108,7 +109,7 @@ class Batch:
     """Thin handle on iamf_hip_batch_*; pointers are raw device addresses (ints)."""
 
     def __init__(self, n_streams, matrix, out_channels, frame_size=1024, sample_rate=48000,
-                 out_format=FMT_S16, limiter=True, threshold_db=-1.0, loudness=False):
+                 out_format=FMT_S16, limiter=True, threshold_db=-1.0, loudness=False, projection=PROJ_AUTO):
         cfg = BatchConfig()
         cfg.n_streams = n_streams
         cfg.frame_size = frame_size
@@ -119,6 +120,7 @@ class Batch:
         cfg.limiter_enable = 1 if limiter else 0
         cfg.limiter_threshold_db = threshold_db
         cfg.loudness_enable = 1 if loudness else 0
+        cfg.projection = projection
         self.cfg = cfg
         self.bytes_per_sample = lib().iamf_hip_format_bytes(out_format)
         h = C.c_void_p()

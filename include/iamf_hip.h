@@ -47,6 +47,14 @@ enum {
 
 enum { IAMF_HIP_KIND_H2M = 0, IAMF_HIP_KIND_M2M = 1 };
 
+/* Projection arithmetic for output layouts wider than stereo.
+ *   EXACT: VALU, separate f32 multiply and add in the reference's order -> bit-identical PCM.
+ *   MFMA : v_mfma_f32_32x32x2_f32 (exact f32 products, fused k-ordered accumulation) -> PCM within
+ *          +-1 LSB of the reference (rounding ties only).
+ *   AUTO : MFMA for the HOA projection (h2m_rdr.c:1103-1112, a dense contraction), EXACT for
+ *          channel-layout matrices (m2m_rdr.c:1826-1837) and always for mono/stereo/binaural. */
+enum { IAMF_HIP_PROJ_AUTO = 0, IAMF_HIP_PROJ_EXACT = 1, IAMF_HIP_PROJ_MFMA = 2 };
+
 /* output sample formats.  16/24/32 = interleaved little-endian integer PCM exactly as
  * iamf_decoder_plane2stride_out writes it (IAMF_decoder.c:121-167).  F32 = the limiter output
  * as interleaved float, unscaled: a stage tap for parity tests, not a reference format. */
@@ -91,7 +99,8 @@ typedef struct {
                                  attack 1 ms, release 200 ms, look-ahead 240 are the reference's
                                  constants (common/audio_defines.h:38-41) */
   int32_t loudness_enable; /* normalization_loudness != 0 (IAMF_decoder.c:3480) */
-  int32_t reserved[7];
+  int32_t projection;      /* IAMF_HIP_PROJ_*: how layouts with more than 2 channels are projected */
+  int32_t reserved[6];
 } iamf_hip_batch_config;
 
 /* Creates device state for cfg->n_streams streams on the CURRENT HIP device.  Synchronous.

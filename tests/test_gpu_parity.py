@@ -115,7 +115,7 @@ def test_pipeline_toa_H_24ch_vs_oracle(hip):
     fs, F = 1024, 3
     x = synth.gaussian(13, 16, F * fs, 0.15)[None]
     mx = A.get_h2m_matrix(3, A.SS["H"])
-    got = G.hip_render(mx, 24, x, frame_size=fs, limiter=True, flush=True)[0]
+    got = G.hip_render(mx, 24, x, frame_size=fs, limiter=True, flush=True, projection=A.PROJ_EXACT)[0]
     want = O.stream_run(O.get_h2m(3, O.SS["H"]), 24, x[0], fs)
     assert np.array_equal(got, want)
     assert np.all(got[:, 3] == 0) and np.all(got[:, 23] == 0) and np.any(got[:, 22] != 0)
