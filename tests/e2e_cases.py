@@ -1,0 +1,147 @@
+"""Synthetic IAMF streams for the end-to-end goldens (oracle/gen_golden_extra.py runs the real
+reference decoder on them) and for the tests that replay them through the oracle, the HIP path
+and the IAMF_decoder.h facade.  build(name) -> (stream bytes, info) where info carries the
+element PCM exactly as the renderer sees it (quantised LPCM values, playback channel order).
+"""
+import numpy as np
+
+import iamf_writer as W
+import synth
+
+SS = dict(A=0, B=1, C=2, D=3, E=4, F=5, G=6, H=7, I=8, J=9, EXT712=10, EXT312=11, MONO=12)
+
+# audio-layer order -> playback order (reference IAMF_utils.c:117-133 vs :181-196): playback
+# channel p is audio-layer channel AL_OF_PLAYBACK[layout][p]
+_CL = {1: "L2 R2", 2: "L5 R5 C LFE SL5 SR5", 7: "L7 R7 C LFE SL7 SR7 BL7 BR7 HFL HFR HBL HBR",
+       3: "L5 R5 C LFE SL5 SR5 HL HR", 4: "L5 R5 C LFE SL5 SR5 HFL HFR HBL HBR", 0: "MONO",
+       5: "L7 R7 C LFE SL7 SR7 BL7 BR7", 6: "L7 R7 C LFE SL7 SR7 BL7 BR7 HL HR", 8: "L3 R3 C LFE TL TR"}
+_AL = {1: "L2 R2", 2: "L5 R5 SL5 SR5 C LFE", 7: "L7 R7 SL7 SR7 BL7 BR7 HFL HFR HBL HBR C LFE",
+       3: "L5 R5 SL5 SR5 HL HR C LFE", 4: "L5 R5 SL5 SR5 HFL HFR HBL HBR C LFE", 0: "MONO",
+       5: "L7 R7 SL7 SR7 BL7 BR7 C LFE", 6: "L7 R7 SL7 SR7 BL7 BR7 HL HR C LFE", 8: "L3 R3 TL TR C LFE"}
+
+
+def al_index_of_playback(layout):
+    cl, al = _CL[layout].split(), _AL[layout].split()
+    return [al.index(c) for c in cl]
+
+
+def _pdef_static(pid, rate=48000):
+    return W.param_definition(pid, rate, mode=1)
+
+
+def _descriptor_prefix(frame_size, sample_size=16, rate=48000):
+    return W.sequence_header(1) + W.codec_config_lpcm(0, frame_size, sample_size, rate)
+
+
+def _ss_layout(name):
+    return ("ss", SS[name])
+
+
+CASES = {
+    # BASELINE configs[0]: stereo element -> Sound System A, 16 bit (the reference's own
+    # CPU-runnable case, iamfplayer -o2 -s0)
+    "stereo_A_s16": dict(layout=_ss_layout("A"), bit_depth=16, frames=20, fs=1024, seed=7),
+    "toa_binaural_s16": dict(layout=("binaural",), bit_depth=16, frames=12, fs=1024, seed=1000),
+    "toa_H_s16": dict(layout=_ss_layout("H"), bit_depth=16, frames=5, fs=1024, seed=13),
+    "l714_J_s24_gain": dict(layout=_ss_layout("J"), bit_depth=24, frames=6, fs=960, seed=11,
+                            element_gain_q78=-768, output_gain_q78=384),
+    "two_elements_A_s32": dict(layout=_ss_layout("A"), bit_depth=32, frames=5, fs=1024, seed=21,
+                               limiter=False, element_gain_q78=1536),
+    "toa_binaural_loudness": dict(layout=("binaural",), bit_depth=16, frames=6, fs=1024, seed=31,
+                                  loudness=-16.0, mix_loudness_q78=-24 * 256),
+    "l714_A_s16": dict(layout=_ss_layout("A"), bit_depth=16, frames=5, fs=1024, seed=41),
+}
+
+
+def _channel_element(eid, layout, x_playback, first_sid, sample_size):
+    """returns (descriptor obu, function frame_index -> substreams, quantised playback PCM)"""
+    xq = W.quantize(x_playback, sample_size)
+    perm = al_index_of_playback(layout)
+    x_al = np.empty_like(xq)
+    for p, a in enumerate(perm):
+        x_al[a] = xq[p]
+    ns = W.LAYOUT_SUBSTREAMS[layout][0]
+    desc = W.audio_element_channel(eid, 0, layout, list(range(first_sid, first_sid + ns)))
+    return desc, x_al, xq
+
+
+def _toa_element(eid, x, first_sid, sample_size):
+    xq = W.quantize(x, sample_size)
+    desc = W.audio_element_ambisonics_mono(eid, 0, x.shape[0], list(range(first_sid, first_sid + x.shape[0])))
+    return desc, xq
+
+
+def build(name):
+    c = CASES[name]
+    fs, F = c["fs"], c["frames"]
+    n = fs * F
+    ss = c.get("sample_size", 16)
+    rate = c.get("rate", 48000)
+    stream = _descriptor_prefix(fs, ss, rate)
+    info = dict(case=c, elements=[])
+    eg = c.get("element_gain_q78", 0)
+    og = c.get("output_gain_q78", 0)
+    lay = [c["layout"]] if c["layout"][0] == "ss" else [("binaural",)]
+    layouts_field = [("ss", c["layout"][1])] if c["layout"][0] == "ss" else [("binaural",)]
+
+    def frames_of(subs_fn):
+        return subs_fn
+
+    if name in ("stereo_A_s16",):
+        x = synth.uniform(c["seed"], 2, n, 0.9)
+        desc, x_al, xq = _channel_element(1, 1, x, 0, ss)
+        stream += desc
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100), default_q78=eg)],
+                                     dict(pdef=_pdef_static(101), default_q78=og), layouts_field)
+        info["elements"].append(dict(kind="channel", layout=1, x=xq))
+        for f in range(F):
+            stream += W.temporal_delimiter()
+            stream += W.audio_frames(W.channel_element_substreams(1, x_al[:, f * fs:(f + 1) * fs], 0, ss))
+    elif name in ("toa_binaural_s16", "toa_H_s16", "toa_binaural_loudness"):
+        if name == "toa_H_s16":
+            x = synth.gaussian(c["seed"], 16, n, 0.15)
+        else:
+            x = np.clip(synth.hot(c["seed"], 16, n, sigma=0.2, burst_amp=0.7, burst_phase=900, burst_period=5000),
+                        -1, 1 - 2 ** -15).astype(np.float32)
+        desc, xq = _toa_element(1, x, 0, ss)
+        stream += desc
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100), default_q78=eg)],
+                                     dict(pdef=_pdef_static(101), default_q78=og), layouts_field,
+                                     loudness_q78=c.get("mix_loudness_q78", 0))
+        info["elements"].append(dict(kind="scene", order=3, x=xq))
+        for f in range(F):
+            stream += W.temporal_delimiter()
+            subs = [(i, W.lpcm_bytes(xq[i:i + 1, f * fs:(f + 1) * fs], ss)) for i in range(16)]
+            stream += W.audio_frames(subs)
+    elif name in ("l714_J_s24_gain", "l714_A_s16"):
+        x = np.clip(synth.hot(c["seed"], 12, n, sigma=0.2, burst_amp=0.6, burst_phase=500, burst_period=3000),
+                    -1, 1 - 2 ** -15).astype(np.float32)
+        desc, x_al, xq = _channel_element(1, 7, x, 0, ss)
+        stream += desc
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100), default_q78=eg)],
+                                     dict(pdef=_pdef_static(101), default_q78=og), layouts_field)
+        info["elements"].append(dict(kind="channel", layout=7, x=xq))
+        for f in range(F):
+            stream += W.temporal_delimiter()
+            stream += W.audio_frames(W.channel_element_substreams(7, x_al[:, f * fs:(f + 1) * fs], 0, ss))
+    elif name == "two_elements_A_s32":
+        xs = synth.uniform(c["seed"], 2, n, 0.9)
+        xs[0, 100] = 0.99997
+        xs[1, 101] = -1.0
+        xt = synth.gaussian(c["seed"] + 1, 16, n, 0.15)
+        d1, xs_al, xsq = _channel_element(1, 1, xs, 0, ss)
+        d2, xtq = _toa_element(2, xt, 1, ss)
+        stream += d1 + d2
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100), default_q78=eg),
+                                         dict(eid=2, pdef=_pdef_static(102), default_q78=0)],
+                                     dict(pdef=_pdef_static(101), default_q78=og), layouts_field)
+        info["elements"].append(dict(kind="channel", layout=1, x=xsq))
+        info["elements"].append(dict(kind="scene", order=3, x=xtq))
+        for f in range(F):
+            stream += W.temporal_delimiter()
+            subs = W.channel_element_substreams(1, xs_al[:, f * fs:(f + 1) * fs], 0, ss)
+            subs += [(1 + i, W.lpcm_bytes(xtq[i:i + 1, f * fs:(f + 1) * fs], ss)) for i in range(16)]
+            stream += W.audio_frames(subs)
+    else:
+        raise KeyError(name)
+    return stream, info
