@@ -10,6 +10,7 @@ from .hipabi import (  # noqa: F401
     FMT_S16,
     FMT_S24,
     FMT_S32,
+    KIND_DMX,
     KIND_H2M,
     KIND_M2M,
     PROJ_AUTO,
@@ -18,6 +19,10 @@ from .hipabi import (  # noqa: F401
     SS,
     Batch,
     BatchConfig,
+    DmxFrame,
+    DmxState,
+    RenderArgs,
+    dmx_matrix,
     IamfHipError,
     Matrix,
     build,

@@ -121,6 +121,13 @@ struct iamf_hip_batch {
         *d_ring_pm = nullptr;
   LimState *d_lim = nullptr;
   std::vector<float> h_gains;
+  // second element / down-mixer
+  bool has2 = false;
+  int m2 = 0;
+  float *d_matrix2 = nullptr, *d_gains2 = nullptr;
+  int32_t *d_src_feed2 = nullptr, *d_dmx_tab = nullptr;
+  bool dmx = false;
+  int dmx_n_in = 0, dmx_n_out = 0;
 };
 
 namespace {
@@ -188,6 +195,7 @@ void launch_wide_m(const RenderParams &p, dim3 grid, hipStream_t st) {
 bool fast_path_ok(const RenderParams &p) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
   if (!p.limiter_on || !p.in || p.out_ch > 2 || p.n_end + 1 > kFTabMax) return false;
+  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp) return false;
   if ((p.pos0 & 15) || (p.total & 63) || (p.frame_size & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
@@ -198,6 +206,7 @@ bool fast_path_ok(const RenderParams &p) {
 bool wide_path_ok(const RenderParams &p, int m) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
   if (!p.limiter_on || !p.in || p.out_ch <= 2 || p.out_ch > kMaxOut || p.n_end < kWWin) return false;
+  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp) return false;
   if ((p.pos0 & 15) || (p.total & 63)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
   return sizeof(float) * (size_t)wide_lds_floats(p.out_ch, m) <= 80 * 1024;
@@ -225,15 +234,31 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
   return IAMF_HIP_OK;
 }
 
-int render_call(iamf_hip_batch *b, const float *d_in, int64_t ss, int64_t fsr, int total, void *d_pcm,
-                int64_t pcm_stride, void *stream) {
+// layout tables of the down-mixer: playback channel order per IAChannelLayoutType (reference
+// IAMF_utils.c:117-133) and surround / top counts (:157-161)
+const int kLayoutCount[9] = {1, 2, 6, 8, 10, 8, 10, 12, 6};
+const int kLayoutCh[9][12] = {
+    {kChMono},
+    {kChL2, kChR2},
+    {kChL7, kChR7, kChC, kChLFE, kChSL5, kChSR5},
+    {kChL7, kChR7, kChC, kChLFE, kChSL5, kChSR5, kChHL, kChHR},
+    {kChL7, kChR7, kChC, kChLFE, kChSL5, kChSR5, kChHFL, kChHFR, kChHBL, kChHBR},
+    {kChL7, kChR7, kChC, kChLFE, kChSL7, kChSR7, kChBL7, kChBR7},
+    {kChL7, kChR7, kChC, kChLFE, kChSL7, kChSR7, kChBL7, kChBR7, kChHL, kChHR},
+    {kChL7, kChR7, kChC, kChLFE, kChSL7, kChSR7, kChBL7, kChBR7, kChHFL, kChHFR, kChHBL, kChHBR},
+    {kChL3, kChR3, kChC, kChLFE, kChTL, kChTR},
+};
+const int kLayoutSurround[9] = {1, 2, 5, 5, 5, 7, 7, 7, 3};
+const int kLayoutTop[9] = {0, 0, 0, 2, 4, 0, 2, 4, 2};
+
+int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
   RenderParams p;
   memset(&p, 0, sizeof(p));
-  p.in = d_in;
-  p.in_stream_stride = ss;
-  p.in_frame_stride = fsr;
-  p.pcm = static_cast<uint8_t *>(d_pcm);
-  p.pcm_stream_stride = pcm_stride;
+  p.in = a.d_in;
+  p.in_stream_stride = a.in_stream_stride;
+  p.in_frame_stride = a.in_frame_stride;
+  p.pcm = static_cast<uint8_t *>(a.d_pcm);
+  p.pcm_stream_stride = a.pcm_stream_stride_bytes;
   p.matrix = b->d_matrix;
   p.gains = b->d_gains;
   p.ctab = b->d_ctab;
@@ -261,13 +286,57 @@ int render_call(iamf_hip_batch *b, const float *d_in, int64_t ss, int64_t fsr, i
   p.n_end = b->n_end;
   p.thr = b->thr;
   p.src_feed = b->d_src_feed;
-  const size_t lds = sizeof(float) * ((size_t)(p.out_ch + 2) * kRing + 3 * kChunk + kHead + 4);
-  const int r = launch(p, b->m, lds, static_cast<hipStream_t>(stream));
+  if (b->has2 && a.d_in2) {
+    p.in2 = a.d_in2;
+    p.in2_stream_stride = a.in2_stream_stride;
+    p.in2_frame_stride = a.in2_frame_stride;
+    p.matrix2 = b->d_matrix2;
+    p.src_feed2 = b->d_src_feed2;
+    p.gains2 = b->d_gains2;
+    p.m2 = b->m2;
+  }
+  p.elem_ramp = a.d_element_ramp;
+  p.elem2_ramp = a.d_element2_ramp;
+  p.out_ramp = a.d_output_ramp;
+  p.ramp_stream_stride = a.ramp_stream_stride;
+  if (b->dmx) {
+    p.dmx_on = 1;
+    p.dmx_frames = a.d_in ? a.d_dmx_frames : nullptr;
+    p.dmx_n_in = b->dmx_n_in;
+    p.dmx_n_out = b->dmx_n_out;
+    p.dmx_tab = b->d_dmx_tab;
+  }
+  const size_t lds = sizeof(float) * ((size_t)(p.out_ch + 2) * kRing + 3 * kChunk + kHead + 4 +
+                                      (b->dmx ? (size_t)kChCount * kChunk : 0));
+  const int r = launch(p, b->m, lds, static_cast<hipStream_t>(a.stream));
   if (r != IAMF_HIP_OK) return r;
   const int64_t before = p.limiter_on ? (b->pos > kDelay ? b->pos - kDelay : 0) : b->pos;
   b->pos += total;
   const int64_t after = p.limiter_on ? (b->pos > kDelay ? b->pos - kDelay : 0) : b->pos;
   return (int)(after - before);
+}
+
+// feed-major copy of a renderer matrix and its output-slot map (h2m_rdr.c:1114-1150 keeps the
+// slots lfe1/lfe2 free - the comparison is against the SOURCE index - and zeroes them; every
+// other slot no feed reaches stays silent; m2m feeds map 1:1)
+void build_feed_map(const iamf_hip_matrix &mx, int out_channels, std::vector<float> &fm, int32_t *src_feed) {
+  for (int i = 0; i < kMaxOut; ++i) src_feed[i] = -1;
+  for (int i = 0; i < mx.n; ++i) {
+    int d = i;
+    if (mx.kind == IAMF_HIP_KIND_H2M && (mx.lfe1 >= 0 || mx.lfe2 >= 0)) {
+      if (mx.lfe1 >= 0 && mx.lfe1 <= i) ++d;
+      if (mx.lfe2 >= 0 && mx.lfe2 <= i) ++d;
+    }
+    if (d < out_channels) src_feed[d] = i;
+  }
+  if (mx.kind == IAMF_HIP_KIND_H2M) {
+    if (mx.lfe1 >= 0 && mx.lfe1 < out_channels) src_feed[mx.lfe1] = -1;
+    if (mx.lfe2 >= 0 && mx.lfe2 < out_channels) src_feed[mx.lfe2] = -1;
+  }
+  fm.assign((size_t)mx.m * mx.n, 0.f);
+  for (int f = 0; f < mx.n; ++f)
+    for (int k = 0; k < mx.m; ++k)
+      fm[(size_t)f * mx.m + k] = mx.kind == IAMF_HIP_KIND_H2M ? mx.mat[f * mx.m + k] : mx.mat[k * mx.n + f];
 }
 
 }  // namespace
@@ -317,11 +386,17 @@ const char *iamf_hip_version(void) { return "iamf_hip 0.1 (gfx950, HIP)"; }
 int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out) {
   if (!cfg || !out) return IAMF_HIP_ERR_BAD_ARG;
   *out = nullptr;
-  const iamf_hip_matrix &mx = cfg->matrix;
-  if (cfg->n_streams <= 0 || cfg->frame_size <= 0 || cfg->sample_rate <= 0 || !mx.mat ||
+  iamf_hip_matrix mx = cfg->matrix;
+  const bool dmx = mx.kind == IAMF_HIP_KIND_DMX;
+  if (dmx) {
+    if (!iamf_hip_dmx_valid(mx.in_id, mx.out_id)) return IAMF_HIP_ERR_BAD_ARG;
+    mx.m = kLayoutCount[mx.in_id];
+    mx.n = kLayoutCount[mx.out_id];
+  }
+  if (cfg->n_streams <= 0 || cfg->frame_size <= 0 || cfg->sample_rate <= 0 || (!dmx && !mx.mat) ||
       mx.m <= 0 || mx.m > kMaxIn || mx.n <= 0 || mx.n > kMaxOut || cfg->out_channels <= 0 ||
       cfg->out_channels > kMaxOut || !iamf_hip_format_bytes(cfg->out_format) || cfg->projection < 0 ||
-      cfg->projection > IAMF_HIP_PROJ_MFMA)
+      cfg->projection > IAMF_HIP_PROJ_MFMA || (dmx && cfg->out_channels != mx.n))
     return IAMF_HIP_ERR_BAD_ARG;
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
@@ -332,29 +407,20 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
   b->cfg = *cfg;
   b->m = mx.m;
   b->n_feeds = mx.n;
+  b->dmx = dmx;
 
-  // output slot <- feed: h2m_rdr.c:1114-1150 keeps slots lfe1/lfe2 free (the comparison is
-  // against the SOURCE index) and zeroes them; every other slot that no feed reaches stays
-  // silent.  m2m feeds map 1:1.
-  for (int i = 0; i < kMaxOut; ++i) b->src_feed[i] = -1;
-  for (int i = 0; i < mx.n; ++i) {
-    int d = i;
-    if (mx.kind == IAMF_HIP_KIND_H2M && (mx.lfe1 >= 0 || mx.lfe2 >= 0)) {
-      if (mx.lfe1 >= 0 && mx.lfe1 <= i) ++d;
-      if (mx.lfe2 >= 0 && mx.lfe2 <= i) ++d;
-    }
-    if (d < cfg->out_channels) b->src_feed[d] = i;
+  std::vector<float> fm(1, 0.f);
+  int32_t dmx_tab[24];
+  memset(dmx_tab, 0, sizeof(dmx_tab));
+  if (dmx) {
+    for (int i = 0; i < kMaxOut; ++i) b->src_feed[i] = -1;
+    b->dmx_n_in = mx.m;
+    b->dmx_n_out = mx.n;
+    for (int i = 0; i < mx.m; ++i) dmx_tab[i] = kLayoutCh[mx.in_id][i];
+    for (int i = 0; i < mx.n; ++i) dmx_tab[12 + i] = kLayoutCh[mx.out_id][i];
+  } else {
+    build_feed_map(mx, cfg->out_channels, fm, b->src_feed);
   }
-  if (mx.kind == IAMF_HIP_KIND_H2M) {
-    if (mx.lfe1 >= 0 && mx.lfe1 < cfg->out_channels) b->src_feed[mx.lfe1] = -1;
-    if (mx.lfe2 >= 0 && mx.lfe2 < cfg->out_channels) b->src_feed[mx.lfe2] = -1;
-  }
-
-  // feed-major copy of the matrix: row f = coefficients of feed f over inputs 0..m-1
-  std::vector<float> fm((size_t)mx.m * mx.n);
-  for (int f = 0; f < mx.n; ++f)
-    for (int k = 0; k < mx.m; ++k)
-      fm[(size_t)f * mx.m + k] = mx.kind == IAMF_HIP_KIND_H2M ? mx.mat[f * mx.m + k] : mx.mat[k * mx.n + f];
 
   // limiter constants and the coefficient table.  currentTC only ever takes the values
   // T[n] = n-fold f32 accumulation of incTC from 0 (audio_effect_peak_limiter.c:82,242,248,263),
@@ -389,6 +455,8 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
   CREATE_CHK(hipMalloc(&b->d_ring_pm, sizeof(float) * (size_t)ns * kSave));
   CREATE_CHK(hipMalloc(&b->d_src_feed, sizeof(int32_t) * kMaxOut));
   CREATE_CHK(hipMemcpy(b->d_src_feed, b->src_feed, sizeof(int32_t) * kMaxOut, hipMemcpyHostToDevice));
+  CREATE_CHK(hipMalloc(&b->d_dmx_tab, sizeof(dmx_tab)));
+  CREATE_CHK(hipMemcpy(b->d_dmx_tab, dmx_tab, sizeof(dmx_tab), hipMemcpyHostToDevice));
   CREATE_CHK(hipMemcpy(b->d_matrix, fm.data(), sizeof(float) * fm.size(), hipMemcpyHostToDevice));
   CREATE_CHK(hipMemcpy(b->d_gains, b->h_gains.data(), sizeof(float) * 3 * ns, hipMemcpyHostToDevice));
   CREATE_CHK(hipMemcpy(b->d_ctab, ctab.data(), sizeof(float) * ctab.size(), hipMemcpyHostToDevice));
@@ -411,6 +479,10 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_ring_y);
   (void)hipFree(b->d_ring_pm);
   (void)hipFree(b->d_src_feed);
+  (void)hipFree(b->d_dmx_tab);
+  (void)hipFree(b->d_matrix2);
+  (void)hipFree(b->d_gains2);
+  (void)hipFree(b->d_src_feed2);
   delete b;
 }
 
@@ -424,27 +496,129 @@ int iamf_hip_batch_set_gains(iamf_hip_batch *b, const float *eg, const float *og
   return IAMF_HIP_OK;
 }
 
+int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *a) {
+  if (!b || !a || !a->d_in || !a->d_pcm || a->n_frames < 0) return IAMF_HIP_ERR_BAD_ARG;
+  if (b->flushed) return IAMF_HIP_ERR_INVALID_STATE;
+  if (a->n_frames == 0) return 0;
+  if (b->has2 && !a->d_in2) return IAMF_HIP_ERR_BAD_ARG;
+  if (b->dmx && !a->d_dmx_frames) return IAMF_HIP_ERR_BAD_ARG;
+  if ((a->d_element_ramp || a->d_element2_ramp || a->d_output_ramp) &&
+      a->ramp_stream_stride < (int64_t)a->n_frames * b->cfg.frame_size && b->cfg.n_streams > 1)
+    return IAMF_HIP_ERR_BAD_ARG;
+  const int64_t total = (int64_t)a->n_frames * b->cfg.frame_size;
+  if (total > INT32_MAX) return IAMF_HIP_ERR_BAD_ARG;
+  const int64_t need = total * b->cfg.out_channels * iamf_hip_format_bytes(b->cfg.out_format);
+  if (b->cfg.n_streams > 1 && a->pcm_stream_stride_bytes < need) return IAMF_HIP_ERR_BUFFER_TOO_SMALL;
+  return render_call(b, *a, (int)total);
+}
+
 int iamf_hip_batch_render(iamf_hip_batch *b, const float *d_in, int64_t in_stream_stride,
                           int64_t in_frame_stride, int32_t n_frames, void *d_pcm,
                           int64_t pcm_stream_stride_bytes, void *stream) {
-  if (!b || !d_in || !d_pcm || n_frames < 0) return IAMF_HIP_ERR_BAD_ARG;
-  if (b->flushed) return IAMF_HIP_ERR_INVALID_STATE;
-  if (n_frames == 0) return 0;
-  const int64_t total = (int64_t)n_frames * b->cfg.frame_size;
-  if (total > INT32_MAX) return IAMF_HIP_ERR_BAD_ARG;
-  const int64_t need = total * b->cfg.out_channels * iamf_hip_format_bytes(b->cfg.out_format);
-  if (b->cfg.n_streams > 1 && pcm_stream_stride_bytes < need) return IAMF_HIP_ERR_BUFFER_TOO_SMALL;
-  return render_call(b, d_in, in_stream_stride, in_frame_stride, (int)total, d_pcm,
-                     pcm_stream_stride_bytes, stream);
+  iamf_hip_render_args a;
+  memset(&a, 0, sizeof(a));
+  a.d_in = d_in;
+  a.in_stream_stride = in_stream_stride;
+  a.in_frame_stride = in_frame_stride;
+  a.n_frames = n_frames;
+  a.d_pcm = d_pcm;
+  a.pcm_stream_stride_bytes = pcm_stream_stride_bytes;
+  a.stream = stream;
+  if (b && (b->has2 || b->dmx)) return IAMF_HIP_ERR_BAD_ARG;  // those need iamf_hip_batch_render_ex
+  return iamf_hip_batch_render_ex(b, &a);
 }
 
 int iamf_hip_batch_flush(iamf_hip_batch *b, void *d_pcm, int64_t pcm_stream_stride_bytes, void *stream) {
   if (!b || !d_pcm) return IAMF_HIP_ERR_BAD_ARG;
   if (b->flushed) return IAMF_HIP_ERR_INVALID_STATE;
   if (!b->cfg.limiter_enable) return 0;
-  const int r = render_call(b, nullptr, 0, 0, kDelay, d_pcm, pcm_stream_stride_bytes, stream);
+  iamf_hip_render_args a;
+  memset(&a, 0, sizeof(a));  // no inputs: 240 zero samples go through the limiter
+  a.d_pcm = d_pcm;
+  a.pcm_stream_stride_bytes = pcm_stream_stride_bytes;
+  a.stream = stream;
+  const int r = render_call(b, a, kDelay);
   if (r >= 0) b->flushed = true;
   return r;
+}
+
+int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *mx, const float *g2) {
+  if (!b || !mx || !mx->mat || mx->m <= 0 || mx->m > kMaxIn || mx->n <= 0 || mx->n > kMaxOut ||
+      mx->kind == IAMF_HIP_KIND_DMX || b->pos != 0)
+    return IAMF_HIP_ERR_BAD_ARG;
+  std::vector<float> fm;
+  int32_t feed[kMaxOut];
+  build_feed_map(*mx, b->cfg.out_channels, fm, feed);
+  const int ns = b->cfg.n_streams;
+  std::vector<float> gains((size_t)ns, 1.0f);
+  if (g2) memcpy(gains.data(), g2, sizeof(float) * ns);
+  (void)hipFree(b->d_matrix2);
+  (void)hipFree(b->d_gains2);
+  (void)hipFree(b->d_src_feed2);
+  b->d_matrix2 = nullptr;
+  b->d_gains2 = nullptr;
+  b->d_src_feed2 = nullptr;
+  HIPCHK(hipMalloc(&b->d_matrix2, sizeof(float) * fm.size()));
+  HIPCHK(hipMalloc(&b->d_gains2, sizeof(float) * ns));
+  HIPCHK(hipMalloc(&b->d_src_feed2, sizeof(feed)));
+  HIPCHK(hipMemcpy(b->d_matrix2, fm.data(), sizeof(float) * fm.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->d_gains2, gains.data(), sizeof(float) * ns, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->d_src_feed2, feed, sizeof(feed), hipMemcpyHostToDevice));
+  b->m2 = mx->m;
+  b->has2 = true;
+  return IAMF_HIP_OK;
+}
+
+/* ---- down-mixer control plane (downmix_renderer.c:77-91,131-216; IAMF_utils.c:234-245;
+ *      fixedp11_5.c:81-99) ---- */
+int iamf_hip_dmx_layout_channels(int layout) { return layout >= 0 && layout < 9 ? kLayoutCount[layout] : 0; }
+
+int iamf_hip_dmx_valid(int in, int out) {
+  if (in == out || in < 0 || in >= 9 || out < 0 || out >= 9) return 0;  // binaural (9) is refused
+  if (kLayoutTop[in] && !kLayoutTop[out]) return 0;
+  return !(kLayoutSurround[in] < kLayoutSurround[out] || kLayoutTop[in] < kLayoutTop[out]);
+}
+
+void iamf_hip_dmx_state_init(iamf_hip_dmx_state *st) {
+  memset(st, 0, sizeof(*st));
+  st->mode = -1;
+  st->w_idx = -1;
+}
+
+int iamf_hip_dmx_set_mode_weight(iamf_hip_dmx_state *st, int mode, int w_idx) {
+  static const struct { float a, b, g, d; int woff; } mixf[7] = {
+      {1.0, 1.0, (float)0.707, (float)0.707, -1}, {(float)0.707, (float)0.707, (float)0.707, (float)0.707, -1},
+      {1.0, (float)0.866, (float)0.866, (float)0.866, -1}, {0, 0, 0, 0, 0},
+      {1.0, 1.0, (float)0.707, (float)0.707, 1}, {(float)0.707, (float)0.707, (float)0.707, (float)0.707, 1},
+      {1.0, (float)0.866, (float)0.866, (float)0.866, 1}};
+  static const float wtab[11] = {0.0, (float)0.0179, (float)0.0391, (float)0.0658, (float)0.1038, 0.25,
+                                 (float)0.3962, (float)0.4342, (float)0.4609, (float)0.4821, 0.5};
+  if (!st || mode < 0 || mode == 3 || mode >= 7) return IAMF_HIP_ERR_BAD_ARG;
+  if (st->mode != mode) {
+    st->mode = mode;
+    st->alpha = mixf[mode].a;
+    st->beta = mixf[mode].b;
+    st->gamma = mixf[mode].g;
+    st->delta = mixf[mode].d;
+    st->w_idx_offset = mixf[mode].woff;
+  }
+  if (w_idx < 0 || w_idx > 10) {  // no explicit index: step the weight state one way
+    int nw = st->w_idx_offset > 0 ? (st->w_idx + 1 < 10 ? st->w_idx + 1 : 10) : (st->w_idx - 1 > 0 ? st->w_idx - 1 : 0);
+    st->w_idx = nw;
+    st->gamma_w = st->gamma * wtab[nw];
+  } else if (st->w_idx != w_idx) {
+    st->w_idx = w_idx;
+    st->gamma_w = st->gamma * wtab[w_idx];
+  }
+  return IAMF_HIP_OK;
+}
+
+void iamf_hip_dmx_coefficients(const iamf_hip_dmx_state *st, float out[5]) {
+  out[0] = st->alpha;
+  out[1] = st->beta;
+  out[2] = st->gamma;
+  out[3] = st->delta;
+  out[4] = st->gamma_w;
 }
 
 int iamf_hip_batch_reset(iamf_hip_batch *b) {

@@ -42,6 +42,25 @@ struct RenderParams {
   int32_t n_atk, n_end;     // limiter table split points
   float thr;
   const int32_t *src_feed;  // device [out_ch]: output slot -> feed index, or -1 = silent slot
+  // ---- optional extras (generic kernel only) ----
+  const float *in2;         // second element (planar f32) or nullptr
+  int64_t in2_stream_stride, in2_frame_stride;
+  const float *matrix2;     // device, feed-major [n_feeds2][m2]
+  const int32_t *src_feed2; // device [out_ch]
+  const float *gains2;      // device [n_streams] element-2 constant gain
+  int32_t m2;
+  int32_t dmx_on;           // element 0 is rendered by the parametric down-mixer
+  const float *elem_ramp, *elem2_ramp, *out_ramp;  // per-sample gains of this call or nullptr
+  int64_t ramp_stream_stride;
+  const iamf_hip_dmx_frame *dmx_frames;  // device [n_streams][frames of this call]
+  int32_t dmx_n_in, dmx_n_out;
+  const int32_t *dmx_tab;   // device [24]: IAChannel ids of the inputs, then (from [12]) of the outputs
+};
+
+// IAChannel ids (reference IAMF_types.h:61-90; L5/R5 alias L7/R7)
+enum {
+  kChNone = 0, kChL7, kChR7, kChC, kChLFE, kChSL7, kChSR7, kChBL7, kChBR7, kChHFL, kChHFR, kChHBL,
+  kChHBR, kChMono, kChL2, kChR2, kChTL, kChTR, kChL3, kChR3, kChSL5, kChSR5, kChHL, kChHR, kChCount
 };
 
 // One gain step evaluated for a hypothetical pre-state n_pre (no trigger since the state was

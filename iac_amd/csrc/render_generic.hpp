@@ -16,6 +16,7 @@ __global__ __launch_bounds__(kChunk) void render_kernel(const RenderParams p) {
   float *arr_g = arr_e + kChunk;              // [kChunk] gains (serial fallback)
   float *head = arr_g + kChunk;               // [kHead]  ctab[0..kHead)
   float *st = head + kHead;                   // [4]      limiter state exchange
+  float *dmx_ch = st + 4;                     // [kChCount][kChunk] per-thread channel file (down-mixer only)
 
   const int s = blockIdx.x;
   const int t = threadIdx.x;
@@ -81,21 +82,104 @@ __global__ __launch_bounds__(kChunk) void render_kernel(const RenderParams p) {
       for (int m = 0; m < M; ++m) x[m] = 0.f;
     }
 
-    // ---- element renderer + gains; the rendered sample goes to the LDS delay ring ----
+    // ---- element renderer(s) + gains; the rendered sample goes to the LDS delay ring ----
+    const int fcur = valid ? k / fs : 0;
+    const int icur = k - fcur * fs;
+    float er = 1.f, er2 = 1.f, orr = 1.f;  // per-sample mix gains of this call, when given
+    if (valid) {
+      if (p.elem_ramp) er = p.elem_ramp[(int64_t)s * p.ramp_stream_stride + k];
+      if (p.elem2_ramp) er2 = p.elem2_ramp[(int64_t)s * p.ramp_stream_stride + k];
+      if (p.out_ramp) orr = p.out_ramp[(int64_t)s * p.ramp_stream_stride + k];
+    }
+    if (p.dmx_on) {
+      // parametric down-mixer (downmix_renderer.c:115-129,218-242): every derived channel is the
+      // f32 sum (from 0) of two scaled sources; input channels are taken as they are.  The
+      // thread's channel file lives in its own LDS column.
+      float cf[5] = {1.f, 1.f, 1.f, 1.f, 0.f};
+      if (valid && p.dmx_frames) {
+        const iamf_hip_dmx_frame *fr = p.dmx_frames + (int64_t)s * ((p.total + fs - 1) / fs) + fcur;
+        const bool use_prev = icur < fr->offset;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) cf[j] = use_prev ? fr->prev[j] : fr->cur[j];
+      }
+      for (int c = 0; c < kChCount; ++c) dmx_ch[c * kChunk + t] = 0.f;
+      bool is_in[kChCount];
+#pragma unroll
+      for (int c = 0; c < kChCount; ++c) is_in[c] = false;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const int ch = p.dmx_tab[m];
+        dmx_ch[ch * kChunk + t] = x[m];
+#pragma unroll
+        for (int c = 0; c < kChCount; ++c) is_in[c] = is_in[c] || (ch == c);
+      }
+      auto CH = [&](int c) -> float & { return dmx_ch[c * kChunk + t]; };
+      auto rule = [&](int dst, int s0, float k0, int s1, float k1) {
+        if (!is_in[dst]) {
+          float sum = 0.f;
+          sum = sum + CH(s0) * k0;
+          sum = sum + CH(s1) * k1;
+          CH(dst) = sum;
+        }
+      };
+      const float c707 = (float)0.707;
+      rule(kChSL5, kChSL7, cf[0], kChBL7, cf[1]);
+      rule(kChSR5, kChSR7, cf[0], kChBR7, cf[1]);
+      rule(kChHL, kChHFL, 1.f, kChHBL, cf[2]);
+      rule(kChHR, kChHFR, 1.f, kChHBR, cf[2]);
+      rule(kChL3, kChL7, 1.f, kChSL5, cf[3]);
+      rule(kChR3, kChR7, 1.f, kChSR5, cf[3]);
+      rule(kChTL, kChHL, 1.f, kChSL5, cf[4]);
+      rule(kChTR, kChHR, 1.f, kChSR5, cf[4]);
+      rule(kChL2, kChL3, 1.f, kChC, c707);
+      rule(kChR2, kChR3, 1.f, kChC, c707);
+      rule(kChMono, kChR2, 0.5f, kChL2, 0.5f);
+    }
+    const float *src2 = nullptr;
+    if (p.in2 && valid) src2 = p.in2 + (int64_t)s * p.in2_stream_stride + (int64_t)fcur * p.in2_frame_stride + icur;
+    const float eg2 = p.in2 ? p.gains2[s] : 1.f;
     float pm = 0.f;
     for (int c = 0; c < out_ch; ++c) {
-      const int f = p.src_feed[c];
       float y = 0.f;
-      if (f >= 0) {
-        const float *row = p.matrix + f * M;  // wave-uniform -> scalar loads
-        float acc = 0.f;
+      if (p.dmx_on) {
+        y = dmx_ch[p.dmx_tab[12 + c] * kChunk + t];
+      } else {
+        const int f = p.src_feed[c];
+        if (f >= 0) {
+          const float *row = p.matrix + f * M;  // wave-uniform -> scalar loads
+          float acc = 0.f;
 #pragma unroll
-        for (int m = 0; m < M; ++m) acc = acc + row[m] * x[m];
-        y = acc;
+          for (int m = 0; m < M; ++m) acc = acc + row[m] * x[m];
+          y = acc;
+        }
       }
-      if (eg_on) y = y * eg;
+      if (p.elem_ramp) {
+        y = y * er;  // iamf_frame_gain with a gains[] array: unconditional (IAMF_decoder.c:1401-1405)
+      } else if (eg_on) {
+        y = y * eg;
+      }
       y = 0.f + y;  // iamf_mixer_mix: memset 0 then += (IAMF_decoder.c:2719-2730)
-      if (og_on) y = y * og;
+      if (p.in2) {
+        float y2 = 0.f;
+        const int f2 = p.src_feed2[c];
+        if (f2 >= 0 && src2) {
+          const float *row2 = p.matrix2 + f2 * p.m2;
+          float acc = 0.f;
+          for (int m = 0; m < p.m2; ++m) acc = acc + row2[m] * src2[(int64_t)m * fs];
+          y2 = acc;
+        }
+        if (p.elem2_ramp) {
+          y2 = y2 * er2;
+        } else if (eg2 != 1.f && eg2 > 0.f) {
+          y2 = y2 * eg2;
+        }
+        y = y + y2;
+      }
+      if (p.out_ramp) {
+        y = y * orr;
+      } else if (og_on) {
+        y = y * og;
+      }
       if (lg_on) y = y * lg;
       if (valid) ring_y[c * kRing + rp] = y;
       pm = fmaxf(pm, fabsf(y));

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "iac_amd", "csrc")
 
 FMT_S16, FMT_S24, FMT_S32, FMT_F32 = 16, 24, 32, -32
-KIND_H2M, KIND_M2M = 0, 1
+KIND_H2M, KIND_M2M, KIND_DMX = 0, 1, 2
 PROJ_AUTO, PROJ_EXACT, PROJ_MFMA = 0, 1, 2
 SS = dict(A=0x020, B=0x050, C=0x250, D=0x450, E=0x451, F=0x370, G=0x490, H=0x9A3, I=0x070,
           J=0x470, STEREO=0x200, L51=0x510, L512=0x512, L514=0x514, L71=0x710, L714=0x714,
@@ -36,6 +36,25 @@ class BatchConfig(C.Structure):
                 ("out_channels", C.c_int32), ("out_format", C.c_int32), ("matrix", Matrix),
                 ("limiter_enable", C.c_int32), ("limiter_threshold_db", C.c_float),
                 ("loudness_enable", C.c_int32), ("projection", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
+class DmxState(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("w_idx", C.c_int32), ("w_idx_offset", C.c_int32),
+                ("reserved", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float), ("gamma", C.c_float),
+                ("delta", C.c_float), ("gamma_w", C.c_float)]
+
+
+class DmxFrame(C.Structure):
+    _fields_ = [("offset", C.c_int32), ("prev", C.c_float * 5), ("cur", C.c_float * 5)]
+
+
+class RenderArgs(C.Structure):
+    _fields_ = [("d_in", C.c_void_p), ("in_stream_stride", C.c_int64), ("in_frame_stride", C.c_int64),
+                ("d_in2", C.c_void_p), ("in2_stream_stride", C.c_int64), ("in2_frame_stride", C.c_int64),
+                ("d_element_ramp", C.c_void_p), ("d_element2_ramp", C.c_void_p),
+                ("d_output_ramp", C.c_void_p), ("ramp_stream_stride", C.c_int64),
+                ("d_dmx_frames", C.c_void_p), ("n_frames", C.c_int32), ("reserved", C.c_int32),
+                ("d_pcm", C.c_void_p), ("pcm_stream_stride_bytes", C.c_int64), ("stream", C.c_void_p)]
 
 
 def lib_path():
@@ -76,6 +95,15 @@ def lib():
         L.iamf_hip_batch_reset.argtypes = [C.c_void_p]
         L.iamf_hip_format_bytes.argtypes = [C.c_int]
         L.iamf_hip_version.restype = C.c_char_p
+        L.iamf_hip_batch_render_ex.argtypes = [C.c_void_p, C.POINTER(RenderArgs)]
+        L.iamf_hip_batch_set_second_element.argtypes = [C.c_void_p, C.POINTER(Matrix), FP]
+        L.iamf_hip_dmx_valid.argtypes = [C.c_int, C.c_int]
+        L.iamf_hip_dmx_layout_channels.argtypes = [C.c_int]
+        L.iamf_hip_dmx_state_init.argtypes = [C.POINTER(DmxState)]
+        L.iamf_hip_dmx_state_init.restype = None
+        L.iamf_hip_dmx_set_mode_weight.argtypes = [C.POINTER(DmxState), C.c_int, C.c_int]
+        L.iamf_hip_dmx_coefficients.argtypes = [C.POINTER(DmxState), FP]
+        L.iamf_hip_dmx_coefficients.restype = None
         _lib = L
     return _lib
 
@@ -91,6 +119,16 @@ def get_m2m_matrix(in_id, out_id):
     m = Matrix()
     if lib().iamf_hip_get_m2m_matrix(in_id, out_id, C.byref(m)) != 0:
         raise KeyError((hex(in_id), hex(out_id)))
+    return m
+
+
+def dmx_matrix(in_layout, out_layout):
+    """config 'matrix' selecting the parametric down-mixer between two IAChannelLayoutType ids"""
+    m = Matrix()
+    m.kind, m.in_id, m.out_id = KIND_DMX, in_layout, out_layout
+    m.channels = m.n = lib().iamf_hip_dmx_layout_channels(out_layout)
+    m.m = lib().iamf_hip_dmx_layout_channels(in_layout)
+    m.lfe1 = m.lfe2 = -1
     return m
 
 
@@ -141,6 +179,17 @@ class Batch:
         if r < 0:
             raise IamfHipError(r, "iamf_hip_batch_render")
         return r
+
+    def render_ex(self, args):
+        r = lib().iamf_hip_batch_render_ex(self.h, C.byref(args))
+        if r < 0:
+            raise IamfHipError(r, "iamf_hip_batch_render_ex")
+        return r
+
+    def set_second_element(self, matrix, gains=None):
+        r = lib().iamf_hip_batch_set_second_element(self.h, C.byref(matrix), _fparr(gains))
+        if r != 0:
+            raise IamfHipError(r, "iamf_hip_batch_set_second_element")
 
     def flush(self, d_pcm, pcm_stream_stride_bytes, stream=None):
         r = lib().iamf_hip_batch_flush(self.h, d_pcm, pcm_stream_stride_bytes, stream)

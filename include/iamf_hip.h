@@ -45,7 +45,9 @@ enum {
   IAMF_HIP_L_BINAURAL = 0x1020
 };
 
-enum { IAMF_HIP_KIND_H2M = 0, IAMF_HIP_KIND_M2M = 1 };
+/* element renderer kinds.  DMX = the parametric down-mixer (downmix_renderer.c): matrix.in_id /
+ * out_id are IAChannelLayoutType values (IAMF_defines.h:196-209), matrix.mat is unused. */
+enum { IAMF_HIP_KIND_H2M = 0, IAMF_HIP_KIND_M2M = 1, IAMF_HIP_KIND_DMX = 2 };
 
 /* Projection arithmetic for output layouts wider than stereo.
  *   EXACT: VALU, separate f32 multiply and add in the reference's order -> bit-identical PCM.
@@ -130,6 +132,64 @@ int iamf_hip_batch_set_gains(iamf_hip_batch *b, const float *element_gain,
 int iamf_hip_batch_render(iamf_hip_batch *b, const float *d_in, int64_t in_stream_stride,
                           int64_t in_frame_stride, int32_t n_frames, void *d_pcm,
                           int64_t pcm_stream_stride_bytes, void *stream);
+
+/* ---- parametric down-mixer control (host side of src/iamf_dec/downmix_renderer.c) ---- */
+typedef struct {
+  int32_t mode, w_idx;     /* -1 until set (DMRenderer_open, downmix_renderer.c:151-152) */
+  int32_t w_idx_offset;
+  int32_t reserved;
+  float alpha, beta, gamma, delta; /* MixFactors of the mode (IAMF_utils.c:236-240) */
+  float gamma_w;                   /* gamma * w(w_idx): the TL/TR weight (downmix_renderer.c:199-211) */
+} iamf_hip_dmx_state;
+
+/* one frame of one stream: samples [0, offset) use `prev`, the rest `cur`
+ * ({alpha, beta, gamma, delta, gamma_w}); this is how iamf_stream_render applies a demixing mode
+ * change (IAMF_decoder.c:2574-2583) */
+typedef struct {
+  int32_t offset;
+  float prev[5];
+  float cur[5];
+} iamf_hip_dmx_frame;
+
+/* 1 if DMRenderer_open(in, out) would succeed (downmix_renderer.c:77-91,131-139), else 0 */
+int iamf_hip_dmx_valid(int in_layout, int out_layout);
+/* channel count of an IAChannelLayoutType (IAMF_utils.c:111), 0 if invalid */
+int iamf_hip_dmx_layout_channels(int layout);
+void iamf_hip_dmx_state_init(iamf_hip_dmx_state *st);
+/* replaces DMRenderer_set_mode_weight (downmix_renderer.c:180-216): 0 or IAMF_HIP_ERR_BAD_ARG */
+int iamf_hip_dmx_set_mode_weight(iamf_hip_dmx_state *st, int mode, int w_idx);
+/* copies the state's five coefficients into out[5] */
+void iamf_hip_dmx_coefficients(const iamf_hip_dmx_state *st, float out[5]);
+
+/* A second audio element for the mix (a sub-mix carries 1 or 2, IAMF_OBU.c:742-752): its renderer
+ * matrix (H2M or M2M) and, per stream, its constant element mix gain.  Call before the first
+ * render.  The mix is  0 + element0 + element1  in that order (iamf_mixer_mix,
+ * IAMF_decoder.c:2719-2730). */
+int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *mx,
+                                      const float *element2_gain);
+
+/* Everything one render call can take.  Unused pointers are NULL. */
+typedef struct {
+  const float *d_in;            /* element 0 planar f32, layout as iamf_hip_batch_render */
+  int64_t in_stream_stride, in_frame_stride;
+  const float *d_in2;           /* element 1 (needs iamf_hip_batch_set_second_element) */
+  int64_t in2_stream_stride, in2_frame_stride;
+  /* per-sample mix gains for this call, [n_streams][n_frames*frame_size] f32 on the device,
+   * built by the host like iamf_database_parameter_get_mix_gain_unit (IAMF_decoder.c:857-982);
+   * when given they are multiplied in unconditionally (iamf_frame_gain, :1401-1405) and the
+   * constant gain of that stage is not used */
+  const float *d_element_ramp, *d_element2_ramp, *d_output_ramp;
+  int64_t ramp_stream_stride;   /* floats */
+  const iamf_hip_dmx_frame *d_dmx_frames; /* kind DMX: [n_streams][n_frames] on the device */
+  int32_t n_frames;
+  int32_t reserved;
+  void *d_pcm;
+  int64_t pcm_stream_stride_bytes;
+  void *stream;
+} iamf_hip_render_args;
+
+/* Extended form of iamf_hip_batch_render; same return value. */
+int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *args);
 
 /* End of stream: pushes 240 zero samples through each stream's limiter and emits the withheld
  * tail (iamf_delay_buffer_handle, IAMF_decoder.c:3250-3301).  Returns sample-frames per stream. */

@@ -1,0 +1,181 @@
+"""-m gpu: the parametric down-mixer, two-element mixing and per-sample mix-gain ramps on the HIP
+path (generic kernel), bit-exact against reference goldens / the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import e2e_cases
+import e2e_model
+import oracle_lib as O
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available()
+    import iac_amd as A
+    import gpu_util as G
+    return A, G, torch
+
+
+def _run_ex(A, G, torch, batch, S, m, x, fs, out_ch, fmt, x2=None, m2=0, ramps=None, dmx_frames=None,
+            calls=None, flush=True):
+    """x: [S][m][total]; returns list of per-stream outputs"""
+    total = x.shape[2]
+    F = total // fs
+    xin = torch.from_numpy(G.to_frames(x, fs)).cuda()
+    xin2 = torch.from_numpy(G.to_frames(x2, fs)).cuda() if x2 is not None else None
+    bps = {A.FMT_S16: 2, A.FMT_S24: 3, A.FMT_S32: 4, A.FMT_F32: 4}[fmt]
+    d_ramps = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda() for k, v in (ramps or {}).items()}
+    d_dmx = None
+    if dmx_frames is not None:
+        raw = np.frombuffer(bytes(dmx_frames), dtype=np.uint8).copy()
+        d_dmx = torch.from_numpy(raw).cuda()
+    outs = [[] for _ in range(S)]
+    st = torch.cuda.current_stream().cuda_stream
+    f0 = 0
+    for nf in (calls or [F]):
+        cap = max(nf * fs, 240) * out_ch * bps
+        pcm = torch.zeros((S, cap), dtype=torch.uint8, device="cuda")
+        a = A.RenderArgs()
+        a.d_in = xin.data_ptr() + 4 * f0 * m * fs
+        a.in_stream_stride, a.in_frame_stride = F * m * fs, m * fs
+        if xin2 is not None:
+            a.d_in2 = xin2.data_ptr() + 4 * f0 * m2 * fs
+            a.in2_stream_stride, a.in2_frame_stride = F * m2 * fs, m2 * fs
+        for key, field in (("element", "d_element_ramp"), ("element2", "d_element2_ramp"), ("output", "d_output_ramp")):
+            if key in d_ramps:
+                setattr(a, field, d_ramps[key].data_ptr() + 4 * f0 * fs)
+        a.ramp_stream_stride = total
+        if d_dmx is not None:
+            assert calls is None  # one call: frames index from 0
+            a.d_dmx_frames = d_dmx.data_ptr()
+        a.n_frames = nf
+        a.d_pcm = pcm.data_ptr()
+        a.pcm_stream_stride_bytes = cap
+        a.stream = st
+        n = batch.render_ex(a)
+        torch.cuda.synchronize()
+        h = pcm.cpu().numpy()
+        for s in range(S):
+            outs[s].append(G._view(h[s], n, out_ch, fmt))
+        f0 += nf
+    if flush:
+        cap = 240 * out_ch * bps
+        pcm = torch.zeros((S, cap), dtype=torch.uint8, device="cuda")
+        n = batch.flush(pcm.data_ptr(), cap, st)
+        torch.cuda.synchronize()
+        h = pcm.cpu().numpy()
+        for s in range(S):
+            outs[s].append(G._view(h[s], n, out_ch, fmt))
+    return [np.concatenate(o, axis=0) for o in outs]
+
+
+def test_downmixer_goldens_bit_exact(hip, golden):
+    A, G, torch = hip
+    g = golden.npz("dmx")
+    L = A.lib()
+    for key, meta in golden.manifest.items():
+        if not key.startswith("dmx/") or key.endswith("_invalid"):
+            continue
+        name = key.split("/")[1]
+        il, ol, ns = meta["in_layout"], meta["out_layout"], meta["ns"]
+        sched = [tuple(s) for s in meta["schedule"]]
+        F = len(sched)
+        assert L.iamf_hip_dmx_valid(il, ol) == 1
+        x = np.stack([synth.uniform(meta["seed0"] + f, O.LAYOUT_CH[il], ns, 0.5) for f in range(F)])  # [F][m][ns]
+        # host control plane, as IAMF_decoder.c:2574-2583 drives DMRenderer_set_mode_weight
+        st = A.DmxState()
+        L.iamf_hip_dmx_state_init(C.byref(st))
+        L.iamf_hip_dmx_set_mode_weight(C.byref(st), meta["default_mode"], meta["default_w"])
+        frames = (A.DmxFrame * F)()
+        for f, (mode, off) in enumerate(sched):
+            frames[f].offset = off
+            L.iamf_hip_dmx_coefficients(C.byref(st), frames[f].prev)
+            if mode > -1:
+                L.iamf_hip_dmx_set_mode_weight(C.byref(st), mode, -1)
+            L.iamf_hip_dmx_coefficients(C.byref(st), frames[f].cur)
+        m, oc = O.LAYOUT_CH[il], O.LAYOUT_CH[ol]
+        xs = np.ascontiguousarray(x.transpose(1, 0, 2).reshape(1, m, F * ns))
+        b = A.Batch(1, A.dmx_matrix(il, ol), oc, frame_size=ns, out_format=A.FMT_F32, limiter=False)
+        y = _run_ex(A, G, torch, b, 1, m, xs, ns, oc, A.FMT_F32, dmx_frames=frames, flush=False)[0]
+        b.close()
+        want = g[name].transpose(0, 2, 1).reshape(F * ns, oc)
+        assert y.shape == want.shape, name
+        assert np.array_equal(y, want), name
+
+
+def test_invalid_downmix_pairs_are_refused(hip, golden):
+    A, _, _ = hip
+    for a, b in golden.manifest["dmx/_invalid"]:
+        assert A.lib().iamf_hip_dmx_valid(a, b) == 0
+
+
+def test_two_elements_match_reference_decoder(hip, golden):
+    """stereo bed + 3rd-order HOA scene mixed into Sound System A, 32-bit, limiter off"""
+    A, G, torch = hip
+    _, info = e2e_cases.build("two_elements_A_s32")
+    c = info["case"]
+    e0, e1 = info["elements"]
+    out_id = e2e_model.out_id_of(c["layout"])
+    b = A.Batch(1, A.get_m2m_matrix(e2e_model.LAYOUT_RID[e0["layout"]], out_id), 2, frame_size=c["fs"],
+                out_format=A.FMT_S32, limiter=False)
+    b.set_gains(element=[e2e_model.q78_to_lin(c["element_gain_q78"])])
+    b.set_second_element(A.get_h2m_matrix(3, out_id), [1.0])
+    got = _run_ex(A, G, torch, b, 1, 2, e0["x"][None], c["fs"], 2, A.FMT_S32, x2=e1["x"][None], m2=16,
+                  calls=[2, 3])[0]
+    b.close()
+    want = golden.npz("e2e")["two_elements_A_s32"]
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_two_elements_with_limiter_vs_oracle(hip):
+    A, G, torch = hip
+    fs, F = 1024, 4
+    x0 = synth.hot(61, 12, F * fs, sigma=0.2, burst_phase=400, burst_period=2600)
+    x1 = synth.hot(62, 16, F * fs, sigma=0.2, burst_phase=1400, burst_period=2600)
+    oid = A.SS["J"]
+    b = A.Batch(1, A.get_m2m_matrix(A.SS["L714"], oid), 12, frame_size=fs)
+    b.set_gains(element=[0.8], output=[1.1])
+    b.set_second_element(A.get_h2m_matrix(3, oid), [0.6])
+    got = _run_ex(A, G, torch, b, 1, 12, x0[None], fs, 12, A.FMT_S16, x2=x1[None], m2=16)[0]
+    b.close()
+    y0 = O.render(O.get_m2m(O.SS["L714"], O.SS["J"]), x0, 12)
+    y1 = O.render(O.get_h2m(3, O.SS["J"]), x1, 12)
+    O.lib().orc_frame_gain_const(O.fp(y0), 12, F * fs, 0.8)
+    O.lib().orc_frame_gain_const(O.fp(y1), 12, F * fs, 0.6)
+    z = ((np.zeros_like(y0) + y0) + y1).astype(np.float32)
+    O.lib().orc_frame_gain_const(O.fp(z), 12, F * fs, 1.1)
+    z, _ = O.limiter_run(z, [fs] * F)
+    assert np.array_equal(got, O.pack(z, 16))
+
+
+def test_mix_gain_ramps_vs_oracle(hip):
+    """per-sample element / output gains (linear and quadratic-Bezier ramps built the way
+    IAMF_decoder.c:639-664 builds them) are applied unconditionally, sample by sample"""
+    A, G, torch = hip
+    fs, F = 960, 4
+    n = fs * F
+    x = synth.hot(71, 16, n, sigma=0.2, burst_phase=300, burst_period=2100)
+    er = np.ones(n, dtype=np.float32)
+    orr = np.ones(n, dtype=np.float32)
+    L = O.lib()
+    L.orc_mix_gain_linear(0.5, 1.25, fs, 0, fs, O.fp(er[0:fs]))
+    L.orc_mix_gain_quad(1.25, 0.7, fs, 0.2, int(0.3 * (fs + 0.1)), 0, fs, O.fp(er[fs:2 * fs]))
+    er[2 * fs:] = np.float32(0.7)
+    L.orc_mix_gain_linear(1.0, 0.9, 2 * fs, 100, 2 * fs - 100, O.fp(orr[fs:3 * fs - 100]))
+    oid = A.SS["BINAURAL"]
+    b = A.Batch(1, A.get_h2m_matrix(3, oid), 2, frame_size=fs)
+    got = _run_ex(A, G, torch, b, 1, 16, x[None], fs, 2, A.FMT_S16,
+                  ramps=dict(element=er[None], output=orr[None]), calls=[1, 3])[0]
+    b.close()
+    y = O.render(O.get_h2m(3, O.SS["BINAURAL"]), x, 2)
+    L.orc_frame_gain_ramp(O.fp(y), 2, n, O.fp(er))
+    z = (np.zeros_like(y) + y).astype(np.float32)
+    L.orc_frame_gain_ramp(O.fp(z), 2, n, O.fp(orr))
+    z, _ = O.limiter_run(z, [fs] * F)
+    assert np.array_equal(got, O.pack(z, 16))
