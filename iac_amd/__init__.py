@@ -22,6 +22,7 @@ from .hipabi import (  # noqa: F401
     DmxFrame,
     DmxState,
     RenderArgs,
+    Resampler,
     dmx_matrix,
     IamfHipError,
     Matrix,

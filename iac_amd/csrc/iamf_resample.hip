@@ -1,0 +1,308 @@
+// iamf_resample.hip — the decoder's sample-rate converter (reference src/iamf_dec/resample.c, a
+// speexdsp derivative at quality 4; glue iamf_resample, IAMF_decoder.c:3223-3248) for a batch of
+// streams on the GPU.
+//
+// The reference walks each channel serially with a phase accumulator.  Output k of a call is a
+// pure function of the call's start state: pos_k = last_sample + floor((frac + k*num)/den),
+// phase_k = (frac + k*num) mod den, so every (stream, output, channel) is one independent thread
+// doing the reference's 64-tap f32 dot product in the reference's order (bit-exact).  Buffers are
+// interleaved f32 ([sample][channel]) — what the render kernels emit with IAMF_HIP_FMT_F32 and
+// what a frame_size-1 batch consumes — so the resampled path is: render(F32, limiter off) ->
+// resample -> render(identity matrix, loudness, limiter, PCM pack).
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/iamf_hip.h"
+#include "../data/resample_window_q4.h"
+
+namespace {
+
+struct RsParams {
+  const float *in;        // [stream][ns][ch] or nullptr (zeros)
+  int64_t in_stream_stride;
+  const float *hist;      // [stream][N-1][ch]
+  float *hist_next;       // [stream][N-1][ch]
+  float *out;             // [stream][cap][ch]
+  int64_t out_stream_stride;
+  const float *table;
+  int32_t ch, ns, n_out, consumed;
+  int32_t N, oversample, direct;
+  uint32_t num, den, int_adv;
+  int32_t ls0;
+  uint32_t fr0;
+};
+
+// resample.c:246-256
+__device__ __forceinline__ void cubic_coef(float frac, float interp[4]) {
+  interp[0] = -0.16667f * frac + 0.16667f * frac * frac * frac;
+  interp[1] = frac + 0.5f * frac * frac - 0.5f * frac * frac * frac;
+  interp[3] = -0.33333f * frac + 0.5f * frac * frac - 0.16667f * frac * frac * frac;
+  interp[2] = (float)(1. - interp[0] - interp[1] - interp[3]);
+}
+
+__global__ __launch_bounds__(256) void resample_kernel(const RsParams p) {
+  const int s = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // flat (output, channel)
+  const int hist_len = p.N - 1;
+  const float *in = p.in ? p.in + (int64_t)s * p.in_stream_stride : nullptr;
+  const float *hist = p.hist + (int64_t)s * hist_len * p.ch;
+
+  // history for the next call: [hist | in] shifted by the consumed samples (resample.c:801-809)
+  if (e < (int64_t)hist_len * p.ch) {
+    const int j = (int)(e / p.ch), c = (int)(e - (int64_t)j * p.ch);
+    const int src = j + p.consumed;  // index into [hist | in]
+    float v = 0.f;
+    if (src < hist_len)
+      v = hist[src * p.ch + c];
+    else if (in)
+      v = in[(int64_t)(src - hist_len) * p.ch + c];
+    p.hist_next[((int64_t)s * hist_len + j) * p.ch + c] = v;
+  }
+  if (e >= (int64_t)p.n_out * p.ch) return;
+  const int k = (int)(e / p.ch), c = (int)(e - (int64_t)k * p.ch);
+  const uint64_t tot = (uint64_t)p.fr0 + (uint64_t)k * p.num;  // int_adv*den + frac_adv == num
+  const int pos = p.ls0 + (int)(tot / p.den);
+  const uint32_t frac = (uint32_t)(tot % p.den);
+  const int N = p.N;
+
+  // sample j of the window = position pos + j of [hist | in]
+  auto tap = [&](int j) -> float {
+    const int idx = pos + j;
+    if (idx < hist_len) return hist[idx * p.ch + c];
+    return in ? in[(int64_t)(idx - hist_len) * p.ch + c] : 0.f;
+  };
+
+  float sum;
+  if (p.direct) {  // resample.c:273-281
+    const float *sinct = p.table + (size_t)frac * N;
+    sum = 0.f;
+    for (int j = 0; j < N; ++j) sum = sum + sinct[j] * tap(j);
+  } else {  // resample.c:372-400
+    const int offset = (int)(frac * (uint32_t)p.oversample / p.den);
+    const float fr = ((float)((frac * (uint32_t)p.oversample) % p.den)) / (float)p.den;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int j = 0; j < N; ++j) {
+      const float cur = tap(j);
+      const float *t = p.table + 4 + (j + 1) * p.oversample - offset;
+      a0 = a0 + cur * t[-2];
+      a1 = a1 + cur * t[-1];
+      a2 = a2 + cur * t[0];
+      a3 = a3 + cur * t[1];
+    }
+    float interp[4];
+    cubic_coef(fr, interp);
+    sum = interp[0] * a0 + interp[1] * a1 + interp[2] * a2 + interp[3] * a3;
+  }
+  sum = sum < -1.0f ? -1.0f : (sum > 1.0f ? 1.0f : sum);  // FLTADJUST, resample.c:84,959
+  p.out[(int64_t)s * p.out_stream_stride + e] = sum;
+}
+
+// ---- filter design on the host: resample.c:194-231 (window, sinc) and :527-611 ----
+double window_at(float x) {
+  float y, frac;
+  double interp[4];
+  int ind;
+  y = x * IAMF_RS_Q4_WINDOW_OVERSAMPLE;
+  ind = (int)floor(y);
+  frac = (y - ind);
+  interp[3] = -0.1666666667 * frac + 0.1666666667 * (frac * frac * frac);
+  interp[2] = frac + 0.5 * (frac * frac) - 0.5 * (frac * frac * frac);
+  interp[0] = -0.3333333333 * frac + 0.5 * (frac * frac) - 0.1666666667 * (frac * frac * frac);
+  interp[1] = 1.f - interp[3] - interp[2] - interp[0];
+  return interp[0] * iamf_rs_q4_window[ind] + interp[1] * iamf_rs_q4_window[ind + 1] +
+         interp[2] * iamf_rs_q4_window[ind + 2] + interp[3] * iamf_rs_q4_window[ind + 3];
+}
+
+float sinc_at(float cutoff, float x, int N) {
+  float xx = x * cutoff;
+  if (fabs(x) < 1e-6)
+    return cutoff;
+  else if (fabs(x) > .5 * N)
+    return 0;
+  return (float)(cutoff * sin(M_PI * xx) / (M_PI * xx) * window_at((float)fabs(2. * x / N)));
+}
+
+unsigned gcd_u(unsigned a, unsigned b) {
+  while (b) {
+    unsigned t = a;
+    a = b;
+    b = t % b;
+  }
+  return a;
+}
+
+#define RS_HIPCHK(expr)                                                                \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      fprintf(stderr, "iamf_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), \
+              __FILE__, __LINE__);                                                     \
+      return IAMF_HIP_ERR_DEVICE;                                                      \
+    }                                                                                  \
+  } while (0)
+
+}  // namespace
+
+struct iamf_hip_resampler {
+  int n_streams = 0, ch = 0, in_rate = 0, out_rate = 0;
+  unsigned num = 0, den = 0, filt_len = 0, oversample = 0, int_adv = 0, frac_adv = 0;
+  int direct = 0;
+  float cutoff = 0.f;
+  int last_sample = 0;
+  unsigned frac = 0;
+  float *d_table = nullptr, *d_hist[2] = {nullptr, nullptr};
+  int cur = 0;
+};
+
+namespace {
+
+int rs_run(iamf_hip_resampler *r, const float *d_in, int64_t in_stride, int ns, float *d_out,
+           int64_t out_stride, int out_len, void *stream) {
+  // host replica of the phase walk (resample.c:269-303): how many outputs this call yields
+  int ls = r->last_sample;
+  unsigned fr = r->frac;
+  int n_out = 0;
+  while (!(ls >= ns || n_out >= out_len)) {
+    ++n_out;
+    ls += (int)r->int_adv;
+    fr += r->frac_adv;
+    if (fr >= r->den) {
+      fr -= r->den;
+      ls++;
+    }
+  }
+  const int consumed = ls < ns ? ls : ns;  // resample.c:801-804
+  RsParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = d_in;
+  p.in_stream_stride = in_stride;
+  p.hist = r->d_hist[r->cur];
+  p.hist_next = r->d_hist[r->cur ^ 1];
+  p.out = d_out;
+  p.out_stream_stride = out_stride;
+  p.table = r->d_table;
+  p.ch = r->ch;
+  p.ns = ns;
+  p.n_out = n_out;
+  p.consumed = consumed;
+  p.N = (int)r->filt_len;
+  p.oversample = (int)r->oversample;
+  p.direct = r->direct;
+  p.num = r->num;
+  p.den = r->den;
+  p.int_adv = r->int_adv;
+  p.ls0 = r->last_sample;
+  p.fr0 = r->frac;
+  const int64_t work = (int64_t)(n_out > (int)r->filt_len - 1 ? n_out : (int)r->filt_len - 1) * r->ch;
+  dim3 grid((unsigned)((work + 255) / 256), (unsigned)r->n_streams);
+  hipLaunchKernelGGL(resample_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  RS_HIPCHK(hipGetLastError());
+  r->last_sample = ls - consumed;
+  r->frac = fr;
+  r->cur ^= 1;
+  return n_out;
+}
+
+}  // namespace
+
+extern "C" {
+
+int iamf_hip_resampler_create(int n_streams, int channels, int in_rate, int out_rate,
+                              iamf_hip_resampler **out) {
+  if (!out || n_streams <= 0 || channels <= 0 || channels > 24 || in_rate <= 0 || out_rate <= 0)
+    return IAMF_HIP_ERR_BAD_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  RS_HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return IAMF_HIP_ERR_DEVICE;
+  iamf_hip_resampler *r = new (std::nothrow) iamf_hip_resampler();
+  if (!r) return IAMF_HIP_ERR_ALLOC_FAIL;
+  r->n_streams = n_streams;
+  r->ch = channels;
+  r->in_rate = in_rate;
+  r->out_rate = out_rate;
+  const unsigned g = gcd_u((unsigned)in_rate, (unsigned)out_rate);
+  r->num = (unsigned)in_rate / g;
+  r->den = (unsigned)out_rate / g;
+  r->int_adv = r->num / r->den;
+  r->frac_adv = r->num % r->den;
+  r->oversample = IAMF_RS_Q4_OVERSAMPLE;
+  r->filt_len = IAMF_RS_Q4_BASE_LENGTH;
+  if (r->num > r->den) {  // down-sampling: longer, narrower filter (resample.c:539-552)
+    r->cutoff = IAMF_RS_Q4_DOWN_BW * r->den / r->num;
+    r->filt_len = (unsigned)((unsigned long long)r->filt_len * r->num / r->den);
+    r->filt_len = ((r->filt_len - 1) & (~0x7U)) + 8;
+    if (2 * r->den < r->num) r->oversample >>= 1;
+    if (4 * r->den < r->num) r->oversample >>= 1;
+    if (8 * r->den < r->num) r->oversample >>= 1;
+    if (16 * r->den < r->num) r->oversample >>= 1;
+    if (r->oversample < 1) r->oversample = 1;
+  } else {
+    r->cutoff = IAMF_RS_Q4_UP_BW;
+  }
+  r->direct = r->filt_len * r->den <= r->filt_len * r->oversample + 8;
+  std::vector<float> tab;
+  if (r->direct) {
+    tab.resize((size_t)r->filt_len * r->den);
+    for (unsigned i = 0; i < r->den; i++)
+      for (int j = 0; j < (int)r->filt_len; j++)
+        tab[(size_t)i * r->filt_len + j] =
+            sinc_at(r->cutoff, ((j - (int)r->filt_len / 2 + 1) - ((float)i) / r->den), (int)r->filt_len);
+  } else {
+    tab.resize((size_t)r->filt_len * r->oversample + 8);
+    for (int i = -4; i < (int)(r->oversample * r->filt_len + 4); i++)
+      tab[i + 4] = sinc_at(r->cutoff, (i / (float)r->oversample - r->filt_len / 2), (int)r->filt_len);
+  }
+  r->last_sample = (int)(r->filt_len / 2);  // speex_resampler_skip_zeros (IAMF_decoder.c:1902)
+  r->frac = 0;
+  const size_t hist_bytes = sizeof(float) * (size_t)n_streams * (r->filt_len - 1) * channels;
+  if (hipMalloc(&r->d_table, sizeof(float) * tab.size()) != hipSuccess ||
+      hipMalloc(&r->d_hist[0], hist_bytes) != hipSuccess || hipMalloc(&r->d_hist[1], hist_bytes) != hipSuccess ||
+      hipMemcpy(r->d_table, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(r->d_hist[0], 0, hist_bytes) != hipSuccess || hipMemset(r->d_hist[1], 0, hist_bytes) != hipSuccess) {
+    iamf_hip_resampler_destroy(r);
+    return IAMF_HIP_ERR_DEVICE;
+  }
+  *out = r;
+  return IAMF_HIP_OK;
+}
+
+void iamf_hip_resampler_destroy(iamf_hip_resampler *r) {
+  if (!r) return;
+  (void)hipFree(r->d_table);
+  (void)hipFree(r->d_hist[0]);
+  (void)hipFree(r->d_hist[1]);
+  delete r;
+}
+
+int iamf_hip_resampler_out_capacity(const iamf_hip_resampler *r, int ns) {
+  return r ? ns * (r->out_rate / r->in_rate + 1) : 0;
+}
+
+int iamf_hip_resampler_flush_capacity(const iamf_hip_resampler *r) {
+  return r ? (int)(((r->filt_len / 2) * r->den + (r->num >> 1)) / r->num) : 0;
+}
+
+int iamf_hip_resampler_process(iamf_hip_resampler *r, const float *d_in, int64_t in_stream_stride, int ns,
+                               float *d_out, int64_t out_stream_stride, void *stream) {
+  if (!r || !d_in || !d_out || ns < 0) return IAMF_HIP_ERR_BAD_ARG;
+  const int cap = iamf_hip_resampler_out_capacity(r, ns);
+  if (r->n_streams > 1 && out_stream_stride < (int64_t)cap * r->ch) return IAMF_HIP_ERR_BUFFER_TOO_SMALL;
+  return rs_run(r, d_in, in_stream_stride, ns, d_out, out_stream_stride, cap, stream);
+}
+
+int iamf_hip_resampler_flush(iamf_hip_resampler *r, float *d_out, int64_t out_stream_stride, void *stream) {
+  if (!r || !d_out) return IAMF_HIP_ERR_BAD_ARG;
+  const int cap = iamf_hip_resampler_flush_capacity(r);
+  return rs_run(r, nullptr, 0, (int)(r->filt_len / 2), d_out, out_stream_stride, cap, stream);
+}
+
+}  // extern "C"

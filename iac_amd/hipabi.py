@@ -97,6 +97,14 @@ def lib():
         L.iamf_hip_version.restype = C.c_char_p
         L.iamf_hip_batch_render_ex.argtypes = [C.c_void_p, C.POINTER(RenderArgs)]
         L.iamf_hip_batch_set_second_element.argtypes = [C.c_void_p, C.POINTER(Matrix), FP]
+        L.iamf_hip_resampler_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.iamf_hip_resampler_destroy.argtypes = [C.c_void_p]
+        L.iamf_hip_resampler_destroy.restype = None
+        L.iamf_hip_resampler_out_capacity.argtypes = [C.c_void_p, C.c_int]
+        L.iamf_hip_resampler_flush_capacity.argtypes = [C.c_void_p]
+        L.iamf_hip_resampler_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                                 C.c_void_p]
+        L.iamf_hip_resampler_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.iamf_hip_dmx_valid.argtypes = [C.c_int, C.c_int]
         L.iamf_hip_dmx_layout_channels.argtypes = [C.c_int]
         L.iamf_hip_dmx_state_init.argtypes = [C.POINTER(DmxState)]
@@ -212,3 +220,37 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+class Resampler:
+    """Thin handle on iamf_hip_resampler_*; buffers are raw device addresses (interleaved f32)."""
+
+    def __init__(self, n_streams, channels, in_rate, out_rate):
+        h = C.c_void_p()
+        r = lib().iamf_hip_resampler_create(n_streams, channels, in_rate, out_rate, C.byref(h))
+        if r != 0:
+            raise IamfHipError(r, "iamf_hip_resampler_create")
+        self.h = h
+
+    def out_capacity(self, ns):
+        return lib().iamf_hip_resampler_out_capacity(self.h, ns)
+
+    def flush_capacity(self):
+        return lib().iamf_hip_resampler_flush_capacity(self.h)
+
+    def process(self, d_in, in_stride, ns, d_out, out_stride, stream=None):
+        r = lib().iamf_hip_resampler_process(self.h, d_in, in_stride, ns, d_out, out_stride, stream)
+        if r < 0:
+            raise IamfHipError(r, "iamf_hip_resampler_process")
+        return r
+
+    def flush(self, d_out, out_stride, stream=None):
+        r = lib().iamf_hip_resampler_flush(self.h, d_out, out_stride, stream)
+        if r < 0:
+            raise IamfHipError(r, "iamf_hip_resampler_flush")
+        return r
+
+    def close(self):
+        if self.h:
+            lib().iamf_hip_resampler_destroy(self.h)
+            self.h = None

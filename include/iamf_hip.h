@@ -196,6 +196,30 @@ int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *args
 int iamf_hip_batch_flush(iamf_hip_batch *b, void *d_pcm, int64_t pcm_stream_stride_bytes,
                          void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Sample-rate converter for a batch of streams (the decoder's speexdsp-derived resampler at
+ * quality 4, src/iamf_dec/resample.c; the decoder only creates one when the stream rate differs
+ * from the requested output rate, IAMF_decoder.c:3193-3199).  Buffers are interleaved f32
+ * [sample-frame][channel] on the device: the output of a batch with IAMF_HIP_FMT_F32, the input
+ * of a batch with frame_size 1.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct iamf_hip_resampler iamf_hip_resampler;
+/* replaces speex_resampler_init(channels, in, out, 4) + speex_resampler_skip_zeros as
+ * iamf_stream_resampler_open calls them (IAMF_decoder.c:1892-1909); one state per stream */
+int iamf_hip_resampler_create(int n_streams, int channels, int in_rate, int out_rate,
+                              iamf_hip_resampler **out);
+void iamf_hip_resampler_destroy(iamf_hip_resampler *r);
+/* sample-frames the output buffer must hold for ns input frames: ns * (out/in + 1), integer
+ * division, as iamf_resample asks (IAMF_decoder.c:3225-3226) */
+int iamf_hip_resampler_out_capacity(const iamf_hip_resampler *r, int ns);
+int iamf_hip_resampler_flush_capacity(const iamf_hip_resampler *r);
+/* replaces iamf_resample / speex_resampler_process_interleaved_float (IAMF_decoder.c:3223-3248,
+ * resample.c:974-997).  Stream strides in floats.  Returns sample-frames produced per stream. */
+int iamf_hip_resampler_process(iamf_hip_resampler *r, const float *d_in, int64_t in_stream_stride,
+                               int ns, float *d_out, int64_t out_stream_stride, void *stream);
+/* end of stream (rest_flag 2, IAMF_decoder.c:3227-3232): drains the filter latency */
+int iamf_hip_resampler_flush(iamf_hip_resampler *r, float *d_out, int64_t out_stream_stride, void *stream);
+
 /* Forgets all stream state (new IA sequence: limiter re-initialised as in
  * iamf_decoder_internal_configure, IAMF_decoder.c:3809-3815).  Synchronous. */
 int iamf_hip_batch_reset(iamf_hip_batch *b);

@@ -234,6 +234,51 @@ def main():
     assert len(manifest["dmx/_invalid"]) == len(invalid)
     np.savez_compressed(os.path.join(GOLD, "dmx.npz"), **out)
 
+    # ---- K6: resampler (speex-derived), driven like iamf_resample (IAMF_decoder.c:3223-3248) ----
+    ref.speex_resampler_init.restype = C.c_void_p
+    ref.speex_resampler_init.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int)]
+    ref.speex_resampler_skip_zeros.argtypes = [C.c_void_p]
+    ref.speex_resampler_process_interleaved_float.argtypes = [C.c_void_p, FP, C.POINTER(C.c_uint32), FP,
+                                                              C.POINTER(C.c_uint32)]
+    ref.speex_resampler_get_input_latency.argtypes = [C.c_void_p]
+    ref.speex_resampler_get_output_latency.argtypes = [C.c_void_p]
+    ref.speex_resampler_destroy.argtypes = [C.c_void_p]
+    out = {}
+    rs_cases = [("441_48_2ch", 44100, 48000, 2, [1024] * 6), ("16_48_2ch", 16000, 48000, 2, [960] * 4),
+                ("48_16_6ch", 48000, 16000, 6, [1024] * 4), ("32_48_ragged", 32000, 48000, 1, [100, 333, 1024, 7, 640]),
+                ("24_48_12ch", 24000, 48000, 12, [512] * 3), ("48_441_2ch", 48000, 44100, 2, [1024] * 4),
+                ("8_48_1ch", 8000, 48000, 1, [160] * 5)]
+    for name, ir, orate, ch, sizes in rs_cases:
+        total = sum(sizes)
+        x = synth.hot(600 + ch, ch, total, sigma=0.3, burst_amp=1.2, burst_len=60, burst_phase=50, burst_period=700)
+        err = C.c_int(0)
+        st = ref.speex_resampler_init(ch, ir, orate, 4, C.byref(err))
+        assert st and err.value == 0
+        ref.speex_resampler_skip_zeros(st)
+        outs, rets, pos = [], [], 0
+        for ns in sizes:
+            inter = np.ascontiguousarray(x[:, pos:pos + ns].T)
+            pos += ns
+            cap = ns * (orate // ir + 1)
+            o = np.zeros((cap, ch), dtype=np.float32)
+            il, ol = C.c_uint32(ns), C.c_uint32(cap)
+            ref.speex_resampler_process_interleaved_float(st, inter.ctypes.data_as(FP), C.byref(il),
+                                                          o.ctypes.data_as(FP), C.byref(ol))
+            assert il.value == ns
+            outs.append(o[:ol.value].T.copy())
+            rets.append(ol.value)
+        il = C.c_uint32(ref.speex_resampler_get_input_latency(st))
+        ol = C.c_uint32(ref.speex_resampler_get_output_latency(st))
+        o = np.zeros((max(ol.value, 1), ch), dtype=np.float32)
+        ref.speex_resampler_process_interleaved_float(st, None, C.byref(il), o.ctypes.data_as(FP), C.byref(ol))
+        outs.append(o[:ol.value].T.copy())
+        rets.append(ol.value)
+        ref.speex_resampler_destroy(st)
+        out[name] = np.concatenate(outs, axis=1)
+        out[name + "_rets"] = np.array(rets, dtype=np.int32)
+        manifest["resample/" + name] = dict(in_rate=ir, out_rate=orate, ch=ch, sizes=sizes, seed=600 + ch)
+    np.savez_compressed(os.path.join(GOLD, "resample.npz"), **out)
+
     extra = os.path.join(HERE, "gen_golden_extra.py")
     if os.path.exists(extra):
         import importlib.util

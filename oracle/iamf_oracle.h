@@ -97,6 +97,8 @@ void orc_resampler_close(orc_resampler *r);
 /* planar in[ch][ns] -> planar out[ch][ret]; mirrors iamf_resample, IAMF_decoder.c:3223-3248 */
 int orc_resample(orc_resampler *r, const float *in, float *out, int ns);
 int orc_resample_flush(orc_resampler *r, float *out);
+int orc_resample_out_capacity(const orc_resampler *r, int ns);
+int orc_resample_flush_capacity(const orc_resampler *r);
 
 /* ---- one stream, render -> pack: the stage order of IAMF_decoder.c:3335-3500 ---- */
 typedef struct {

@@ -78,6 +78,8 @@ def lib():
             L.orc_resampler_close.argtypes = [C.c_void_p]
             L.orc_resample.argtypes = [C.c_void_p, FP, FP, C.c_int]
             L.orc_resample_flush.argtypes = [C.c_void_p, FP]
+            L.orc_resample_out_capacity.argtypes = [C.c_void_p, C.c_int]
+            L.orc_resample_flush_capacity.argtypes = [C.c_void_p]
         assert L.orc_tables_load(TABLES.encode()) == 0
         _lib = L
     return _lib
@@ -244,3 +246,28 @@ def stream_run(mx, out_channels, x, frame_size, flush=True, **kw):
         outs.append(s.flush())
     s.close()
     return np.concatenate(outs, axis=0)
+
+
+def resample_run(x, in_rate, out_rate, sizes, flush=True):
+    """x [ch][total] -> (y [ch][n_out], per-call counts), driven like iamf_resample"""
+    L = lib()
+    ch = x.shape[0]
+    r = L.orc_resampler_open(ch, in_rate, out_rate, 4)
+    assert r
+    outs, rets, pos = [], [], 0
+    for ns in sizes:
+        xi = np.ascontiguousarray(x[:, pos:pos + ns], dtype=np.float32)
+        pos += ns
+        cap = L.orc_resample_out_capacity(r, ns)
+        o = np.zeros((ch, cap), dtype=np.float32)
+        n = L.orc_resample(r, fp(xi), fp(o), ns)
+        outs.append(o[:, :n].copy())
+        rets.append(n)
+    if flush:
+        cap = max(L.orc_resample_flush_capacity(r), 1)
+        o = np.zeros((ch, cap), dtype=np.float32)
+        n = L.orc_resample_flush(r, fp(o))
+        outs.append(o[:, :n].copy())
+        rets.append(n)
+    L.orc_resampler_close(r)
+    return np.concatenate(outs, axis=1), rets

@@ -179,3 +179,94 @@ def test_mix_gain_ramps_vs_oracle(hip):
     L.orc_frame_gain_ramp(O.fp(z), 2, n, O.fp(orr))
     z, _ = O.limiter_run(z, [fs] * F)
     assert np.array_equal(got, O.pack(z, 16))
+
+
+def test_resampler_goldens_bit_exact(hip, golden):
+    """every rate pair of the reference goldens (direct and interpolated filters, up and down,
+    ragged call sizes, end-of-stream drain), two streams per batch"""
+    A, G, torch = hip
+    g = golden.npz("resample")
+    st = torch.cuda.current_stream().cuda_stream
+    for key, meta in golden.manifest.items():
+        if not key.startswith("resample/"):
+            continue
+        name = key.split("/")[1]
+        ch, sizes = meta["ch"], meta["sizes"]
+        x = synth.hot(meta["seed"], ch, sum(sizes), sigma=0.3, burst_amp=1.2, burst_len=60, burst_phase=50,
+                      burst_period=700)
+        xs = np.stack([x, (x * np.float32(0.5)).astype(np.float32)])  # stream 1: half amplitude
+        r = A.Resampler(2, ch, meta["in_rate"], meta["out_rate"])
+        outs, rets, pos = [[], []], [], 0
+        for ns in sizes:
+            inter = torch.from_numpy(np.ascontiguousarray(xs[:, :, pos:pos + ns].transpose(0, 2, 1))).cuda()
+            pos += ns
+            cap = r.out_capacity(ns)
+            o = torch.zeros((2, cap, ch), dtype=torch.float32, device="cuda")
+            n = r.process(inter.data_ptr(), ns * ch, ns, o.data_ptr(), cap * ch, st)
+            torch.cuda.synchronize()
+            h = o.cpu().numpy()
+            rets.append(n)
+            for s in range(2):
+                outs[s].append(h[s, :n].T.copy())
+        cap = max(r.flush_capacity(), 1)
+        o = torch.zeros((2, cap, ch), dtype=torch.float32, device="cuda")
+        n = r.flush(o.data_ptr(), cap * ch, st)
+        torch.cuda.synchronize()
+        h = o.cpu().numpy()
+        rets.append(n)
+        for s in range(2):
+            outs[s].append(h[s, :n].T.copy())
+        r.close()
+        assert rets == list(g[name + "_rets"]), name
+        y0 = np.concatenate(outs[0], axis=1)
+        assert np.array_equal(y0.view(np.uint32), g[name].view(np.uint32)), name
+        y1, _ = O.resample_run(xs[1], meta["in_rate"], meta["out_rate"], sizes)
+        assert np.array_equal(np.concatenate(outs[1], axis=1).view(np.uint32), y1.view(np.uint32)), name
+
+
+def test_resampled_pipeline_vs_oracle(hip):
+    """44.1 kHz stereo element -> Sound System A at 48 kHz: render (f32) -> resample -> limiter +
+    pack as three launches, against the oracle's stages in the decoder's order
+    (IAMF_decoder.c:3459-3500)."""
+    A, G, torch = hip
+    fs, F = 1024, 5
+    x = synth.hot(91, 2, F * fs, sigma=0.25, burst_phase=200, burst_period=1800)
+    st = torch.cuda.current_stream().cuda_stream
+    mx = A.get_m2m_matrix(A.SS["STEREO"], A.SS["A"])
+    stage1 = A.Batch(1, mx, 2, frame_size=fs, sample_rate=44100, out_format=A.FMT_F32, limiter=False)
+    rs = A.Resampler(1, 2, 44100, 48000)
+    stage3 = A.Batch(1, G.identity_matrix(2), 2, frame_size=1, sample_rate=48000, out_format=A.FMT_S16, limiter=True)
+    xin = torch.from_numpy(G.to_frames(x[None], fs)).cuda()
+    got = []
+    for f in range(F):
+        mid = torch.zeros((fs, 2), dtype=torch.float32, device="cuda")
+        n1 = stage1.render(xin.data_ptr() + 4 * f * 2 * fs, F * 2 * fs, 2 * fs, 1, mid.data_ptr(), fs * 2 * 4, st)
+        assert n1 == fs
+        cap = rs.out_capacity(fs)
+        res = torch.zeros((cap, 2), dtype=torch.float32, device="cuda")
+        n2 = rs.process(mid.data_ptr(), fs * 2, fs, res.data_ptr(), cap * 2, st)
+        pcm = torch.zeros((max(n2, 240), 2), dtype=torch.int16, device="cuda")
+        n3 = stage3.render(res.data_ptr(), cap * 2, 2, n2, pcm.data_ptr(), pcm.numel() * 2, st)
+        torch.cuda.synchronize()
+        got.append(pcm.cpu().numpy()[:n3])
+    # end of stream (iamf_delay_buffer_handle, IAMF_decoder.c:3250-3301): resampler tail + 240 zeros
+    cap = rs.flush_capacity()
+    tail = torch.zeros((cap + 240, 2), dtype=torch.float32, device="cuda")
+    n2 = rs.flush(tail.data_ptr(), (cap + 240) * 2, st)
+    pcm = torch.zeros((n2 + 240, 2), dtype=torch.int16, device="cuda")
+    n3 = stage3.render(tail.data_ptr(), (cap + 240) * 2, 2, n2 + 240, pcm.data_ptr(), pcm.numel() * 2, st)
+    torch.cuda.synchronize()
+    got.append(pcm.cpu().numpy()[:n3])
+    got = np.concatenate(got, axis=0)
+
+    y = O.render(O.get_m2m(O.SS["STEREO"], O.SS["A"]), x, 2)
+    z = (np.zeros_like(y) + y).astype(np.float32)
+    r, rets = O.resample_run(z, 44100, 48000, [fs] * F, flush=True)
+    n_tail = rets[-1]
+    body, tail_o = r[:, :r.shape[1] - n_tail], r[:, r.shape[1] - n_tail:]
+    sizes = rets[:-1] + [n_tail + 240]
+    lim_in = np.concatenate([body, tail_o, np.zeros((2, 240), dtype=np.float32)], axis=1)
+    zl, _ = O.limiter_run(lim_in, sizes, flush=False)
+    want = O.pack(zl, 16)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
