@@ -33,7 +33,12 @@ WORKLOADS = {
     "toa_binaural_limiter_s16": ("h2m", 3, 0x1020, 16, 16 * 4 + 2 * 2),
     "toa_ssH_limiter_s16": ("h2m", 3, 0x9A3, 16, 16 * 4 + 24 * 2),
     "714_ssJ_limiter_s16": ("m2m", 0x714, 0x470, 12, 12 * 4 + 12 * 2),
+    # binaural by HRTF FIR (256-tap synthetic HRIRs; the reference's own binauraliser is not in its
+    # tree -> "parity unpinned"): compute-bound on the f32 MFMA, 2*16*2*256 flop per sample-frame
+    "toa_hrtf256_limiter_s16": ("fir", 3, 0x1020, 16, 16 * 4 + 2 * 2),
 }
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA, dense (155 TF measured)
+FIR_TAPS = 256
 
 
 def synth_hot_device(n_streams, in_ch, frames, fs, seed, device):
@@ -131,14 +136,20 @@ def main():
 
     import iac_amd as A
     kind, in_id, out_id, in_ch, bytes_per_sf = WORKLOADS[args.workload]
-    mx = A.get_h2m_matrix(in_id, out_id) if kind == "h2m" else A.get_m2m_matrix(in_id, out_id)
+    if kind == "fir":
+        rng = np.random.default_rng(5)
+        hr = (rng.standard_normal((2, in_ch, FIR_TAPS)) * np.exp(-np.arange(FIR_TAPS) / 40.0) * 0.08).astype(np.float32)
+        mx = A.fir_matrix(hr)
+    else:
+        mx = A.get_h2m_matrix(in_id, out_id) if kind == "h2m" else A.get_m2m_matrix(in_id, out_id)
     out_ch = A.layout_channels(out_id)
     S, F, fs = args.streams, args.frames, args.frame_size
 
     x = synth_hot_device(S, in_ch, F, fs, 1000 + rank, dev)
     if args.signal == "quiet":
         x = (torch.randn_like(x) * 0.05).contiguous()
-    batch = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True)
+    batch = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True,
+                    fir_taps=FIR_TAPS if kind == "fir" else 0)
     stride_bytes = F * fs * out_ch * 2
     pcm = [torch.zeros((S, stride_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
     gather_on = world > 1 and not args.no_gather
@@ -188,7 +199,7 @@ def main():
         total_sf = sf_per_step * args.steps * world
         value = total_sf / elapsed / 1e6
         achieved = bytes_per_sf * sf_per_step / (kernel_ms * 1e-3) / 1e9
-        ktag = "render_fast_kernel<%d, %d>" % (in_ch, out_ch) if out_ch <= 2 else "render_kernel<%d>" % in_ch
+        ktag = "render_fast_kernel<%d, %d" % (in_ch, out_ch) if out_ch <= 2 else "render_wide_kernel<%d" % in_ch
         traffic = measured_traffic(ktag, sf_per_step)
         out = {
             "metric": "Msamples/s rendered (3rd-order HOA->binaural, 48 kHz)",
@@ -212,8 +223,16 @@ def main():
                          "algorithmic_bytes_per_sample_frame": bytes_per_sf,
                          "frac_of_measured_copy_6290": round(achieved / 6290.0, 4)},
         }
+        if kind == "fir":   # compute-bound: price against the dense f32 MFMA peak
+            flop_sf = 2 * in_ch * 2 * FIR_TAPS
+            tf = flop_sf * sf_per_step / (kernel_ms * 1e-3) / 1e12
+            out["roofline"].update({"bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                                    "algorithmic_flop_per_sample_frame": flop_sf,
+                                    "hbm_gbs": round(achieved, 1)})
+            out["config"]["parity"] = "unpinned (HRTF arithmetic is not in the reference tree)"
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, fs)
+            out["cpu_baseline"] = cpu_baseline(args.workload if kind != "fir" else "toa_binaural_limiter_s16", fs)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -11,6 +11,7 @@ from .hipabi import (  # noqa: F401
     FMT_S24,
     FMT_S32,
     KIND_DMX,
+    KIND_FIR,
     KIND_H2M,
     KIND_M2M,
     PROJ_AUTO,
@@ -24,6 +25,7 @@ from .hipabi import (  # noqa: F401
     RenderArgs,
     Resampler,
     dmx_matrix,
+    fir_matrix,
     IamfHipError,
     Matrix,
     build,

@@ -29,6 +29,7 @@ namespace {
 
 #include "render_common.hpp"
 #include "render_generic.hpp"
+#include "render_fir.hpp"
 #include "render_fast.hpp"
 #include "render_wide.hpp"
 
@@ -128,6 +129,10 @@ struct iamf_hip_batch {
   int32_t *d_src_feed2 = nullptr, *d_dmx_tab = nullptr;
   bool dmx = false;
   int dmx_n_in = 0, dmx_n_out = 0;
+  bool fir = false;
+  int fir_taps = 0;
+  float *d_fir_hist[2] = {nullptr, nullptr};
+  int fir_cur = 0;
 };
 
 namespace {
@@ -145,6 +150,11 @@ int reset_state(iamf_hip_batch *b) {
   HIPCHK(hipMemcpy(b->d_lim, init.data(), sizeof(LimState) * ns, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(b->d_ring_y, 0, sizeof(float) * (size_t)ns * b->cfg.out_channels * kSave));
   HIPCHK(hipMemset(b->d_ring_pm, 0, sizeof(float) * (size_t)ns * kSave));
+  if (b->fir) {
+    const size_t hb = sizeof(float) * (size_t)ns * b->m * 256;
+    HIPCHK(hipMemset(b->d_fir_hist[0], 0, hb));
+    HIPCHK(hipMemset(b->d_fir_hist[1], 0, hb));
+  }
   b->pos = 0;
   b->flushed = false;
   return IAMF_HIP_OK;
@@ -153,6 +163,18 @@ int reset_state(iamf_hip_batch *b) {
 template <int M>
 void launch_m(const RenderParams &p, dim3 grid, size_t lds_bytes, hipStream_t st) {
   hipLaunchKernelGGL(render_kernel<M>, grid, dim3(kChunk), lds_bytes, st, p);
+}
+
+template <int M>
+void launch_fir_m(const RenderParams &p, dim3 grid, hipStream_t st) {
+  const size_t lds = sizeof(float) * (size_t)fast_lds_floats(2, M, p.n_end + 1, true);
+  static bool opted = false;
+  if (!opted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    opted = true;
+  }
+  hipLaunchKernelGGL((render_fast_kernel<M, 2, true>), grid, dim3(256), lds, st, p);
 }
 
 template <int M>
@@ -214,6 +236,18 @@ bool wide_path_ok(const RenderParams &p, int m) {
 
 int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
   dim3 grid((unsigned)p.n_streams);
+  if (p.fir_taps > 0 && p.in) {  // HRTF renderer: aligned calls only (the flush goes to the generic kernel)
+    if (!fast_path_ok(p)) return IAMF_HIP_ERR_UNIMPLEMENTED;
+    switch (m) {
+      case 1: launch_fir_m<1>(p, grid, st); break;
+      case 4: launch_fir_m<4>(p, grid, st); break;
+      case 9: launch_fir_m<9>(p, grid, st); break;
+      case 16: launch_fir_m<16>(p, grid, st); break;
+      default: return IAMF_HIP_ERR_UNIMPLEMENTED;
+    }
+    HIPCHK(hipGetLastError());
+    return IAMF_HIP_OK;
+  }
   const bool fast = fast_path_ok(p);
   const bool wide = !fast && wide_path_ok(p, m);
   switch (m) {
@@ -306,10 +340,16 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     p.dmx_n_out = b->dmx_n_out;
     p.dmx_tab = b->d_dmx_tab;
   }
+  if (b->fir) {
+    p.fir_taps = b->fir_taps;
+    p.fir_hist = b->d_fir_hist[b->fir_cur];
+    p.fir_hist_next = b->d_fir_hist[b->fir_cur ^ 1];
+  }
   const size_t lds = sizeof(float) * ((size_t)(p.out_ch + 2) * kRing + 3 * kChunk + kHead + 4 +
                                       (b->dmx ? (size_t)kChCount * kChunk : 0));
   const int r = launch(p, b->m, lds, static_cast<hipStream_t>(a.stream));
   if (r != IAMF_HIP_OK) return r;
+  if (b->fir && p.in) b->fir_cur ^= 1;
   const int64_t before = p.limiter_on ? (b->pos > kDelay ? b->pos - kDelay : 0) : b->pos;
   b->pos += total;
   const int64_t after = p.limiter_on ? (b->pos > kDelay ? b->pos - kDelay : 0) : b->pos;
@@ -388,6 +428,10 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
   *out = nullptr;
   iamf_hip_matrix mx = cfg->matrix;
   const bool dmx = mx.kind == IAMF_HIP_KIND_DMX;
+  const bool fir = mx.kind == IAMF_HIP_KIND_FIR;
+  if (fir && (cfg->fir_taps < 1 || cfg->fir_taps > 256 || mx.n != 2 || cfg->out_channels != 2 ||
+              !cfg->limiter_enable || (mx.m != 1 && mx.m != 4 && mx.m != 9 && mx.m != 16)))
+    return IAMF_HIP_ERR_BAD_ARG;
   if (dmx) {
     if (!iamf_hip_dmx_valid(mx.in_id, mx.out_id)) return IAMF_HIP_ERR_BAD_ARG;
     mx.m = kLayoutCount[mx.in_id];
@@ -409,6 +453,8 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
   b->n_feeds = mx.n;
   b->dmx = dmx;
 
+  b->fir = fir;
+  b->fir_taps = fir ? cfg->fir_taps : 0;
   std::vector<float> fm(1, 0.f);
   int32_t dmx_tab[24];
   memset(dmx_tab, 0, sizeof(dmx_tab));
@@ -418,6 +464,9 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
     b->dmx_n_out = mx.n;
     for (int i = 0; i < mx.m; ++i) dmx_tab[i] = kLayoutCh[mx.in_id][i];
     for (int i = 0; i < mx.n; ++i) dmx_tab[12 + i] = kLayoutCh[mx.out_id][i];
+  } else if (fir) {
+    for (int i = 0; i < kMaxOut; ++i) b->src_feed[i] = -1;  // the flush renders silence
+    fm.assign(mx.mat, mx.mat + (size_t)2 * mx.m * cfg->fir_taps);
   } else {
     build_feed_map(mx, cfg->out_channels, fm, b->src_feed);
   }
@@ -455,6 +504,13 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
   CREATE_CHK(hipMalloc(&b->d_ring_pm, sizeof(float) * (size_t)ns * kSave));
   CREATE_CHK(hipMalloc(&b->d_src_feed, sizeof(int32_t) * kMaxOut));
   CREATE_CHK(hipMemcpy(b->d_src_feed, b->src_feed, sizeof(int32_t) * kMaxOut, hipMemcpyHostToDevice));
+  if (fir) {
+    const size_t hb = sizeof(float) * (size_t)ns * mx.m * 256;
+    CREATE_CHK(hipMalloc(&b->d_fir_hist[0], hb));
+    CREATE_CHK(hipMalloc(&b->d_fir_hist[1], hb));
+    CREATE_CHK(hipMemset(b->d_fir_hist[0], 0, hb));
+    CREATE_CHK(hipMemset(b->d_fir_hist[1], 0, hb));
+  }
   CREATE_CHK(hipMalloc(&b->d_dmx_tab, sizeof(dmx_tab)));
   CREATE_CHK(hipMemcpy(b->d_dmx_tab, dmx_tab, sizeof(dmx_tab), hipMemcpyHostToDevice));
   CREATE_CHK(hipMemcpy(b->d_matrix, fm.data(), sizeof(float) * fm.size(), hipMemcpyHostToDevice));
@@ -480,6 +536,8 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_ring_pm);
   (void)hipFree(b->d_src_feed);
   (void)hipFree(b->d_dmx_tab);
+  (void)hipFree(b->d_fir_hist[0]);
+  (void)hipFree(b->d_fir_hist[1]);
   (void)hipFree(b->d_matrix2);
   (void)hipFree(b->d_gains2);
   (void)hipFree(b->d_src_feed2);

@@ -55,6 +55,10 @@ struct RenderParams {
   const iamf_hip_dmx_frame *dmx_frames;  // device [n_streams][frames of this call]
   int32_t dmx_n_in, dmx_n_out;
   const int32_t *dmx_tab;   // device [24]: IAChannel ids of the inputs, then (from [12]) of the outputs
+  // ---- HRTF FIR renderer (render_fast_kernel<M, 2, true>): matrix = h[2][M][fir_taps] ----
+  int32_t fir_taps;
+  const float *fir_hist;    // device [n_streams][M][256] input history before this call
+  float *fir_hist_next;     // device, same shape: history after this call
 };
 
 // IAChannel ids (reference IAMF_types.h:61-90; L5/R5 alias L7/R7)

@@ -114,8 +114,9 @@ __device__ __forceinline__ void limiter_wave(const float *arr_p, const float *ar
 
 // LDS floats the fast kernel needs for an OC-channel layout, M inputs and a limiter table of
 // `tab` entries (host and device use the same carve-up)
-__host__ __device__ constexpr int fast_lds_floats(int oc, int m, int tab) {
-  return oc * kFRing + 2 * kFRing + kFRing / 16 + 3 * kFChunk + ((tab + 15) & ~15) + ((oc * m + 15) & ~15) + 16;
+__host__ __device__ constexpr int fast_lds_floats(int oc, int m, int tab, bool fir = false) {
+  return oc * kFRing + 2 * kFRing + kFRing / 16 + 3 * kFChunk + ((tab + 15) & ~15) + ((oc * m + 15) & ~15) + 16 +
+         (fir ? kFirLdsFloats : 0);
 }
 
 __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
@@ -123,7 +124,7 @@ __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
   return i >= kFRing ? i - kFRing : i;
 }
 
-template <int M, int OC>
+template <int M, int OC, bool FIR = false>
 __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) {
   extern __shared__ float lds[];
   constexpr int R = kFRing;
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
   float *ctl = arr_g + kFChunk;         // [tab]     limiter curve table
   float *mat = ctl + tab;               // [OC*M]    feed-major matrix rows of the OC slots
   float *misc = mat + ((OC * M + 15) & ~15);  // [16]
+  float *fir = misc + 16;               // [kFirLdsFloats]  HRTF staging (FIR variant only)
 
   const int s = blockIdx.x;
   const int t = threadIdx.x;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     ring_suf[rp] = sfx;
     if ((t & 15) == 0) ring_bm[rp >> 4] = sfx;
     for (int i = t; i <= n_end; i += 256) ctl[i] = p.ctab[i];
-    if (t < OC * M) {
+    if (!FIR && t < OC * M) {
       const int c = t / M, m = t - c * M;
       const int f = p.src_feed[c];
       mat[t] = f >= 0 ? p.matrix[f * M + m] : 0.f;
@@ -184,7 +186,8 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
   const bool lg_on = p.loudness_on && (lg != 1.0f);
   bool live[OC];
 #pragma unroll
-  for (int c = 0; c < OC; ++c) live[c] = p.src_feed[c] >= 0;
+  for (int c = 0; c < OC; ++c) live[c] = FIR || p.src_feed[c] >= 0;
+  const float *fir_hist = FIR ? p.fir_hist + (int64_t)s * M * kFirHist : nullptr;
 
   const int64_t out_base = p.pos0 > kDelay ? p.pos0 - kDelay : 0;
   const int bytes = p.out_format == IAMF_HIP_FMT_S16 ? 2 : (p.out_format == IAMF_HIP_FMT_S24 ? 3 : 4);
@@ -192,8 +195,8 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
   const float *in_s = p.in + (int64_t)s * p.in_stream_stride;
 
   // input of the first chunk
-  float4 x[M];
-  {
+  float4 x[FIR ? 1 : M];
+  if constexpr (!FIR) {
     const int k = 4 * t;
     if (k < p.total) {
       const int f = k / fs;
@@ -218,13 +221,21 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     // ---- element renderer + gains (reference operation order) ----
     float4 y[OC];
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (FIR) fir_stage<M>(p, in_s, fir_hist, c0, fir, fir);  // both ears of the chunk -> LDS partials
 #pragma unroll
     for (int c = 0; c < OC; ++c) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live[c]) {
+      if constexpr (FIR) {
+        const float *p0 = fir + c * (kFChunk + 32), *p1 = fir + (c + 2) * (kFChunk + 32);
+        const int u = 4 * t + ((4 * t) >> 5);  // padded index; 4 consecutive samples stay in one 32-block
+        v.x = p0[u + 0] + p1[u + 0];
+        v.y = p0[u + 1] + p1[u + 1];
+        v.z = p0[u + 2] + p1[u + 2];
+        v.w = p0[u + 3] + p1[u + 3];
+      } else if (live[c]) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
+        for (int m = 0; m < (FIR ? 0 : M); ++m) {
           const float w = mat[c * M + m];
           acc.x = acc.x + w * x[m].x;
           acc.y = acc.y + w * x[m].y;
@@ -243,10 +254,11 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
       pm.z = fmaxf(pm.z, fabsf(v.z));
       pm.w = fmaxf(pm.w, fabsf(v.w));
     }
+    if constexpr (FIR) __syncthreads();  // partials are consumed; the staging area is reused by the next chunk
 
     // ---- prefetch the next chunk's input: the ONLY vector-memory loads of the loop, so they
     //      stay in flight under everything below (the in-order vmcnt never has to drain them) ----
-    {
+    if constexpr (!FIR) {
       const int kn = k + kFChunk;
       if (kn < p.total) {
         const int f = kn / fs;
@@ -422,6 +434,11 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     __syncthreads();  // ring / arr slots are rewritten by the next chunk
   }
 
+  if constexpr (FIR) {
+    // input history for the next call: the last 256 samples of [old history | this call's input]
+    float *hn = p.fir_hist_next + (int64_t)s * M * kFirHist;
+    for (int ch = 0; ch < M; ++ch) hn[ch * kFirHist + t] = fir_input(p, in_s, fir_hist, ch, p.total - kFirHist + t);
+  }
   // ---- persist stream state (same format as the generic kernel) ----
   {
     float *sy = p.ring_y + (int64_t)s * OC * kSave;

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "iac_amd", "csrc")
 
 FMT_S16, FMT_S24, FMT_S32, FMT_F32 = 16, 24, 32, -32
-KIND_H2M, KIND_M2M, KIND_DMX = 0, 1, 2
+KIND_H2M, KIND_M2M, KIND_DMX, KIND_FIR = 0, 1, 2, 3
 PROJ_AUTO, PROJ_EXACT, PROJ_MFMA = 0, 1, 2
 SS = dict(A=0x020, B=0x050, C=0x250, D=0x450, E=0x451, F=0x370, G=0x490, H=0x9A3, I=0x070,
           J=0x470, STEREO=0x200, L51=0x510, L512=0x512, L514=0x514, L71=0x710, L714=0x714,
@@ -35,7 +35,7 @@ class BatchConfig(C.Structure):
     _fields_ = [("n_streams", C.c_int32), ("frame_size", C.c_int32), ("sample_rate", C.c_int32),
                 ("out_channels", C.c_int32), ("out_format", C.c_int32), ("matrix", Matrix),
                 ("limiter_enable", C.c_int32), ("limiter_threshold_db", C.c_float),
-                ("loudness_enable", C.c_int32), ("projection", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("loudness_enable", C.c_int32), ("projection", C.c_int32), ("fir_taps", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class DmxState(C.Structure):
@@ -140,6 +140,18 @@ def dmx_matrix(in_layout, out_layout):
     return m
 
 
+def fir_matrix(hrir):
+    """config 'matrix' for the binaural HRTF renderer; hrir: float32 ndarray [2][channels][taps]"""
+    import numpy as np
+    h = np.ascontiguousarray(hrir, dtype=np.float32)
+    m = Matrix()
+    m.kind, m.in_id, m.out_id, m.channels, m.lfe1, m.lfe2 = KIND_FIR, 0, SS["BINAURAL"], 2, -1, -1
+    m.m, m.n = h.shape[1], 2
+    m.mat = h.ctypes.data_as(FP)
+    m._keep = h
+    return m
+
+
 def layout_channels(out_id):
     return lib().iamf_hip_layout_channels(out_id)
 
@@ -155,7 +167,7 @@ class Batch:
     """Thin handle on iamf_hip_batch_*; pointers are raw device addresses (ints)."""
 
     def __init__(self, n_streams, matrix, out_channels, frame_size=1024, sample_rate=48000,
-                 out_format=FMT_S16, limiter=True, threshold_db=-1.0, loudness=False, projection=PROJ_AUTO):
+                 out_format=FMT_S16, limiter=True, threshold_db=-1.0, loudness=False, projection=PROJ_AUTO, fir_taps=0):
         cfg = BatchConfig()
         cfg.n_streams = n_streams
         cfg.frame_size = frame_size
@@ -167,6 +179,7 @@ class Batch:
         cfg.limiter_threshold_db = threshold_db
         cfg.loudness_enable = 1 if loudness else 0
         cfg.projection = projection
+        cfg.fir_taps = fir_taps
         self.cfg = cfg
         self.bytes_per_sample = lib().iamf_hip_format_bytes(out_format)
         h = C.c_void_p()

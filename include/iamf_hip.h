@@ -47,7 +47,13 @@ enum {
 
 /* element renderer kinds.  DMX = the parametric down-mixer (downmix_renderer.c): matrix.in_id /
  * out_id are IAChannelLayoutType values (IAMF_defines.h:196-209), matrix.mat is unused. */
-enum { IAMF_HIP_KIND_H2M = 0, IAMF_HIP_KIND_M2M = 1, IAMF_HIP_KIND_DMX = 2 };
+enum { IAMF_HIP_KIND_H2M = 0, IAMF_HIP_KIND_M2M = 1, IAMF_HIP_KIND_DMX = 2, IAMF_HIP_KIND_FIR = 3 };
+/* FIR = binaural HRTF convolution of a scene-based element (the role of
+ * IAMF_element_renderer_render_H2B, h2b_rdr.c:109-130): matrix.m = ambisonics channels, matrix.n = 2,
+ * matrix.mat = HRIRs h[ear][channel][fir_taps] (host), out_channels = 2, limiter on.
+ *   y[ear][t] = sum_c sum_k h[ear][c][k] * x[c][t-k]     (f32 MFMA; fir_taps <= 256)
+ * PARITY UNPINNED: the reference's binauraliser arithmetic lives in Resonance Audio / BEAR, which
+ * are not in the reference tree; this formula is this library's specification. */
 
 /* Projection arithmetic for output layouts wider than stereo.
  *   EXACT: VALU, separate f32 multiply and add in the reference's order -> bit-identical PCM.
@@ -102,7 +108,8 @@ typedef struct {
                                  constants (common/audio_defines.h:38-41) */
   int32_t loudness_enable; /* normalization_loudness != 0 (IAMF_decoder.c:3480) */
   int32_t projection;      /* IAMF_HIP_PROJ_*: how layouts with more than 2 channels are projected */
-  int32_t reserved[6];
+  int32_t fir_taps;        /* kind FIR: taps per HRIR (1..256) */
+  int32_t reserved[5];
 } iamf_hip_batch_config;
 
 /* Creates device state for cfg->n_streams streams on the CURRENT HIP device.  Synchronous.
