@@ -199,7 +199,12 @@ def main():
         total_sf = sf_per_step * args.steps * world
         value = total_sf / elapsed / 1e6
         achieved = bytes_per_sf * sf_per_step / (kernel_ms * 1e-3) / 1e9
-        ktag = "render_fast_kernel<%d, %d" % (in_ch, out_ch) if out_ch <= 2 else "render_wide_kernel<%d" % in_ch
+        if kind == "fir":
+            ktag = "render_fast_kernel<%d, 2, true>" % in_ch
+        elif out_ch <= 2:
+            ktag = "render_fast_kernel<%d, %d, false>" % (in_ch, out_ch)
+        else:
+            ktag = "render_wide_kernel<%d" % in_ch
         traffic = measured_traffic(ktag, sf_per_step)
         out = {
             "metric": "Msamples/s rendered (3rd-order HOA->binaural, 48 kHz)",

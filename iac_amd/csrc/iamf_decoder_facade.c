@@ -1,0 +1,1083 @@
+/*
+ * iamf_decoder_facade.c — the reference's public decoder API (include/IAMF_decoder.h) on top of
+ * the GPU batch renderer (include/iamf_hip.h), one stream per handle.  Plain C host code.
+ *
+ * Host side (this file): OBU parsing (wire format as the reference parses it in
+ * src/iamf_dec/IAMF_OBU.c:79-138,256-607,641-932,990-1248), LPCM unpacking
+ * (pcm/IAMF_pcm_decoder.c:60-151), the audio-layer -> playback channel order of single-layer
+ * channel-based elements (IAMF_utils.c:117-133,181-196), the mix-gain / demixing parameter
+ * timeline (IAMF_decoder.c:857-982, downmix_renderer.c:180-216) and the call protocol of
+ * IAMF_decoder.c:3726-4168.  Device side: everything from iamf_stream_render to
+ * iamf_decoder_plane2stride_out (IAMF_decoder.c:3374-3500).
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include "IAMF_decoder.h"
+#include "iamf_hip.h"
+
+#define MAX_ELEMENTS 8
+#define MAX_PRESENTATIONS 8
+#define MAX_SUBSTREAMS 24
+#define MAX_SEGMENTS 16
+#define MAX_PARAMS 16
+
+/* ---- byte reader: every field the path needs is byte aligned or the leading bits of a byte ---- */
+typedef struct {
+  const uint8_t *p;
+  uint32_t size, pos;
+  int err;
+} Rd;
+
+static uint8_t rd_u8(Rd *r) {
+  if (r->pos >= r->size) {
+    r->err = 1;
+    return 0;
+  }
+  return r->p[r->pos++];
+}
+static uint16_t rd_u16(Rd *r) {
+  uint16_t a = rd_u8(r);
+  return (uint16_t)((a << 8) | rd_u8(r));
+}
+static uint32_t rd_u32(Rd *r) {
+  uint32_t a = rd_u16(r);
+  return (a << 16) | rd_u16(r);
+}
+static uint64_t rd_leb128(Rd *r) { /* bitstream.c:136-157 */
+  uint64_t v = 0;
+  for (int i = 0; i < 8; ++i) {
+    uint8_t b = rd_u8(r);
+    v |= ((uint64_t)(b & 0x7f)) << (7 * i);
+    if (!(b & 0x80)) return v;
+  }
+  r->err = 1;
+  return v;
+}
+static void rd_skip(Rd *r, uint64_t n) {
+  if (r->pos + n > r->size)
+    r->err = 1;
+  else
+    r->pos += (uint32_t)n;
+}
+static void rd_string(Rd *r) {
+  while (r->pos < r->size && r->p[r->pos]) r->pos++;
+  rd_skip(r, 1);
+}
+
+typedef struct {
+  int type, redundant, trimming, extension;
+  uint64_t trim_end, trim_start;
+  const uint8_t *payload;
+  uint32_t payload_size, size;
+} Obu;
+
+/* IAMF_OBU_split, IAMF_OBU.c:79-138 */
+static uint32_t obu_split(const uint8_t *data, uint32_t size, Obu *o) {
+  Rd r = {data, size, 0, 0};
+  uint8_t h;
+  uint64_t len;
+  if (size < 2) return 0;
+  h = rd_u8(&r);
+  o->type = h >> 3;
+  o->redundant = (h >> 2) & 1;
+  o->trimming = (h >> 1) & 1;
+  o->extension = h & 1;
+  len = rd_leb128(&r);
+  if (r.err || len + r.pos > size) return 0;
+  o->size = r.pos + (uint32_t)len;
+  r.size = o->size;
+  o->trim_end = o->trim_start = 0;
+  if (o->trimming) {
+    o->trim_end = rd_leb128(&r);
+    o->trim_start = rd_leb128(&r);
+  }
+  if (o->extension) rd_skip(&r, rd_leb128(&r));
+  if (r.err) return 0;
+  o->payload = data + r.pos;
+  o->payload_size = o->size - r.pos;
+  return o->size;
+}
+
+/* ---- parsed descriptors ---- */
+typedef struct {
+  uint64_t id, rate;
+  int mode; /* 1: the parameter blocks carry duration / intervals themselves */
+  uint64_t duration, constant_interval, nb_segments, intervals[MAX_SEGMENTS];
+} ParamDef;
+
+typedef struct {
+  int anim;
+  float start, end, control, control_rel; /* linear gains, relative time in [0,1] */
+  uint64_t interval;
+} GainSeg;
+
+typedef struct {
+  uint64_t id;
+  int type; /* IAMF_PARAMETER_TYPE_* */
+  ParamDef def;
+  int have_block;
+  uint64_t block_start; /* stream time (samples) where the held block begins */
+  uint64_t block_duration, next_start;
+  int nseg;
+  GainSeg seg[MAX_SEGMENTS];
+  int dmx_mode; /* demixing: mode of the held block */
+} Param;
+
+typedef struct {
+  uint64_t id;
+  int type; /* AudioElementType */
+  int nsub;
+  uint64_t sub_ids[MAX_SUBSTREAMS];
+  int layout, nb_coupled;              /* channel-based */
+  int amb_channels;
+  uint8_t amb_map[MAX_SUBSTREAMS];     /* scene-based, mono mapping */
+  int has_demix;
+  uint64_t demix_pid;
+  int demix_default_mode, demix_default_w;
+  int channels;
+} Element;
+
+typedef struct {
+  uint64_t id;
+  int nel;
+  uint64_t el_id[2];
+  ParamDef el_gain_def[2];
+  int16_t el_gain_q[2];
+  ParamDef out_gain_def;
+  int16_t out_gain_q;
+  int nlayouts;
+  int layout_type[8], layout_ss[8];
+  IAMF_LoudnessInfo loud[8];
+} Presentation;
+
+struct IAMF_Decoder {
+  /* user settings (IAMF_decoder.c:3726-3744, 3960-4130) */
+  int out_type; /* IAMF_LayoutType */
+  IAMF_SoundSystem out_ss;
+  uint32_t bit_depth, out_rate;
+  int limiter_on;
+  float limiter_db, norm_loudness;
+  int64_t mix_id;
+  int64_t pts;
+  uint32_t pts_base;
+  /* descriptors */
+  int have_header, have_codec;
+  uint32_t frame_size, sample_size, rate;
+  int little_endian;
+  int nel, npr, nparam;
+  Element el[MAX_ELEMENTS];
+  Presentation pr[MAX_PRESENTATIONS];
+  Param param[MAX_PARAMS];
+  /* runtime */
+  int configured;
+  Presentation *sel;
+  Element *sel_el[2];
+  Param *el_gain_p[2], *out_gain_p, *demix_p;
+  IAMF_StreamInfo info;
+  int out_channels;
+  float mix_loudness;
+  iamf_hip_batch *batch, *batch3; /* batch3: limiter stage behind the resampler */
+  iamf_hip_resampler *rs;
+  iamf_hip_dmx_state dmx;
+  int use_dmx;
+  /* packets of the temporal unit being assembled */
+  uint8_t *pkt[2][MAX_SUBSTREAMS];
+  uint32_t pkt_len[2][MAX_SUBSTREAMS];
+  int pkt_have[2][MAX_SUBSTREAMS];
+  uint64_t tu_trim_start, tu_trim_end;
+  uint64_t timestamp; /* stream time of the next frame, samples */
+  /* buffers */
+  float *h_in[2], *d_in[2], *h_ramp[3], *d_ramp[3], *d_mid, *d_res;
+  float *tmp; /* [MAX_SUBSTREAMS * 2][frame_size] unpack scratch */
+  iamf_hip_dmx_frame *d_dmx;
+  void *d_pcm;
+  size_t pcm_cap;
+  hipStream_t stream;
+  int flushed;
+  uint32_t last_frame;
+};
+
+/* ---- small tables ---- */
+static const int k_ss_channels[] = {2, 6, 8, 10, 11, 12, 14, 24, 8, 12, 10, 6, 1}; /* IAMF_decoder.c:208-219 */
+static const int k_ss_rid[] = {IAMF_HIP_SS_A, IAMF_HIP_SS_B, IAMF_HIP_SS_C, IAMF_HIP_SS_D, IAMF_HIP_SS_E,
+                               IAMF_HIP_SS_F, IAMF_HIP_SS_G, IAMF_HIP_SS_H, IAMF_HIP_SS_I, IAMF_HIP_SS_J,
+                               IAMF_HIP_L_712, IAMF_HIP_L_312, IAMF_HIP_L_MONO}; /* :221-226 */
+static const int k_layer_rid[] = {IAMF_HIP_L_MONO, IAMF_HIP_L_STEREO, IAMF_HIP_L_51, IAMF_HIP_L_512,
+                                  IAMF_HIP_L_514, IAMF_HIP_L_71, IAMF_HIP_L_712, IAMF_HIP_L_714,
+                                  IAMF_HIP_L_312, IAMF_HIP_L_BINAURAL}; /* :256-261 */
+static const int k_ss_layout[] = {IA_CHANNEL_LAYOUT_STEREO, IA_CHANNEL_LAYOUT_510, IA_CHANNEL_LAYOUT_512,
+                                  IA_CHANNEL_LAYOUT_514, -1, -1, -1, -1, IA_CHANNEL_LAYOUT_710,
+                                  IA_CHANNEL_LAYOUT_714, IA_CHANNEL_LAYOUT_712, IA_CHANNEL_LAYOUT_312,
+                                  IA_CHANNEL_LAYOUT_MONO}; /* :228-238 */
+static const int k_layout_channels[] = {1, 2, 6, 8, 10, 8, 10, 12, 6, 2};
+/* playback channel p of a layer layout is audio-layer channel k_al_of_pl[layout][p]
+ * (IAMF_utils.c:117-133 vs :181-196) */
+static const int k_al_of_pl[9][12] = {
+    {0}, {0, 1}, {0, 1, 4, 5, 2, 3}, {0, 1, 6, 7, 2, 3, 4, 5}, {0, 1, 8, 9, 2, 3, 4, 5, 6, 7},
+    {0, 1, 6, 7, 2, 3, 4, 5}, {0, 1, 8, 9, 2, 3, 4, 5, 6, 7}, {0, 1, 10, 11, 2, 3, 4, 5, 6, 7, 8, 9},
+    {0, 1, 4, 5, 2, 3}};
+
+static float q_to_float(int16_t q, int frac) { return ((float)q) * powf(2.0f, (float)-frac); } /* fixedp11_5.c:45 */
+static float qf_to_float(uint8_t q, int frac) { return ((float)q / (pow(2.0f, (float)frac) - 1.0)); } /* :53 */
+static float db2lin(float db) { return powf(10.0f, 0.05f * db); }                               /* :72 */
+
+/* ---- descriptor parsing ---- */
+static int parse_param_def(Rd *r, ParamDef *d) { /* IAMF_OBU.c:358-389 */
+  memset(d, 0, sizeof(*d));
+  d->id = rd_leb128(r);
+  d->rate = rd_leb128(r);
+  d->mode = rd_u8(r) >> 7;
+  if (!d->mode) {
+    d->duration = rd_leb128(r);
+    d->constant_interval = rd_leb128(r);
+    if (!d->constant_interval) {
+      d->nb_segments = rd_leb128(r);
+      if (d->nb_segments > MAX_SEGMENTS) return IAMF_ERR_UNIMPLEMENTED;
+      for (uint64_t i = 0; i < d->nb_segments; ++i) d->intervals[i] = rd_leb128(r);
+    } else {
+      d->nb_segments = (d->duration + d->constant_interval - 1) / d->constant_interval;
+      if (d->nb_segments > MAX_SEGMENTS) return IAMF_ERR_UNIMPLEMENTED;
+    }
+  }
+  return r->err ? IAMF_ERR_INVALID_PACKET : IAMF_OK;
+}
+
+static Param *param_get(struct IAMF_Decoder *d, const ParamDef *def, int type) {
+  for (int i = 0; i < d->nparam; ++i)
+    if (d->param[i].id == def->id) return &d->param[i];
+  if (d->nparam >= MAX_PARAMS) return 0;
+  Param *p = &d->param[d->nparam++];
+  memset(p, 0, sizeof(*p));
+  p->id = def->id;
+  p->type = type;
+  p->def = *def;
+  return p;
+}
+
+static int parse_codec_config(struct IAMF_Decoder *d, const Obu *o) { /* IAMF_OBU.c:303-343 */
+  Rd r = {o->payload, o->payload_size, 0, 0};
+  char cc[4];
+  rd_leb128(&r);
+  for (int i = 0; i < 4; ++i) cc[i] = (char)rd_u8(&r);
+  d->frame_size = (uint32_t)rd_leb128(&r);
+  rd_u16(&r); /* roll distance */
+  if (memcmp(cc, "ipcm", 4)) return IAMF_ERR_UNIMPLEMENTED; /* Opus / AAC / FLAC: upstream of this path */
+  d->little_endian = rd_u8(&r) & 1; /* pcm/IAMF_pcm_decoder.c:60-62 */
+  d->sample_size = rd_u8(&r);
+  d->rate = rd_u32(&r);
+  if (r.err || !d->frame_size || (d->sample_size != 16 && d->sample_size != 24 && d->sample_size != 32))
+    return IAMF_ERR_INVALID_PACKET;
+  d->have_codec = 1;
+  return IAMF_OK;
+}
+
+static int parse_element(struct IAMF_Decoder *d, const Obu *o) { /* IAMF_OBU.c:391-607 */
+  Rd r = {o->payload, o->payload_size, 0, 0};
+  Element e;
+  uint64_t np;
+  memset(&e, 0, sizeof(e));
+  e.id = rd_leb128(&r);
+  e.type = rd_u8(&r) >> 5;
+  rd_leb128(&r); /* codec config id */
+  e.nsub = (int)rd_leb128(&r);
+  if (e.nsub > MAX_SUBSTREAMS) return IAMF_ERR_UNIMPLEMENTED;
+  for (int i = 0; i < e.nsub; ++i) e.sub_ids[i] = rd_leb128(&r);
+  np = rd_leb128(&r);
+  for (uint64_t i = 0; i < np; ++i) {
+    uint64_t type = rd_leb128(&r);
+    if (type == IAMF_PARAMETER_TYPE_DEMIXING || type == IAMF_PARAMETER_TYPE_RECON_GAIN) {
+      ParamDef def;
+      int rc = parse_param_def(&r, &def);
+      if (rc) return rc;
+      if (type == IAMF_PARAMETER_TYPE_DEMIXING) {
+        e.has_demix = 1;
+        e.demix_pid = def.id;
+        e.demix_default_mode = rd_u8(&r) >> 5;
+        e.demix_default_w = rd_u8(&r) >> 4;
+        if (!param_get(d, &def, IAMF_PARAMETER_TYPE_DEMIXING)) return IAMF_ERR_ALLOC_FAIL;
+      }
+    } else {
+      rd_skip(&r, rd_leb128(&r));
+    }
+  }
+  if (e.type == AUDIO_ELEMENT_CHANNEL_BASED) {
+    int layers = rd_u8(&r) >> 5;
+    if (layers != 1) return IAMF_ERR_UNIMPLEMENTED; /* scalable layers need the demixer (upstream) */
+    uint8_t b = rd_u8(&r);
+    e.layout = b >> 4;
+    if ((b >> 3) & 1) return IAMF_ERR_UNIMPLEMENTED; /* output_gain_flag: demixer territory */
+    rd_u8(&r);                  /* substream count of the layer */
+    e.nb_coupled = rd_u8(&r);
+    if (e.layout > IA_CHANNEL_LAYOUT_312) return IAMF_ERR_UNIMPLEMENTED;
+    e.channels = k_layout_channels[e.layout];
+    if (e.nsub + e.nb_coupled != e.channels) return IAMF_ERR_INVALID_PACKET;
+  } else if (e.type == AUDIO_ELEMENT_SCENE_BASED) {
+    if (rd_leb128(&r) != AMBISONICS_MONO) return IAMF_ERR_UNIMPLEMENTED;
+    e.amb_channels = rd_u8(&r);
+    rd_u8(&r);
+    if (e.amb_channels > MAX_SUBSTREAMS) return IAMF_ERR_INVALID_PACKET;
+    for (int i = 0; i < e.amb_channels; ++i) e.amb_map[i] = rd_u8(&r);
+    e.channels = e.amb_channels;
+    if (e.channels != 1 && e.channels != 4 && e.channels != 9 && e.channels != 16) return IAMF_ERR_UNIMPLEMENTED;
+  } else {
+    return IAMF_ERR_UNIMPLEMENTED;
+  }
+  if (r.err) return IAMF_ERR_INVALID_PACKET;
+  for (int i = 0; i < d->nel; ++i)
+    if (d->el[i].id == e.id) {
+      d->el[i] = e;
+      return IAMF_OK;
+    }
+  if (d->nel >= MAX_ELEMENTS) return IAMF_ERR_UNIMPLEMENTED;
+  d->el[d->nel++] = e;
+  return IAMF_OK;
+}
+
+static int parse_presentation(struct IAMF_Decoder *d, const Obu *o) { /* IAMF_OBU.c:641-932 */
+  Rd r = {o->payload, o->payload_size, 0, 0};
+  Presentation p;
+  uint64_t labels;
+  memset(&p, 0, sizeof(p));
+  p.id = rd_leb128(&r);
+  labels = rd_leb128(&r);
+  for (uint64_t i = 0; i < 2 * labels; ++i) rd_string(&r);
+  if (rd_leb128(&r) != 1) return IAMF_ERR_UNIMPLEMENTED; /* one sub-mix, as the reference */
+  p.nel = (int)rd_leb128(&r);
+  if (p.nel < 1 || p.nel > 2) return IAMF_ERR_UNIMPLEMENTED;
+  for (int i = 0; i < p.nel; ++i) {
+    int rc;
+    p.el_id[i] = rd_leb128(&r);
+    for (uint64_t k = 0; k < labels; ++k) rd_string(&r);
+    rd_u8(&r); /* headphones_rendering_mode: only matters with an external binauraliser */
+    rd_skip(&r, rd_leb128(&r));
+    if ((rc = parse_param_def(&r, &p.el_gain_def[i]))) return rc;
+    p.el_gain_q[i] = (int16_t)rd_u16(&r);
+  }
+  {
+    int rc = parse_param_def(&r, &p.out_gain_def);
+    if (rc) return rc;
+    p.out_gain_q = (int16_t)rd_u16(&r);
+  }
+  p.nlayouts = (int)rd_leb128(&r);
+  if (p.nlayouts > 8) return IAMF_ERR_UNIMPLEMENTED;
+  for (int i = 0; i < p.nlayouts; ++i) {
+    uint8_t b = rd_u8(&r);
+    p.layout_type[i] = b >> 6;
+    p.layout_ss[i] = (b >> 2) & 15;
+    p.loud[i].info_type = rd_u8(&r);
+    p.loud[i].integrated_loudness = (int16_t)rd_u16(&r);
+    p.loud[i].digital_peak = (int16_t)rd_u16(&r);
+    if (p.loud[i].info_type & 1) p.loud[i].true_peak = (int16_t)rd_u16(&r);
+    if (p.loud[i].info_type & 2) {
+      int n = rd_u8(&r);
+      rd_skip(&r, 3 * (uint64_t)n);
+    }
+    if (p.loud[i].info_type & ~3) rd_skip(&r, rd_leb128(&r));
+  }
+  if (r.err) return IAMF_ERR_INVALID_PACKET;
+  for (int i = 0; i < d->npr; ++i)
+    if (d->pr[i].id == p.id) {
+      d->pr[i] = p;
+      return IAMF_OK;
+    }
+  if (d->npr >= MAX_PRESENTATIONS) return IAMF_ERR_UNIMPLEMENTED;
+  d->pr[d->npr++] = p;
+  return IAMF_OK;
+}
+
+/* IAMF_OBU.c:990-1215 (mix gain and demixing segments) */
+static int parse_parameter_block(struct IAMF_Decoder *d, const Obu *o) {
+  Rd r = {o->payload, o->payload_size, 0, 0};
+  uint64_t id = rd_leb128(&r), duration, cinterval, nseg, left;
+  Param *p = 0;
+  for (int i = 0; i < d->nparam; ++i)
+    if (d->param[i].id == id) p = &d->param[i];
+  if (!p) return IAMF_OK; /* not a parameter of the selected presentation */
+  if (!p->def.mode) {
+    duration = p->def.duration;
+    cinterval = p->def.constant_interval;
+    nseg = p->def.nb_segments;
+  } else {
+    duration = rd_leb128(&r);
+    cinterval = rd_leb128(&r);
+    nseg = cinterval ? (duration + cinterval - 1) / cinterval : rd_leb128(&r);
+  }
+  if (nseg > MAX_SEGMENTS) return IAMF_ERR_UNIMPLEMENTED;
+  left = duration;
+  p->nseg = (int)nseg;
+  for (uint64_t i = 0; i < nseg; ++i) {
+    uint64_t iv = 0;
+    if (!cinterval) iv = p->def.mode ? rd_leb128(&r) : p->def.intervals[i];
+    if (!iv) iv = cinterval < left ? cinterval : left; /* iamf_parameter_get_segment_interval */
+    left -= iv;
+    p->seg[i].interval = iv;
+    if (p->type == IAMF_PARAMETER_TYPE_MIX_GAIN) {
+      GainSeg *g = &p->seg[i];
+      g->anim = (int)rd_leb128(&r);
+      g->start = db2lin(q_to_float((int16_t)rd_u16(&r), 8));
+      if (g->anim != ANIMATION_TYPE_STEP) {
+        g->end = db2lin(q_to_float((int16_t)rd_u16(&r), 8));
+        if (g->anim == ANIMATION_TYPE_BEZIER) {
+          g->control = db2lin(q_to_float((int16_t)rd_u16(&r), 8));
+          g->control_rel = qf_to_float(rd_u8(&r), 8);
+        }
+      }
+    } else if (p->type == IAMF_PARAMETER_TYPE_DEMIXING) {
+      p->dmx_mode = rd_u8(&r) >> 5;
+    }
+  }
+  if (r.err) return IAMF_ERR_INVALID_PACKET;
+  p->block_start = p->have_block ? p->next_start : d->timestamp;
+  p->block_duration = duration;
+  p->next_start = p->block_start + duration;
+  p->have_block = 1;
+  return IAMF_OK;
+}
+
+/* ---- per-frame mix gains: iamf_database_parameter_get_mix_gain_unit, IAMF_decoder.c:857-982,
+ *      with the ramp builders of :639-664 ---- */
+static void gain_linear(float s, float e, int d, int o, int l, float *g) {
+  for (int i = o, k = 0; i < o + l; ++i, ++k) g[k] = s + (e - s) * i / d;
+}
+static void gain_quad(float s, float e, int d, float c, int ct, int o, int l, float *g) {
+  int64_t alpha = d - 2 * ct;
+  float a = 1.0f;
+  for (int i = o, k = 0; i < o + l; ++i, ++k) {
+    if (alpha) {
+      a = (sqrt(pow(ct, 2) + alpha * i) - ct) / alpha;
+    } else {
+      a = i;
+      a /= (2 * ct);
+    }
+    g[k] = (s + e - 2 * c) * pow(a, 2) + 2 * a * (c - s) + s;
+  }
+}
+
+/* returns 0: constant gain in *constant; 1: per-sample gains written to g[0..duration) */
+static int mix_gain_unit(const Param *p, float default_gain, uint64_t pt, int duration, int rate, float *constant,
+                         float *g) {
+  uint64_t start = 0;
+  float ratio = 1.f;
+  int count = 0, have_array = 0;
+  int64_t sgd = 0;
+  int left = duration;
+  *constant = default_gain;
+  if (!p || !p->have_block || pt < p->block_start) return 0;
+  start = pt - p->block_start;
+  if ((uint64_t)rate != p->def.rate) ratio = (rate + 0.1f) / p->def.rate;
+  for (int i = 0; i < p->nseg; ++i) {
+    const GainSeg *seg = &p->seg[i];
+    int64_t minterval = seg->interval * ratio;
+    sgd += minterval;
+    if ((int64_t)start < sgd) {
+      if (seg->anim == ANIMATION_TYPE_STEP) {
+        if (!count && (int64_t)(start + duration) <= sgd) {
+          *constant = seg->start;
+          return 0;
+        } else if (!count) {
+          have_array = 1;
+          count = (int)(sgd - start);
+          for (int k = 0; k < count; ++k) g[k] = seg->start;
+          start = sgd;
+        } else {
+          int e = count + (int)minterval;
+          if (e >= duration)
+            e = duration;
+          else
+            start = sgd;
+          for (int k = count; k < e; ++k) g[k] = seg->start;
+          count = e;
+        }
+      } else {
+        int ss = (int)(sgd - minterval), d2, off = (int)start - ss;
+        have_array = 1;
+        if ((int64_t)(start + left) <= sgd) {
+          d2 = left;
+        } else {
+          d2 = (int)(sgd - start);
+          start = sgd;
+          left -= d2;
+        }
+        if (seg->anim == ANIMATION_TYPE_LINEAR)
+          gain_linear(seg->start, seg->end, (int)minterval, off, d2, g + count);
+        else
+          gain_quad(seg->start, seg->end, (int)minterval, seg->control,
+                    seg->control_rel * (minterval + .1f), off, d2, g + count);
+        count += d2;
+      }
+    }
+    if (count == duration) break;
+  }
+  if (!have_array) return 0;
+  for (int k = count; k < duration; ++k) g[k] = default_gain; /* not reached on well-formed streams */
+  return 1;
+}
+
+/* ---- lifecycle ---- */
+IAMF_DecoderHandle IAMF_decoder_open(void) { /* IAMF_decoder.c:3726-3744 */
+  struct IAMF_Decoder *d = (struct IAMF_Decoder *)calloc(1, sizeof(*d));
+  if (!d) return 0;
+  d->limiter_on = 1;
+  d->limiter_db = -1.0f; /* LIMITER_MaximumTruePeak */
+  d->mix_id = -1;
+  d->out_type = IAMF_LAYOUT_TYPE_NOT_DEFINED;
+  d->pts_base = 90000;
+  return d;
+}
+
+static void free_runtime(struct IAMF_Decoder *d) {
+  if (d->batch) iamf_hip_batch_destroy(d->batch);
+  if (d->batch3) iamf_hip_batch_destroy(d->batch3);
+  if (d->rs) iamf_hip_resampler_destroy(d->rs);
+  d->batch = d->batch3 = 0;
+  d->rs = 0;
+  for (int e = 0; e < 2; ++e) {
+    if (d->h_in[e]) (void)hipHostFree(d->h_in[e]);
+    if (d->d_in[e]) (void)hipFree(d->d_in[e]);
+    d->h_in[e] = d->d_in[e] = 0;
+    for (int s = 0; s < MAX_SUBSTREAMS; ++s) {
+      free(d->pkt[e][s]);
+      d->pkt[e][s] = 0;
+      d->pkt_have[e][s] = 0;
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    if (d->h_ramp[i]) (void)hipHostFree(d->h_ramp[i]);
+    if (d->d_ramp[i]) (void)hipFree(d->d_ramp[i]);
+    d->h_ramp[i] = d->d_ramp[i] = 0;
+  }
+  free(d->tmp);
+  d->tmp = 0;
+  if (d->d_mid) (void)hipFree(d->d_mid);
+  if (d->d_res) (void)hipFree(d->d_res);
+  if (d->d_dmx) (void)hipFree(d->d_dmx);
+  if (d->d_pcm) (void)hipFree(d->d_pcm);
+  d->d_mid = d->d_res = 0;
+  d->d_dmx = 0;
+  d->d_pcm = 0;
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  d->stream = 0;
+  d->configured = 0;
+}
+
+int IAMF_decoder_close(IAMF_DecoderHandle d) {
+  if (!d) return IAMF_ERR_BAD_ARG;
+  free_runtime(d);
+  free(d);
+  return IAMF_OK;
+}
+
+/* ---- configuration ---- */
+static int out_rendering_id(const struct IAMF_Decoder *d) {
+  return d->out_type == IAMF_LAYOUT_TYPE_BINAURAL ? IAMF_HIP_L_BINAURAL : k_ss_rid[d->out_ss];
+}
+
+static int element_matrix(const struct IAMF_Decoder *d, const Element *e, iamf_hip_matrix *mx) {
+  const int out_id = out_rendering_id(d);
+  if (e->type == AUDIO_ELEMENT_SCENE_BASED) {
+    int order = e->channels == 1 ? 0 : e->channels == 4 ? 1 : e->channels == 9 ? 2 : 3; /* IAMF_decoder.c:2403-2413 */
+    return iamf_hip_get_h2m_matrix(order, out_id, mx);
+  }
+  return iamf_hip_get_m2m_matrix(e->channels == 1 ? IAMF_HIP_L_MONO : k_layer_rid[e->layout], out_id, mx);
+}
+
+static Element *find_element(struct IAMF_Decoder *d, uint64_t id) {
+  for (int i = 0; i < d->nel; ++i)
+    if (d->el[i].id == id) return &d->el[i];
+  return 0;
+}
+
+static int setup_pipeline(struct IAMF_Decoder *d) {
+  iamf_hip_batch_config cfg;
+  Presentation *p = 0;
+  int resample;
+  free_runtime(d);
+  if (!d->have_header || !d->have_codec || !d->nel || !d->npr) return IAMF_ERR_BUFFER_TOO_SMALL;
+  if (d->out_type == IAMF_LAYOUT_TYPE_NOT_DEFINED) return IAMF_ERR_BAD_ARG;
+  /* iamf_decoder_get_best_mix_presentation, IAMF_decoder.c:3083-3111 */
+  if (d->npr == 1) {
+    p = &d->pr[0];
+  } else {
+    for (int i = 0; i < d->npr && d->mix_id >= 0; ++i)
+      if (d->pr[i].id == (uint64_t)d->mix_id) p = &d->pr[i];
+    for (int i = 0; i < d->npr && !p; ++i)
+      for (int l = 0; l < d->pr[i].nlayouts; ++l)
+        if (d->pr[i].layout_type[l] == d->out_type &&
+            (d->out_type == IAMF_LAYOUT_TYPE_BINAURAL || d->pr[i].layout_ss[l] == (int)d->out_ss))
+          p = &d->pr[i];
+    if (!p) p = &d->pr[0];
+  }
+  d->sel = p;
+  d->mix_loudness = 0.f;
+  for (int l = p->nlayouts - 1; l >= 0; --l) {
+    int match = p->layout_type[l] == d->out_type &&
+                (d->out_type == IAMF_LAYOUT_TYPE_BINAURAL || p->layout_ss[l] == (int)d->out_ss);
+    if (match || l == 0) d->mix_loudness = q_to_float(p->loud[l].integrated_loudness, 8);
+    if (match) break;
+  }
+  for (int i = 0; i < p->nel; ++i) {
+    d->sel_el[i] = find_element(d, p->el_id[i]);
+    if (!d->sel_el[i]) return IAMF_ERR_INTERNAL;
+    d->el_gain_p[i] = param_get(d, &p->el_gain_def[i], IAMF_PARAMETER_TYPE_MIX_GAIN);
+  }
+  d->out_gain_p = param_get(d, &p->out_gain_def, IAMF_PARAMETER_TYPE_MIX_GAIN);
+  d->out_channels = d->out_type == IAMF_LAYOUT_TYPE_BINAURAL ? 2 : k_ss_channels[d->out_ss];
+  if (!d->out_rate) d->out_rate = d->rate;
+  resample = d->out_rate != d->rate; /* IAMF_decoder.c:3193-3199 */
+  d->info.max_frame_size = d->frame_size <= 1024 ? 6144 : 6 * d->frame_size; /* :1628-1630 */
+
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.n_streams = 1;
+  cfg.frame_size = (int32_t)d->frame_size;
+  cfg.sample_rate = (int32_t)d->rate;
+  cfg.out_channels = d->out_channels;
+  cfg.projection = IAMF_HIP_PROJ_EXACT; /* a single decoder handle is not throughput bound */
+  /* element 0: the parametric down-mixer when the element carries demixing info and the target
+   * is a smaller IAMF layout (iamf_stream_renderer_enable_downmix, IAMF_decoder.c:2448-2478) */
+  d->use_dmx = 0;
+  d->demix_p = 0;
+  {
+    Element *e0 = d->sel_el[0];
+    int out_layout = d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION ? k_ss_layout[d->out_ss] : -1;
+    if (e0->type == AUDIO_ELEMENT_CHANNEL_BASED && e0->has_demix && out_layout >= 0 &&
+        iamf_hip_dmx_valid(e0->layout, out_layout)) {
+      if (p->nel > 1) return IAMF_ERR_UNIMPLEMENTED;
+      d->use_dmx = 1;
+      cfg.matrix.kind = IAMF_HIP_KIND_DMX;
+      cfg.matrix.in_id = e0->layout;
+      cfg.matrix.out_id = out_layout;
+      iamf_hip_dmx_state_init(&d->dmx);
+      iamf_hip_dmx_set_mode_weight(&d->dmx, e0->demix_default_mode, e0->demix_default_w);
+      for (int i = 0; i < d->nparam; ++i)
+        if (d->param[i].id == e0->demix_pid) d->demix_p = &d->param[i];
+    } else if (element_matrix(d, e0, &cfg.matrix)) {
+      return IAMF_ERR_INTERNAL;
+    }
+  }
+  if (resample) {
+    cfg.out_format = IAMF_HIP_FMT_F32;
+    cfg.limiter_enable = 0;
+  } else {
+    cfg.out_format = (int32_t)d->bit_depth;
+    cfg.limiter_enable = d->limiter_on;
+    cfg.limiter_threshold_db = d->limiter_db;
+    cfg.loudness_enable = d->norm_loudness != 0.f;
+  }
+  if (!iamf_hip_format_bytes(cfg.out_format)) return IAMF_ERR_BAD_ARG; /* bit depth never set: IAMF_decoder.c:3726 */
+  if (iamf_hip_batch_create(&cfg, &d->batch)) return IAMF_ERR_INTERNAL;
+  if (p->nel == 2) {
+    iamf_hip_matrix m2;
+    float one = 1.f;
+    if (element_matrix(d, d->sel_el[1], &m2) || iamf_hip_batch_set_second_element(d->batch, &m2, &one))
+      return IAMF_ERR_INTERNAL;
+  }
+  if (resample) {
+    float eye[24 * 24];
+    iamf_hip_batch_config c3;
+    for (int i = 0; i < d->out_channels; ++i)
+      for (int j = 0; j < d->out_channels; ++j) eye[i * d->out_channels + j] = i == j ? 1.f : 0.f;
+    if (iamf_hip_resampler_create(1, d->out_channels, (int)d->rate, (int)d->out_rate, &d->rs)) return IAMF_ERR_INTERNAL;
+    memset(&c3, 0, sizeof(c3));
+    c3.n_streams = 1;
+    c3.frame_size = 1; /* interleaved f32 in */
+    c3.sample_rate = (int32_t)d->out_rate;
+    c3.out_channels = d->out_channels;
+    c3.out_format = (int32_t)d->bit_depth;
+    c3.matrix.kind = IAMF_HIP_KIND_M2M;
+    c3.matrix.m = c3.matrix.n = c3.matrix.channels = d->out_channels;
+    c3.matrix.lfe1 = c3.matrix.lfe2 = -1;
+    c3.matrix.mat = eye;
+    c3.limiter_enable = d->limiter_on;
+    c3.limiter_threshold_db = d->limiter_db;
+    c3.loudness_enable = d->norm_loudness != 0.f;
+    c3.projection = IAMF_HIP_PROJ_EXACT;
+    if (!iamf_hip_format_bytes(c3.out_format)) return IAMF_ERR_BAD_ARG;
+    if (iamf_hip_batch_create(&c3, &d->batch3)) return IAMF_ERR_INTERNAL;
+  }
+  {
+    iamf_hip_batch *lb = d->batch3 ? d->batch3 : d->batch;
+    float one = 1.f, lg = db2lin(d->norm_loudness - d->mix_loudness);
+    if (iamf_hip_batch_set_gains(lb, d->batch3 ? &one : 0, d->batch3 ? &one : 0, &lg)) return IAMF_ERR_INTERNAL;
+  }
+  if (hipStreamCreate(&d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
+  d->tmp = (float *)malloc(sizeof(float) * MAX_SUBSTREAMS * 2 * d->frame_size);
+  if (!d->tmp) return IAMF_ERR_ALLOC_FAIL;
+  for (int e = 0; e < p->nel; ++e) {
+    size_t bytes = sizeof(float) * d->sel_el[e]->channels * d->frame_size;
+    if (hipHostMalloc((void **)&d->h_in[e], bytes, 0) != hipSuccess || hipMalloc((void **)&d->d_in[e], bytes) != hipSuccess)
+      return IAMF_ERR_ALLOC_FAIL;
+  }
+  for (int i = 0; i < 3; ++i)
+    if (hipHostMalloc((void **)&d->h_ramp[i], sizeof(float) * d->frame_size, 0) != hipSuccess ||
+        hipMalloc((void **)&d->d_ramp[i], sizeof(float) * d->frame_size) != hipSuccess)
+      return IAMF_ERR_ALLOC_FAIL;
+  if (hipMalloc((void **)&d->d_dmx, sizeof(iamf_hip_dmx_frame)) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+  d->pcm_cap = (size_t)4 * d->info.max_frame_size * d->out_channels;
+  if (hipMalloc(&d->d_pcm, d->pcm_cap) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+  if (resample) {
+    int cap = iamf_hip_resampler_out_capacity(d->rs, (int)d->frame_size) + 512;
+    if (hipMalloc((void **)&d->d_mid, sizeof(float) * d->frame_size * d->out_channels) != hipSuccess ||
+        hipMalloc((void **)&d->d_res, sizeof(float) * cap * d->out_channels) != hipSuccess)
+      return IAMF_ERR_ALLOC_FAIL;
+  }
+  d->timestamp = 0;
+  d->flushed = 0;
+  d->configured = 1;
+  return IAMF_OK;
+}
+
+int IAMF_decoder_configure(IAMF_DecoderHandle d, const uint8_t *data, uint32_t size, uint32_t *rsize) {
+  uint32_t pos = 0;
+  int saw_data = 0, rc;
+  if (!d) return IAMF_ERR_BAD_ARG;
+  if (rsize) *rsize = 0;
+  while (data && pos < size) { /* iamf_decoder_internal_read_descriptors_OBUs, IAMF_decoder.c:2784-2831 */
+    Obu o;
+    uint32_t n = obu_split(data + pos, size - pos, &o);
+    if (!n) break;
+    rc = IAMF_OK;
+    switch (o.type) {
+      case 31:
+        if (o.payload_size < 6 || memcmp(o.payload, "iamf", 4) || o.payload[4] > 1) return IAMF_ERR_INVALID_PACKET;
+        d->have_header = 1;
+        break;
+      case 0: rc = parse_codec_config(d, &o); break;
+      case 1: rc = parse_element(d, &o); break;
+      case 2: rc = parse_presentation(d, &o); break;
+      default: saw_data = 1; break;
+    }
+    if (rc) return rc;
+    if (saw_data) break;
+    pos += n;
+  }
+  if (rsize) *rsize = pos;
+  if (data && rsize && !saw_data) return IAMF_ERR_BUFFER_TOO_SMALL; /* IAMF_decoder.c:2778,3923-3930 */
+  rc = setup_pipeline(d);
+  return rc;
+}
+
+/* ---- one temporal unit ---- */
+static float lpcm_sample(const struct IAMF_Decoder *d, const uint8_t *p) { /* pcm/IAMF_pcm_decoder.c:64-83,133-149 */
+  if (d->sample_size == 16) {
+    int16_t v = d->little_endian ? (int16_t)(p[0] | (p[1] << 8)) : (int16_t)(p[1] | (p[0] << 8));
+    return v / (float)(1 << 15);
+  } else if (d->sample_size == 24) {
+    int32_t v = d->little_endian ? (p[0] | (p[1] << 8) | (p[2] << 16)) : (p[2] | (p[1] << 8) | (p[0] << 16));
+    if (v & 0x800000) v |= ~0xffffff;
+    return v / (float)(1 << 23);
+  } else {
+    uint32_t u = d->little_endian ? ((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24))
+                                  : ((uint32_t)p[3] | ((uint32_t)p[2] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[0] << 24));
+    return (int32_t)u / (float)(1U << 31);
+  }
+}
+
+/* substreams -> planar f32 in the order the renderer expects; returns samples per channel */
+static int unpack_element(struct IAMF_Decoder *d, int ei) {
+  const Element *e = d->sel_el[ei];
+  const int bps = (int)d->sample_size / 8, fs = (int)d->frame_size;
+  float *dst = d->h_in[ei];
+  int ns = -1;
+  float *tmp = d->tmp;
+  /* audio-layer order: coupled pairs first, then singles */
+  int c = 0;
+  for (int s = 0; s < e->nsub; ++s) {
+    const int w = (e->type == AUDIO_ELEMENT_CHANNEL_BASED && s < e->nb_coupled) ? 2 : 1;
+    const int n = (int)(d->pkt_len[ei][s] / (uint32_t)(w * bps));
+    if (ns < 0) ns = n;
+    if (n != ns || n > fs) return IAMF_ERR_INVALID_PACKET;
+    for (int i = 0; i < n; ++i)
+      for (int k = 0; k < w; ++k) tmp[(size_t)(c + k) * fs + i] = lpcm_sample(d, d->pkt[ei][s] + (size_t)(i * w + k) * bps);
+    c += w;
+  }
+  for (int p = 0; p < e->channels; ++p) {
+    int src = e->type == AUDIO_ELEMENT_CHANNEL_BASED ? k_al_of_pl[e->layout][p] : e->amb_map[p];
+    if (src < c)
+      memcpy(dst + (size_t)p * fs, tmp + (size_t)src * fs, sizeof(float) * ns);
+    else
+      memset(dst + (size_t)p * fs, 0, sizeof(float) * ns);
+  }
+  return ns;
+}
+
+static int tu_complete(const struct IAMF_Decoder *d) { /* IAMF_decoder.c:2854-2869 */
+  for (int e = 0; e < d->sel->nel; ++e)
+    for (int s = 0; s < d->sel_el[e]->nsub; ++s)
+      if (!d->pkt_have[e][s]) return 0;
+  return 1;
+}
+
+static int render_tu(struct IAMF_Decoder *d, void *pcm) {
+  iamf_hip_render_args a;
+  const int fs = (int)d->frame_size, bytes = (int)d->bit_depth / 8;
+  int ns = 0, n, keep, s0;
+  float cgain[3];
+  int ramp[3] = {0, 0, 0};
+  memset(&a, 0, sizeof(a));
+  for (int e = 0; e < d->sel->nel; ++e) {
+    int r = unpack_element(d, e);
+    if (r < 0) return r;
+    ns = r;
+  }
+  /* iamf_frame_trim (IAMF_decoder.c:1361-1381): rendering is memoryless, so trimming the
+   * element PCM before the renderer equals trimming the rendered frame */
+  s0 = (int)d->tu_trim_start;
+  keep = ns - s0 - (int)d->tu_trim_end;
+  for (int e = 0; e < d->sel->nel; ++e)
+    for (int s = 0; s < d->sel_el[e]->nsub; ++s) d->pkt_have[e][s] = 0;
+  if (keep <= 0) {
+    d->timestamp += fs;
+    return 0;
+  }
+  for (int e = 0; e < d->sel->nel; ++e) {
+    const int ch = d->sel_el[e]->channels;
+    if (s0)
+      for (int c = 0; c < ch; ++c) memmove(d->h_in[e] + (size_t)c * fs, d->h_in[e] + (size_t)c * fs + s0, sizeof(float) * keep);
+    if (hipMemcpyAsync(d->d_in[e], d->h_in[e], sizeof(float) * ch * fs, hipMemcpyHostToDevice, d->stream) != hipSuccess)
+      return IAMF_ERR_INTERNAL;
+  }
+  /* mix gains of this frame */
+  {
+    const uint64_t pt = d->timestamp + (uint64_t)s0;
+    float el_def[2] = {db2lin(q_to_float(d->sel->el_gain_q[0], 8)), db2lin(q_to_float(d->sel->el_gain_q[1], 8))};
+    float og_def = db2lin(q_to_float(d->sel->out_gain_q, 8));
+    ramp[0] = mix_gain_unit(d->el_gain_p[0], el_def[0], pt, keep, (int)d->rate, &cgain[0], d->h_ramp[0]);
+    ramp[1] = d->sel->nel > 1 ? mix_gain_unit(d->el_gain_p[1], el_def[1], pt, keep, (int)d->rate, &cgain[1], d->h_ramp[1]) : 0;
+    ramp[2] = mix_gain_unit(d->out_gain_p, og_def, pt, keep, (int)d->rate, &cgain[2], d->h_ramp[2]);
+    if (d->sel->nel < 2) cgain[1] = 1.f;
+    for (int i = 0; i < 3; ++i) {
+      if (!ramp[i]) /* a constant is applied through the ramp too: same product, one code path */
+        for (int k = 0; k < keep; ++k) d->h_ramp[i][k] = cgain[i];
+      if (hipMemcpyAsync(d->d_ramp[i], d->h_ramp[i], sizeof(float) * keep, hipMemcpyHostToDevice, d->stream) != hipSuccess)
+        return IAMF_ERR_INTERNAL;
+    }
+  }
+  a.d_in = d->d_in[0];
+  a.in_stream_stride = a.in_frame_stride = (int64_t)d->sel_el[0]->channels * fs;
+  if (d->sel->nel > 1) {
+    a.d_in2 = d->d_in[1];
+    a.in2_stream_stride = a.in2_frame_stride = (int64_t)d->sel_el[1]->channels * fs;
+  }
+  /* constant gains go through iamf_frame_gain's rule (only if != 1 and > 0); ramps unconditionally */
+  {
+    float eg = ramp[0] ? 1.f : cgain[0], og = ramp[2] ? 1.f : cgain[2];
+    if (iamf_hip_batch_set_gains(d->batch, &eg, &og, 0)) return IAMF_ERR_INTERNAL;
+    if (ramp[0]) a.d_element_ramp = d->d_ramp[0];
+    if (ramp[2]) a.d_output_ramp = d->d_ramp[2];
+    if (d->sel->nel > 1) a.d_element2_ramp = d->d_ramp[1]; /* element 1: constant or ramp, both exact */
+  }
+  a.ramp_stream_stride = fs;
+  if (d->use_dmx) { /* IAMF_decoder.c:2574-2583 */
+    iamf_hip_dmx_frame fr;
+    fr.offset = 0;
+    iamf_hip_dmx_coefficients(&d->dmx, fr.prev);
+    if (d->demix_p && d->demix_p->have_block && d->demix_p->block_start <= d->timestamp &&
+        d->timestamp < d->demix_p->block_start + d->demix_p->block_duration)
+      iamf_hip_dmx_set_mode_weight(&d->dmx, d->demix_p->dmx_mode, -1);
+    iamf_hip_dmx_coefficients(&d->dmx, fr.cur);
+    if (hipMemcpyAsync(d->d_dmx, &fr, sizeof(fr), hipMemcpyHostToDevice, d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
+    a.d_dmx_frames = d->d_dmx;
+  }
+  a.n_frames = 1;
+  a.n_samples = keep < fs ? keep : 0;
+  a.stream = d->stream;
+  if (!d->rs) {
+    a.d_pcm = d->d_pcm;
+    a.pcm_stream_stride_bytes = (int64_t)d->pcm_cap;
+    n = iamf_hip_batch_render_ex(d->batch, &a);
+  } else { /* render (f32) -> resample -> loudness / limiter / pack */
+    int n2;
+    a.d_pcm = d->d_mid;
+    a.pcm_stream_stride_bytes = (int64_t)sizeof(float) * fs * d->out_channels;
+    n = iamf_hip_batch_render_ex(d->batch, &a);
+    if (n < 0) return IAMF_ERR_INTERNAL;
+    n2 = iamf_hip_resampler_process(d->rs, d->d_mid, (int64_t)fs * d->out_channels, n, d->d_res,
+                                    (int64_t)(iamf_hip_resampler_out_capacity(d->rs, fs) + 512) * d->out_channels, d->stream);
+    if (n2 < 0) return IAMF_ERR_INTERNAL;
+    n = n2 ? iamf_hip_batch_render(d->batch3, d->d_res, 0, d->out_channels, n2, d->d_pcm, (int64_t)d->pcm_cap, d->stream) : 0;
+  }
+  if (n < 0) return IAMF_ERR_INTERNAL;
+  if (n > 0 && hipMemcpyAsync(pcm, d->d_pcm, (size_t)n * d->out_channels * bytes, hipMemcpyDeviceToHost, d->stream) != hipSuccess)
+    return IAMF_ERR_INTERNAL;
+  if (hipStreamSynchronize(d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
+  d->timestamp += fs;
+  d->last_frame = (uint32_t)n;
+  return n;
+}
+
+static int flush_tail(struct IAMF_Decoder *d, void *pcm) { /* iamf_delay_buffer_handle, IAMF_decoder.c:3250-3301 */
+  const int bytes = (int)d->bit_depth / 8;
+  int n = 0;
+  if (d->flushed) return 0;
+  d->flushed = 1;
+  if (!d->rs) {
+    if (!d->limiter_on) return 0;
+    n = iamf_hip_batch_flush(d->batch, d->d_pcm, (int64_t)d->pcm_cap, d->stream);
+  } else {
+    const int cap = iamf_hip_resampler_flush_capacity(d->rs);
+    const int extra = d->limiter_on ? 240 : 0;
+    int n2;
+    if (hipMemsetAsync(d->d_res, 0, sizeof(float) * (cap + extra) * d->out_channels, d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
+    n2 = iamf_hip_resampler_flush(d->rs, d->d_res, (int64_t)(cap + extra) * d->out_channels, d->stream);
+    if (n2 < 0) return IAMF_ERR_INTERNAL;
+    n = (n2 + extra) ? iamf_hip_batch_render(d->batch3, d->d_res, 0, d->out_channels, n2 + extra, d->d_pcm, (int64_t)d->pcm_cap, d->stream) : 0;
+  }
+  if (n < 0) return IAMF_ERR_INTERNAL;
+  if (n > 0 && hipMemcpyAsync(pcm, d->d_pcm, (size_t)n * d->out_channels * bytes, hipMemcpyDeviceToHost, d->stream) != hipSuccess)
+    return IAMF_ERR_INTERNAL;
+  if (hipStreamSynchronize(d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
+  return n;
+}
+
+int IAMF_decoder_decode(IAMF_DecoderHandle d, const uint8_t *data, int32_t size, uint32_t *rsize, void *pcm) {
+  uint32_t pos = 0;
+  if (!d || !pcm) return IAMF_ERR_BAD_ARG;
+  if (rsize) *rsize = 0;
+  if (!d->configured) return IAMF_ERR_INVALID_STATE;
+  if (!data || size <= 0) return flush_tail(d, pcm); /* IAMF_decoder.c:3508-3519 */
+  while (pos < (uint32_t)size) { /* iamf_decoder_internal_parse_OBUs, IAMF_decoder.c:2871-2995 */
+    Obu o;
+    uint32_t n = obu_split(data + pos, (uint32_t)size - pos, &o);
+    if (!n) break;
+    pos += n;
+    if (o.type == 31 && !o.redundant) { /* a new IA sequence: the caller must reconfigure (:2918-2921) */
+      if (rsize) *rsize = pos - n;
+      return IAMF_ERR_INVALID_STATE;
+    }
+    if (o.type == 3) {
+      int rc = parse_parameter_block(d, &o);
+      if (rc) return rc;
+    } else if (o.type >= 5 && o.type <= 23) {
+      Rd r = {o.payload, o.payload_size, 0, 0};
+      uint64_t sid = o.type == 5 ? rd_leb128(&r) : (uint64_t)(o.type - 6);
+      for (int e = 0; e < d->sel->nel; ++e)
+        for (int s = 0; s < d->sel_el[e]->nsub; ++s)
+          if (d->sel_el[e]->sub_ids[s] == sid) {
+            uint32_t len = o.payload_size - r.pos;
+            uint8_t *b = (uint8_t *)realloc(d->pkt[e][s], len ? len : 1);
+            if (!b) return IAMF_ERR_ALLOC_FAIL;
+            memcpy(b, o.payload + r.pos, len);
+            d->pkt[e][s] = b;
+            d->pkt_len[e][s] = len;
+            d->pkt_have[e][s] = 1;
+            if (e == 0 && s == 0) {
+              d->tu_trim_start = o.trim_start;
+              d->tu_trim_end = o.trim_end;
+            }
+          }
+      if (tu_complete(d)) {
+        if (rsize) *rsize = pos;
+        return render_tu(d, pcm);
+      }
+    }
+  }
+  if (rsize) *rsize = pos;
+  return 0;
+}
+
+/* ---- setters / getters (IAMF_decoder.c:3948-4168) ---- */
+int IAMF_decoder_set_mix_presentation_id(IAMF_DecoderHandle d, uint64_t id) {
+  if (!d) return IAMF_ERR_BAD_ARG;
+  d->mix_id = (int64_t)id;
+  return IAMF_OK;
+}
+int IAMF_decoder_output_layout_set_sound_system(IAMF_DecoderHandle d, IAMF_SoundSystem ss) {
+  if (!d || ss <= SOUND_SYSTEM_INVALID || ss >= SOUND_SYSTEM_END) return IAMF_ERR_BAD_ARG;
+  d->out_type = IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION;
+  d->out_ss = ss;
+  return IAMF_OK;
+}
+int IAMF_decoder_output_layout_set_binaural(IAMF_DecoderHandle d) {
+  if (!d) return IAMF_ERR_BAD_ARG;
+  d->out_type = IAMF_LAYOUT_TYPE_BINAURAL;
+  return IAMF_OK;
+}
+int IAMF_layout_sound_system_channels_count(IAMF_SoundSystem ss) {
+  if (ss <= SOUND_SYSTEM_INVALID || ss >= SOUND_SYSTEM_END) return IAMF_ERR_BAD_ARG;
+  return k_ss_channels[ss];
+}
+int IAMF_layout_binaural_channels_count(void) { return 2; }
+char *IAMF_decoder_get_codec_capability(void) {
+  const char *s = "iamf.001.001.ipcm"; /* the one codec of this build */
+  char *r = (char *)malloc(strlen(s) + 1);
+  if (r) strcpy(r, s);
+  return r;
+}
+int IAMF_decoder_set_normalization_loudness(IAMF_DecoderHandle d, float loudness) {
+  if (!d) return IAMF_ERR_BAD_ARG;
+  d->norm_loudness = loudness;
+  return IAMF_OK;
+}
+int IAMF_decoder_set_bit_depth(IAMF_DecoderHandle d, uint32_t bit_depth) {
+  if (!d || (bit_depth != 16 && bit_depth != 24 && bit_depth != 32)) return IAMF_ERR_BAD_ARG;
+  d->bit_depth = bit_depth;
+  return IAMF_OK;
+}
+int IAMF_decoder_peak_limiter_enable(IAMF_DecoderHandle d, uint32_t enable) {
+  if (!d) return IAMF_ERR_BAD_ARG;
+  d->limiter_on = enable ? 1 : 0;
+  return IAMF_OK;
+}
+int IAMF_decoder_peak_limiter_set_threshold(IAMF_DecoderHandle d, float db) {
+  if (!d) return IAMF_ERR_BAD_ARG;
+  d->limiter_db = db;
+  return IAMF_OK;
+}
+float IAMF_decoder_peak_limiter_get_threshold(IAMF_DecoderHandle d) { return d ? d->limiter_db : 0.f; }
+int IAMF_decoder_set_sampling_rate(IAMF_DecoderHandle d, uint32_t rate) { /* IAMF_decoder.c:4112-4130 */
+  static const uint32_t ok[] = {8000, 12000, 16000, 24000, 32000, 44100, 48000};
+  if (!d || d->configured) return IAMF_ERR_BAD_ARG;
+  for (unsigned i = 0; i < sizeof(ok) / sizeof(ok[0]); ++i)
+    if (ok[i] == rate) {
+      d->out_rate = rate;
+      return IAMF_OK;
+    }
+  return IAMF_ERR_BAD_ARG;
+}
+IAMF_StreamInfo *IAMF_decoder_get_stream_info(IAMF_DecoderHandle d) { return d ? &d->info : 0; }
+int IAMF_decoder_set_pts(IAMF_DecoderHandle d, int64_t pts, uint32_t time_base) {
+  if (!d) return IAMF_ERR_BAD_ARG;
+  d->pts = pts;
+  d->pts_base = time_base;
+  return IAMF_OK;
+}
+int IAMF_decoder_get_last_metadata(IAMF_DecoderHandle d, int64_t *pts, IAMF_extradata *m) {
+  if (!d || !pts || !m || !d->configured) return IAMF_ERR_BAD_ARG;
+  memset(m, 0, sizeof(*m));
+  *pts = d->pts + (int64_t)((double)(d->timestamp - d->frame_size) * d->pts_base / d->rate + 0.5);
+  m->output_sound_system = d->out_type == IAMF_LAYOUT_TYPE_BINAURAL ? SOUND_SYSTEM_INVALID : d->out_ss;
+  m->number_of_samples = d->last_frame;
+  m->bitdepth = d->bit_depth;
+  m->sampling_rate = d->out_rate;
+  m->output_sound_mode = d->out_type == IAMF_LAYOUT_TYPE_BINAURAL ? IAMF_SOUND_MODE_BINAURAL
+                         : d->out_ss == SOUND_SYSTEM_A             ? IAMF_SOUND_MODE_STEREO
+                                                                   : IAMF_SOUND_MODE_MULTICHANNEL;
+  m->num_loudness_layouts = d->sel->nlayouts;
+  if (d->sel->nlayouts) {
+    m->loudness_layout = (IAMF_Layout *)calloc((size_t)d->sel->nlayouts, sizeof(IAMF_Layout));
+    m->loudness = (IAMF_LoudnessInfo *)calloc((size_t)d->sel->nlayouts, sizeof(IAMF_LoudnessInfo));
+    if (!m->loudness_layout || !m->loudness) return IAMF_ERR_ALLOC_FAIL;
+    for (int i = 0; i < d->sel->nlayouts; ++i) {
+      m->loudness_layout[i].sound_system.type = (uint8_t)d->sel->layout_type[i];
+      m->loudness_layout[i].sound_system.sound_system = (uint8_t)d->sel->layout_ss[i];
+      m->loudness[i] = d->sel->loud[i];
+      m->loudness[i].anchor_loudness = 0;
+      m->loudness[i].num_anchor_loudness = 0;
+    }
+  }
+  if (d->use_dmx) {
+    m->num_parameters = 1;
+    m->param = (IAMF_Param *)calloc(1, sizeof(IAMF_Param));
+    if (!m->param) return IAMF_ERR_ALLOC_FAIL;
+    m->param->parameter_length = 8;
+    m->param->parameter_definition_type = IAMF_PARAMETER_TYPE_DEMIXING;
+    m->param->dmixp_mode = (uint32_t)d->dmx.mode;
+  }
+  return IAMF_OK;
+}

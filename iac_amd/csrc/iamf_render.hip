@@ -563,7 +563,11 @@ int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *a) {
   if ((a->d_element_ramp || a->d_element2_ramp || a->d_output_ramp) &&
       a->ramp_stream_stride < (int64_t)a->n_frames * b->cfg.frame_size && b->cfg.n_streams > 1)
     return IAMF_HIP_ERR_BAD_ARG;
-  const int64_t total = (int64_t)a->n_frames * b->cfg.frame_size;
+  int64_t total = (int64_t)a->n_frames * b->cfg.frame_size;
+  if (a->n_samples > 0) {
+    if (a->n_frames != 1 || a->n_samples > b->cfg.frame_size) return IAMF_HIP_ERR_BAD_ARG;
+    total = a->n_samples;
+  }
   if (total > INT32_MAX) return IAMF_HIP_ERR_BAD_ARG;
   const int64_t need = total * b->cfg.out_channels * iamf_hip_format_bytes(b->cfg.out_format);
   if (b->cfg.n_streams > 1 && a->pcm_stream_stride_bytes < need) return IAMF_HIP_ERR_BUFFER_TOO_SMALL;

@@ -10,7 +10,7 @@
 //     peak*gain > threshold does wave 0 re-run the recurrence from that 64-sample block on:
 //     ballot-driven speculation per block, and for runs of consecutive triggers (the limiter
 //     holding a peak down) a wave-wide DPP shift chain that resolves one sample per 3-4 VALU ops;
-//   * interleaved PCM written as 16-byte stores.
+//   * interleaved PCM written as 16-byte stores; input loads are non-temporal (read once).
 // Same f32 operation order as render_generic.hpp and the reference: bit-exact.
 #pragma once
 
@@ -35,6 +35,12 @@ __device__ __forceinline__ float dpp_quad_bcast3(float v) {
 __device__ __forceinline__ float dpp_wave_shr1(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
+// 16-byte streaming load (read once: non-temporal, keeps the caches for what is re-read)
+__device__ __forceinline__ float4 ld_stream4(const float *p) {
+  using v4 = __attribute__((ext_vector_type(4))) float;
+  const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -45,7 +51,7 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 // state after the last sample.  Restates audio_effect_peak_limiter.c:237-265 sample by sample:
 // every accepted gain is produced by exactly the reference's f32 operations.
 template <typename Lookup>
-__device__ __forceinline__ void limiter_wave(const float *arr_p, const float *arr_e, float *arr_g,
+__device__ __forceinline__ void limiter_wave(const float *arr_p, float *arr_g,
                                              Lookup ctab, int b0, int nblk, int &n, float &gs,
                                              float &ge, float &g_last, float thr, int n_atk, int n_end) {
   const int lane = threadIdx.x & 63;
@@ -53,7 +59,7 @@ __device__ __forceinline__ void limiter_wave(const float *arr_p, const float *ar
   float gacc = 1.0f;
   for (int b = b0; b < nblk; ++b) {
     const float pk = arr_p[b * 64 + lane];
-    const float e = arr_e[b * 64 + lane];
+    const float e = thr / pk;  // targetEndGain if this sample triggers (IEEE division, as the reference)
     int l0 = 0;
     while (true) {
       // speculate: no trigger in lanes l0..63 given the state before lane l0
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
       const int i = k - f * fs;
       const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
 #pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = *reinterpret_cast<const float4 *>(src + (int64_t)m * fs);
+      for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
     } else {
 #pragma unroll
       for (int m = 0; m < M; ++m) x[m] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
         const int i = kn - f * fs;
         const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
 #pragma unroll
-        for (int m = 0; m < M; ++m) x[m] = *reinterpret_cast<const float4 *>(src + (int64_t)m * fs);
+        for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
       }
     }
 
@@ -303,12 +309,6 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     pk.y = fmaxf(fmaxf(so.y, w14), pre_ex.y);
     pk.z = fmaxf(fmaxf(so.z, w14), pre_ex.z);
     pk.w = fmaxf(fmaxf(so.w, w14), pre_ex.w);
-    float4 e;
-    e.x = thr / pk.x;
-    e.y = thr / pk.y;
-    e.z = thr / pk.z;
-    e.w = thr / pk.w;
-
     // ---- gains under the hypothesis "no trigger in this chunk" ----
     float gh[4];
 #pragma unroll
@@ -327,7 +327,6 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
       if (pk.x * g.x > thr) kfirst = 4 * t + 0;
     }
     *reinterpret_cast<float4 *>(&arr_p[4 * t]) = pk;
-    *reinterpret_cast<float4 *>(&arr_e[4 * t]) = e;
     {
       const unsigned long long any = __ballot(kfirst != kBig);
       if (lane == 0) misc[wave] = __int_as_float(any ? __builtin_amdgcn_readlane(kfirst, __builtin_ctzll(any)) : kBig);
@@ -348,7 +347,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
       if (wave == 0) {
         int ln = n_st + 64 * b0 < n_end ? n_st + 64 * b0 : n_end;
         float lgs = gs, lge = ge, lgl = g_cur;
-        limiter_wave(arr_p, arr_e, arr_g, [ctl](int ci) { return ctl[ci]; }, b0, cnt >> 6, ln, lgs, lge, lgl,
+        limiter_wave(arr_p, arr_g, [ctl](int ci) { return ctl[ci]; }, b0, cnt >> 6, ln, lgs, lge, lgl,
                      thr, n_atk, n_end);
         if (lane == 0) {
           misc[4] = lgl;

@@ -275,15 +275,12 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
 #pragma unroll
     for (int j = 1; j <= 14; ++j) w14 = fmaxf(w14, ring_bm[(bpos - j) & (kWPos / 16 - 1)]);
     const float pk = fmaxf(fmaxf(ring_suf[(int)((gk - kDelay) & (kWPos - 1))], w14), pre);
-    const float e = thr / pk;
-
     // ---- gains under the no-trigger hypothesis ----
     int n_pre = n_st + t;
     n_pre = n_pre < n_end ? n_pre : n_end;
     float g = gain_at(n_pre, gs, ge, win[t + 1], n_atk, n_end);
     const bool trig = valid && (pk * g > thr);
     arr_p[t] = pk;
-    arr_e[t] = e;
     {
       const unsigned long long any = __ballot(trig);
       if (lane == 0) misc[wave] = __int_as_float(any ? 64 * wave + (int)__builtin_ctzll(any) : kBig);
@@ -308,7 +305,7 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
           const int d = ci - n_chunk;
           return (d >= 0 && d < kWWin) ? win[d] : head[ci < kWWin ? ci : kWWin - 1];
         };
-        limiter_wave(arr_p, arr_e, arr_g, look, b0, cnt >> 6, ln, lgs, lge, lgl, thr, n_atk, n_end);
+        limiter_wave(arr_p, arr_g, look, b0, cnt >> 6, ln, lgs, lge, lgl, thr, n_atk, n_end);
         if (lane == 0) {
           misc[4] = lgl;
           misc[5] = lgs;

@@ -53,7 +53,7 @@ class RenderArgs(C.Structure):
                 ("d_in2", C.c_void_p), ("in2_stream_stride", C.c_int64), ("in2_frame_stride", C.c_int64),
                 ("d_element_ramp", C.c_void_p), ("d_element2_ramp", C.c_void_p),
                 ("d_output_ramp", C.c_void_p), ("ramp_stream_stride", C.c_int64),
-                ("d_dmx_frames", C.c_void_p), ("n_frames", C.c_int32), ("reserved", C.c_int32),
+                ("d_dmx_frames", C.c_void_p), ("n_frames", C.c_int32), ("n_samples", C.c_int32),
                 ("d_pcm", C.c_void_p), ("pcm_stream_stride_bytes", C.c_int64), ("stream", C.c_void_p)]
 
 

@@ -189,7 +189,8 @@ typedef struct {
   int64_t ramp_stream_stride;   /* floats */
   const iamf_hip_dmx_frame *d_dmx_frames; /* kind DMX: [n_streams][n_frames] on the device */
   int32_t n_frames;
-  int32_t reserved;
+  int32_t n_samples;            /* 0, or with n_frames == 1: render only the first n_samples of the frame
+                                   (a frame shortened by iamf_frame_trim, IAMF_decoder.c:1361-1381) */
   void *d_pcm;
   int64_t pcm_stream_stride_bytes;
   void *stream;

@@ -19,72 +19,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
 import e2e_cases  # noqa: E402
 
 
-def ref_decode(ref, stream_bytes, layout, bit_depth=16, out_rate=0, loudness=0.0, limiter=True,
-               threshold=-1.0):
-    """layout: ('ss', IAMF_SoundSystem enum value) or ('binaural',). Returns (pcm ndarray
-    [n][ch] (24-bit: [n][ch][3] bytes), list of per-call return values)."""
-    ref.IAMF_decoder_open.restype = C.c_void_p
-    ref.IAMF_decoder_close.argtypes = [C.c_void_p]
-    ref.IAMF_decoder_configure.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]
-    ref.IAMF_decoder_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_uint32), C.c_void_p]
-    ref.IAMF_decoder_output_layout_set_sound_system.argtypes = [C.c_void_p, C.c_int]
-    ref.IAMF_decoder_output_layout_set_binaural.argtypes = [C.c_void_p]
-    ref.IAMF_decoder_set_normalization_loudness.argtypes = [C.c_void_p, C.c_float]
-    ref.IAMF_decoder_set_bit_depth.argtypes = [C.c_void_p, C.c_uint32]
-    ref.IAMF_decoder_peak_limiter_enable.argtypes = [C.c_void_p, C.c_uint32]
-    ref.IAMF_decoder_peak_limiter_set_threshold.argtypes = [C.c_void_p, C.c_float]
-    ref.IAMF_decoder_set_sampling_rate.argtypes = [C.c_void_p, C.c_uint32]
-    ref.IAMF_decoder_set_pts.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
-    ref.IAMF_layout_sound_system_channels_count.argtypes = [C.c_int]
-
-    d = ref.IAMF_decoder_open()
-    if not limiter:
-        ref.IAMF_decoder_peak_limiter_enable(d, 0)
-    else:
-        ref.IAMF_decoder_peak_limiter_set_threshold(d, threshold)
-    ref.IAMF_decoder_set_normalization_loudness(d, loudness)
-    ref.IAMF_decoder_set_bit_depth(d, bit_depth)
-    if out_rate:
-        assert ref.IAMF_decoder_set_sampling_rate(d, out_rate) == 0
-    if layout[0] == "ss":
-        ref.IAMF_decoder_output_layout_set_sound_system(d, layout[1])
-        ch = ref.IAMF_layout_sound_system_channels_count(layout[1])
-    else:
-        ref.IAMF_decoder_output_layout_set_binaural(d)
-        ch = 2
-    ref.IAMF_decoder_set_pts(d, 0, 90000)
-    rsize = C.c_uint32(0)
-    r = ref.IAMF_decoder_configure(d, stream_bytes, len(stream_bytes), C.byref(rsize))
-    assert r == 0, "configure failed: %d" % r
-    used = rsize.value
-    bps = bit_depth // 8
-    pcm = C.create_string_buffer(bps * 6144 * 6 * ch)
-    chunks, rets = [], []
-    while used < len(stream_bytes):
-        rsize.value = 0
-        rest = stream_bytes[used:]
-        n = ref.IAMF_decoder_decode(d, rest, len(rest), C.byref(rsize), pcm)
-        assert n >= 0, "decode failed: %d" % n
-        if n > 0:
-            chunks.append(pcm.raw[:n * ch * bps])
-            rets.append(n)
-        used += rsize.value
-        if not rsize.value:
-            break
-    rsize.value = 0
-    n = ref.IAMF_decoder_decode(d, None, 0, C.byref(rsize), pcm)
-    if n > 0:
-        chunks.append(pcm.raw[:n * ch * bps])
-    rets.append(n)
-    ref.IAMF_decoder_close(d)
-    raw = np.frombuffer(b"".join(chunks), dtype=np.uint8)
-    if bit_depth == 16:
-        out = raw.view(np.int16).reshape(-1, ch)
-    elif bit_depth == 32:
-        out = raw.view(np.int32).reshape(-1, ch)
-    else:
-        out = raw.reshape(-1, ch, 3)
-    return out.copy(), rets
+from decoder_driver import decode_stream as ref_decode  # noqa: E402
 
 
 def generate(ref, manifest, gold_dir, synth):

@@ -1,0 +1,53 @@
+"""-m gpu: the IAMF_decoder.h facade of libiamf_hip.so (OBU parsing + LPCM on the host, rendering
+on the GPU) on the end-to-end streams, against PCM the REAL reference decoder produced from the same
+bytes.  `stereo_A_s16` is BASELINE.json configs[0] (iamfplayer -o2 -s0)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import e2e_cases
+from decoder_driver import decode_stream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import torch
+    assert torch.cuda.is_available()
+    import iac_amd
+    return C.CDLL(iac_amd.lib_path())
+
+
+@pytest.mark.parametrize("name", sorted(e2e_cases.CASES))
+def test_facade_matches_reference_decoder(lib, golden, name):
+    case = e2e_cases.CASES[name]
+    stream, _ = e2e_cases.build(name)
+    pcm, rets = decode_stream(lib, stream, case["layout"], bit_depth=case.get("bit_depth", 16),
+                              out_rate=case.get("out_rate", 0), loudness=case.get("loudness", 0.0),
+                              limiter=case.get("limiter", True), threshold=case.get("threshold", -1.0))
+    want = golden.npz("e2e")[name]
+    assert list(rets) == list(golden.npz("e2e")[name + "_rets"]), name
+    assert pcm.shape == want.shape
+    assert np.array_equal(pcm, want), name
+
+
+def test_facade_api_surface(lib):
+    lib.IAMF_decoder_open.restype = C.c_void_p
+    lib.IAMF_decoder_close.argtypes = [C.c_void_p]
+    lib.IAMF_decoder_get_codec_capability.restype = C.c_void_p
+    lib.IAMF_decoder_peak_limiter_get_threshold.restype = C.c_float
+    lib.IAMF_decoder_peak_limiter_get_threshold.argtypes = [C.c_void_p]
+    lib.IAMF_decoder_set_sampling_rate.argtypes = [C.c_void_p, C.c_uint32]
+    lib.IAMF_decoder_set_bit_depth.argtypes = [C.c_void_p, C.c_uint32]
+    assert [lib.IAMF_layout_sound_system_channels_count(i) for i in range(13)] == [2, 6, 8, 10, 11, 12, 14, 24, 8, 12, 10, 6, 1]
+    assert lib.IAMF_layout_binaural_channels_count() == 2
+    d = lib.IAMF_decoder_open()
+    assert abs(lib.IAMF_decoder_peak_limiter_get_threshold(d) + 1.0) < 1e-7  # default -1 dBFS
+    assert lib.IAMF_decoder_set_sampling_rate(d, 44100) == 0
+    assert lib.IAMF_decoder_set_sampling_rate(d, 22050) == -1  # not in the reference's whitelist
+    assert lib.IAMF_decoder_set_bit_depth(d, 20) == -1
+    cap = C.cast(lib.IAMF_decoder_get_codec_capability(), C.c_char_p).value
+    assert b"ipcm" in cap
+    lib.IAMF_decoder_close(d)
