@@ -117,16 +117,18 @@ typedef struct {
   uint64_t interval;
 } GainSeg;
 
+#define MAX_QUEUE 64
+/* One parameter's timeline, kept the way the reference's database keeps it (IAMF_decoder.c:984-1125):
+ * a FIFO of segments; `timestamp` is the start time of the oldest queued segment and only moves
+ * when iamf_database_parameters_time_elapse pops fully elapsed segments after a frame. */
 typedef struct {
   uint64_t id;
   int type; /* IAMF_PARAMETER_TYPE_* */
   ParamDef def;
-  int have_block;
-  uint64_t block_start; /* stream time (samples) where the held block begins */
-  uint64_t block_duration, next_start;
-  int nseg;
-  GainSeg seg[MAX_SEGMENTS];
-  int dmx_mode; /* demixing: mode of the held block */
+  int use_default; /* mix gain: no block received yet */
+  uint64_t timestamp, duration, elapse;
+  int qn;
+  GainSeg q[MAX_QUEUE]; /* demixing segments use .anim as the mode */
 } Param;
 
 typedef struct {
@@ -185,7 +187,7 @@ struct IAMF_Decoder {
   iamf_hip_batch *batch, *batch3; /* batch3: limiter stage behind the resampler */
   iamf_hip_resampler *rs;
   iamf_hip_dmx_state dmx;
-  int use_dmx;
+  int use_dmx, dmx_mode;
   /* packets of the temporal unit being assembled */
   uint8_t *pkt[2][MAX_SUBSTREAMS];
   uint32_t pkt_len[2][MAX_SUBSTREAMS];
@@ -257,6 +259,7 @@ static Param *param_get(struct IAMF_Decoder *d, const ParamDef *def, int type) {
   p->id = def->id;
   p->type = type;
   p->def = *def;
+  p->use_default = type == IAMF_PARAMETER_TYPE_MIX_GAIN;
   return p;
 }
 
@@ -408,36 +411,73 @@ static int parse_parameter_block(struct IAMF_Decoder *d, const Obu *o) {
     cinterval = rd_leb128(&r);
     nseg = cinterval ? (duration + cinterval - 1) / cinterval : rd_leb128(&r);
   }
-  if (nseg > MAX_SEGMENTS) return IAMF_ERR_UNIMPLEMENTED;
+  if (nseg > MAX_SEGMENTS || p->qn + (int)nseg > MAX_QUEUE) return IAMF_ERR_UNIMPLEMENTED;
   left = duration;
-  p->nseg = (int)nseg;
   for (uint64_t i = 0; i < nseg; ++i) {
+    GainSeg g;
     uint64_t iv = 0;
+    memset(&g, 0, sizeof(g));
     if (!cinterval) iv = p->def.mode ? rd_leb128(&r) : p->def.intervals[i];
     if (!iv) iv = cinterval < left ? cinterval : left; /* iamf_parameter_get_segment_interval */
     left -= iv;
-    p->seg[i].interval = iv;
+    g.interval = iv;
     if (p->type == IAMF_PARAMETER_TYPE_MIX_GAIN) {
-      GainSeg *g = &p->seg[i];
-      g->anim = (int)rd_leb128(&r);
-      g->start = db2lin(q_to_float((int16_t)rd_u16(&r), 8));
-      if (g->anim != ANIMATION_TYPE_STEP) {
-        g->end = db2lin(q_to_float((int16_t)rd_u16(&r), 8));
-        if (g->anim == ANIMATION_TYPE_BEZIER) {
-          g->control = db2lin(q_to_float((int16_t)rd_u16(&r), 8));
-          g->control_rel = qf_to_float(rd_u8(&r), 8);
+      g.anim = (int)rd_leb128(&r);
+      g.start = db2lin(q_to_float((int16_t)rd_u16(&r), 8));
+      if (g.anim != ANIMATION_TYPE_STEP) {
+        g.end = db2lin(q_to_float((int16_t)rd_u16(&r), 8));
+        if (g.anim == ANIMATION_TYPE_BEZIER) {
+          g.control = db2lin(q_to_float((int16_t)rd_u16(&r), 8));
+          g.control_rel = qf_to_float(rd_u8(&r), 8);
         }
       }
     } else if (p->type == IAMF_PARAMETER_TYPE_DEMIXING) {
-      p->dmx_mode = rd_u8(&r) >> 5;
+      g.anim = rd_u8(&r) >> 5;
+    }
+    if (r.err) return IAMF_ERR_INVALID_PACKET;
+    /* iamf_database_parameter_add, IAMF_decoder.c:1042-1071 */
+    p->q[p->qn++] = g;
+    p->duration += iv;
+  }
+  p->use_default = 0;
+  /* iamf_stream_decoder_update_parameter, IAMF_decoder.c:2130-2151: a demixing block sets the
+   * element's mode from the segment covering the middle of the current frame */
+  if (p->type == IAMF_PARAMETER_TYPE_DEMIXING && d->sel_el[0] && d->sel_el[0]->has_demix &&
+      d->sel_el[0]->demix_pid == p->id) {
+    const uint64_t pts = d->timestamp + d->frame_size / 2;
+    d->dmx_mode = IAMF_ERR_INTERNAL;
+    if (pts > p->timestamp && pts <= p->timestamp + p->duration) { /* :799-841 */
+      uint64_t start = pts - p->timestamp;
+      for (int i = 0; i < p->qn; ++i) {
+        if (start < p->q[i].interval) {
+          d->dmx_mode = p->q[i].anim;
+          break;
+        }
+        start -= p->q[i].interval;
+      }
     }
   }
-  if (r.err) return IAMF_ERR_INVALID_PACKET;
-  p->block_start = p->have_block ? p->next_start : d->timestamp;
-  p->block_duration = duration;
-  p->next_start = p->block_start + duration;
-  p->have_block = 1;
   return IAMF_OK;
+}
+
+/* iamf_database_parameters_time_elapse, IAMF_decoder.c:1089-1125 */
+static void params_time_elapse(struct IAMF_Decoder *d, uint64_t duration) {
+  for (int i = 0; i < d->nparam; ++i) {
+    Param *p = &d->param[i];
+    uint64_t e = duration;
+    if (d->rate != p->def.rate) { /* time_transform, :90-94 */
+      double r = (double)duration * p->def.rate;
+      e = (uint64_t)(r / d->rate + 0.5f);
+    }
+    p->elapse += e;
+    while (p->qn && p->q[0].interval <= p->elapse) {
+      p->timestamp += p->q[0].interval;
+      p->duration -= p->q[0].interval;
+      p->elapse -= p->q[0].interval;
+      memmove(&p->q[0], &p->q[1], sizeof(GainSeg) * (size_t)(p->qn - 1));
+      p->qn--;
+    }
+  }
 }
 
 /* ---- per-frame mix gains: iamf_database_parameter_get_mix_gain_unit, IAMF_decoder.c:857-982,
@@ -459,20 +499,26 @@ static void gain_quad(float s, float e, int d, float c, int ct, int o, int l, fl
   }
 }
 
-/* returns 0: constant gain in *constant; 1: per-sample gains written to g[0..duration) */
+/* returns 0: constant gain in *constant; 1: per-sample gains in g[0..duration); -1: the unit
+ * does not cover the frame, so iamf_frame_gain refuses it and NO gain is applied
+ * (IAMF_decoder.c:1386-1390) */
 static int mix_gain_unit(const Param *p, float default_gain, uint64_t pt, int duration, int rate, float *constant,
                          float *g) {
   uint64_t start = 0;
   float ratio = 1.f;
-  int count = 0, have_array = 0;
+  int count = 0, have_array = 0, use_default = 0;
   int64_t sgd = 0;
   int left = duration;
   *constant = default_gain;
-  if (!p || !p->have_block || pt < p->block_start) return 0;
-  start = pt - p->block_start;
+  if (!p) return 0;
+  if (pt < p->timestamp)
+    use_default = 1;
+  else
+    start = pt - p->timestamp;
+  if (p->use_default || use_default) return 0;
   if ((uint64_t)rate != p->def.rate) ratio = (rate + 0.1f) / p->def.rate;
-  for (int i = 0; i < p->nseg; ++i) {
-    const GainSeg *seg = &p->seg[i];
+  for (int i = 0; i < p->qn; ++i) {
+    const GainSeg *seg = &p->q[i];
     int64_t minterval = seg->interval * ratio;
     sgd += minterval;
     if ((int64_t)start < sgd) {
@@ -514,8 +560,8 @@ static int mix_gain_unit(const Param *p, float default_gain, uint64_t pt, int du
     }
     if (count == duration) break;
   }
-  if (!have_array) return 0;
-  for (int k = count; k < duration; ++k) g[k] = default_gain; /* not reached on well-formed streams */
+  (void)have_array;
+  if (count < duration) return -1;
   return 1;
 }
 
@@ -653,6 +699,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
       cfg.matrix.in_id = e0->layout;
       cfg.matrix.out_id = out_layout;
       iamf_hip_dmx_state_init(&d->dmx);
+      d->dmx_mode = -1;
       iamf_hip_dmx_set_mode_weight(&d->dmx, e0->demix_default_mode, e0->demix_default_w);
       for (int i = 0; i < d->nparam; ++i)
         if (d->param[i].id == e0->demix_pid) d->demix_p = &d->param[i];
@@ -852,7 +899,11 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     ramp[2] = mix_gain_unit(d->out_gain_p, og_def, pt, keep, (int)d->rate, &cgain[2], d->h_ramp[2]);
     if (d->sel->nel < 2) cgain[1] = 1.f;
     for (int i = 0; i < 3; ++i) {
-      if (!ramp[i]) /* a constant is applied through the ramp too: same product, one code path */
+      if (ramp[i] < 0) { /* unit refused: no gain at all */
+        ramp[i] = 0;
+        cgain[i] = 1.f;
+      }
+      if (!ramp[i]) /* element 1 takes its constant through the ramp: x * positive constant is the same product */
         for (int k = 0; k < keep; ++k) d->h_ramp[i][k] = cgain[i];
       if (hipMemcpyAsync(d->d_ramp[i], d->h_ramp[i], sizeof(float) * keep, hipMemcpyHostToDevice, d->stream) != hipSuccess)
         return IAMF_ERR_INTERNAL;
@@ -877,9 +928,7 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     iamf_hip_dmx_frame fr;
     fr.offset = 0;
     iamf_hip_dmx_coefficients(&d->dmx, fr.prev);
-    if (d->demix_p && d->demix_p->have_block && d->demix_p->block_start <= d->timestamp &&
-        d->timestamp < d->demix_p->block_start + d->demix_p->block_duration)
-      iamf_hip_dmx_set_mode_weight(&d->dmx, d->demix_p->dmx_mode, -1);
+    if (d->dmx_mode > -1) iamf_hip_dmx_set_mode_weight(&d->dmx, d->dmx_mode, -1);
     iamf_hip_dmx_coefficients(&d->dmx, fr.cur);
     if (hipMemcpyAsync(d->d_dmx, &fr, sizeof(fr), hipMemcpyHostToDevice, d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
     a.d_dmx_frames = d->d_dmx;
@@ -906,6 +955,7 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
   if (n > 0 && hipMemcpyAsync(pcm, d->d_pcm, (size_t)n * d->out_channels * bytes, hipMemcpyDeviceToHost, d->stream) != hipSuccess)
     return IAMF_ERR_INTERNAL;
   if (hipStreamSynchronize(d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
+  params_time_elapse(d, (uint64_t)keep); /* IAMF_decoder.c:3471: the mixed frame's length */
   d->timestamp += fs;
   d->last_frame = (uint32_t)n;
   return n;

@@ -50,6 +50,17 @@ CASES = {
     "toa_binaural_loudness": dict(layout=("binaural",), bit_depth=16, frames=6, fs=1024, seed=31,
                                   loudness=-16.0, mix_loudness_q78=-24 * 256),
     "l714_A_s16": dict(layout=_ss_layout("A"), bit_depth=16, frames=5, fs=1024, seed=41),
+    # parameter blocks: element mix gain (definition carries duration: one segment per block, step /
+    # linear / Bezier in turn) and output mix gain (blocks carry two half-frame segments)
+    "l714_J_ramps": dict(layout=_ss_layout("J"), bit_depth=16, frames=7, fs=1024, seed=51, ramps=True),
+    # demixing parameter blocks -> parametric down-mixer 7.1.4 -> 5.1.2 (Sound System C)
+    "l714_C_dmx": dict(layout=_ss_layout("C"), bit_depth=16, frames=8, fs=1024, seed=52,
+                       dmx_modes=[1, 1, 2, 4, 5, 6, 0, 0], dmx_default=(1, 3)),
+    # 44.1 kHz stream, 48 kHz output: speex-derived resampler in the path
+    "stereo_441_to_48k": dict(layout=_ss_layout("A"), bit_depth=16, frames=6, fs=1024, seed=53, rate=44100,
+                              out_rate=48000),
+    # frame trimming: 100 samples off the first frame, 300 off the last
+    "stereo_trim": dict(layout=_ss_layout("A"), bit_depth=16, frames=5, fs=1024, seed=54, trims={0: (100, 0), 4: (0, 300)}),
 }
 
 
@@ -87,16 +98,59 @@ def build(name):
     def frames_of(subs_fn):
         return subs_fn
 
-    if name in ("stereo_A_s16",):
+    if name in ("stereo_A_s16", "stereo_441_to_48k", "stereo_trim"):
         x = synth.uniform(c["seed"], 2, n, 0.9)
         desc, x_al, xq = _channel_element(1, 1, x, 0, ss)
         stream += desc
-        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100), default_q78=eg)],
-                                     dict(pdef=_pdef_static(101), default_q78=og), layouts_field)
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100, rate), default_q78=eg)],
+                                     dict(pdef=_pdef_static(101, rate), default_q78=og), layouts_field)
         info["elements"].append(dict(kind="channel", layout=1, x=xq))
         for f in range(F):
             stream += W.temporal_delimiter()
-            stream += W.audio_frames(W.channel_element_substreams(1, x_al[:, f * fs:(f + 1) * fs], 0, ss))
+            stream += W.audio_frames(W.channel_element_substreams(1, x_al[:, f * fs:(f + 1) * fs], 0, ss),
+                                     trim=c.get("trims", {}).get(f))
+    elif name == "l714_J_ramps":
+        x = np.clip(synth.hot(c["seed"], 12, n, sigma=0.2, burst_amp=0.6, burst_phase=500, burst_period=3000),
+                    -1, 1 - 2 ** -15).astype(np.float32)
+        desc, x_al, xq = _channel_element(1, 7, x, 0, ss)
+        stream += desc
+        el_def = W.param_definition(100, 48000, mode=0, duration=fs, constant_interval=fs)
+        out_def = W.param_definition(101, 48000, mode=1)
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=el_def, default_q78=-256)],
+                                     dict(pdef=out_def, default_q78=128), layouts_field)
+        info["elements"].append(dict(kind="channel", layout=7, x=xq))
+        el_blocks = [dict(anim=W.ANIM_STEP, start=-512), dict(anim=W.ANIM_LINEAR, start=-512, end=256),
+                     dict(anim=W.ANIM_BEZIER, start=256, end=-768, control=-128, rel_time=64),
+                     dict(anim=W.ANIM_LINEAR, start=-768, end=0), dict(anim=W.ANIM_STEP, start=0),
+                     dict(anim=W.ANIM_BEZIER, start=0, end=-300, control=200, rel_time=192),
+                     dict(anim=W.ANIM_STEP, start=-300)]
+        info["el_blocks"] = el_blocks
+        for f in range(F):
+            stream += W.temporal_delimiter()
+            stream += W.mix_gain_block(100, [el_blocks[f]])
+            if f >= 1:  # the first frame runs on the default output gain
+                stream += W.mix_gain_block(101, [dict(anim=W.ANIM_LINEAR, start=128 - 64 * f, end=128 - 64 * f - 32),
+                                                 dict(anim=W.ANIM_STEP, start=128 - 64 * f - 32)],
+                                           mode1=dict(duration=fs, constant_interval=0, intervals=[fs // 2, fs // 2]))
+            stream += W.audio_frames(W.channel_element_substreams(7, x_al[:, f * fs:(f + 1) * fs], 0, ss))
+    elif name == "l714_C_dmx":
+        x = np.clip(synth.hot(c["seed"], 12, n, sigma=0.2, burst_amp=0.6, burst_phase=500, burst_period=3000),
+                    -1, 1 - 2 ** -15).astype(np.float32)
+        xq = W.quantize(x, ss)
+        perm = al_index_of_playback(7)
+        x_al = np.empty_like(xq)
+        for p_, a_ in enumerate(perm):
+            x_al[a_] = xq[p_]
+        dm, dw = c["dmx_default"]
+        stream += W.audio_element_channel(1, 0, 7, list(range(7)),
+                                          demixing=dict(pid=200, rate=48000, frame=fs, mode=dm, w=dw))
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100), default_q78=eg)],
+                                     dict(pdef=_pdef_static(101), default_q78=og), layouts_field)
+        info["elements"].append(dict(kind="channel", layout=7, x=xq))
+        for f in range(F):
+            stream += W.temporal_delimiter()
+            stream += W.demixing_block(200, c["dmx_modes"][f])
+            stream += W.audio_frames(W.channel_element_substreams(7, x_al[:, f * fs:(f + 1) * fs], 0, ss))
     elif name in ("toa_binaural_s16", "toa_H_s16", "toa_binaural_loudness"):
         if name == "toa_H_s16":
             x = synth.gaussian(c["seed"], 16, n, 0.15)
