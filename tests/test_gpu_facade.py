@@ -51,3 +51,25 @@ def test_facade_api_surface(lib):
     cap = C.cast(lib.IAMF_decoder_get_codec_capability(), C.c_char_p).value
     assert b"ipcm" in cap
     lib.IAMF_decoder_close(d)
+
+
+def test_player_cli_writes_the_reference_wav_payload(golden, tmp_path):
+    """BASELINE configs[0] end to end: `iamfplayer -o2 -s0 stereo.iamf` -> WAV, here with the player
+    built on libiamf_hip.so; the PCM payload must equal what the reference decoder produced."""
+    import os
+    import subprocess
+
+    import iac_amd
+    exe = os.path.join(os.path.dirname(iac_amd.lib_path()), "iamfplayer_hip")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    stream, _ = e2e_cases.build("stereo_A_s16")
+    src = tmp_path / "stereo.iamf"
+    src.write_bytes(stream)
+    out = tmp_path / "ss0_stereo.wav"
+    r = subprocess.run([exe, "-o2", "-s0", "-out", str(out), str(src)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "Get 21 frames" in r.stdout  # 20 frames + the flushed tail, like the reference player
+    raw = out.read_bytes()
+    assert raw[:4] == b"RIFF" and raw[8:16] == b"WAVEfmt "
+    pcm = np.frombuffer(raw[44:], dtype=np.int16).reshape(-1, 2)
+    assert np.array_equal(pcm, golden.npz("e2e")["stereo_A_s16"])
