@@ -8,8 +8,8 @@ buildable `-sb` path: the 16->2 static matrix) -> peak limiter (-1 dBFS) -> inte
 A "step" is one pass of that path over one batch of `--frames` frames per stream; the element
 PCM is synthetic ("hot" programme, tests/synth.py recipe) and resident in HBM before the timed
 region starts.  One process per GPU; streams shard over ranks with no collective in the render
-path; the packed PCM of every step is gathered to rank 0 over RCCL, overlapped with the next
-step (the one exchange the job has).
+path; the job's one exchange is the gather of the packed PCM to rank 0 over RCCL after the last
+step (--gather step gathers every step instead, overlapped with the next render).
 
 Prints ONE JSON line on rank 0.  value = sample-frames rendered by all ranks / wall time.
 """
@@ -117,7 +117,9 @@ def main():
     ap.add_argument("--frame-size", type=int, default=1024)
     ap.add_argument("--workload", default="toa_binaural_limiter_s16", choices=sorted(WORKLOADS))
     ap.add_argument("--signal", default="hot", choices=["hot", "quiet"])
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of the PCM")
+    ap.add_argument("--gather", default="final", choices=["final", "step", "none"],
+                    help="N>1: gather packed PCM to rank 0 over RCCL once after the last step (default, the "
+                         "job's one exchange), after every step (overlapped with the next render), or never")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -152,9 +154,12 @@ def main():
                     fir_taps=FIR_TAPS if kind == "fir" else 0)
     stride_bytes = F * fs * out_ch * 2
     pcm = [torch.zeros((S, stride_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
-    gather_on = world > 1 and not args.no_gather
+    gather_on = world > 1 and args.gather != "none"
     from iac_amd.sharding import GatherPipeline
-    pipe = GatherPipeline(pcm, world, rank, enabled=gather_on)
+    pipe = GatherPipeline(pcm, world, rank, enabled=world > 1 and args.gather == "step")
+    final_recv = None
+    if world > 1 and args.gather == "final" and rank == 0:
+        final_recv = [torch.empty_like(pcm[0]) for _ in range(world)]
     stream = torch.cuda.current_stream().cuda_stream
     stream_stride, frame_stride = F * in_ch * fs, in_ch * fs
 
@@ -181,6 +186,9 @@ def main():
     for i in range(args.steps):
         emitted += pipe.step(lambda buf, i=i: render_into(buf, ev[i]))
     pipe.drain()
+    if world > 1 and args.gather == "final":
+        # the job's one exchange: every rank's packed PCM of the last step -> rank 0 (RCCL over xGMI)
+        dist.gather(pcm[(args.steps - 1) % 2], final_recv, dst=0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -217,7 +225,7 @@ def main():
                        "frame_size": fs, "sample_rate": 48000, "in_channels": in_ch,
                        "out_channels": out_ch, "pcm": "s16", "limiter": "-1 dBFS, 240 look-ahead",
                        "signal": "hot (sigma 0.25 + 1.5 bursts)" if args.signal == "hot" else "quiet (sigma 0.05)", "parallelism": "streams sharded, dp%d" % world,
-                       "gather": bool(gather_on)},
+                       "gather": args.gather if world > 1 else "n/a (1 GPU)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": round(traffic[0]) if traffic else None,
