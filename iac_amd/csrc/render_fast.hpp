@@ -121,8 +121,10 @@ __device__ __forceinline__ void limiter_wave(const float *arr_p, float *arr_g,
 // LDS floats the fast kernel needs for an OC-channel layout, M inputs and a limiter table of
 // `tab` entries (host and device use the same carve-up)
 __host__ __device__ constexpr int fast_lds_floats(int oc, int m, int tab, bool fir = false) {
-  return oc * kFRing + 2 * kFRing + kFRing / 16 + 3 * kFChunk + ((tab + 15) & ~15) + ((oc * m + 15) & ~15) + 16 +
-         (fir ? kFirLdsFloats : 0);
+  // the HRTF variant keeps the limiter table in global memory (it has no input prefetch that an
+  // in-loop load could drain) so that two workgroups fit a CU and share its matrix cores
+  return oc * kFRing + 2 * kFRing + kFRing / 16 + 3 * kFChunk + (fir ? 0 : ((tab + 15) & ~15)) +
+         ((oc * m + 15) & ~15) + 16 + (fir ? kFirLdsFloats : 0);
 }
 
 __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
@@ -144,8 +146,9 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
   float *arr_p = ring_bm + NB;          // [1024]    window maxima of the chunk
   float *arr_e = arr_p + kFChunk;       // [1024]    thr / window maximum
   float *arr_g = arr_e + kFChunk;       // [1024]    gains from the limiter wave
-  float *ctl = arr_g + kFChunk;         // [tab]     limiter curve table
-  float *mat = ctl + tab;               // [OC*M]    feed-major matrix rows of the OC slots
+  float *ctl_lds = arr_g + kFChunk;     // [tab]     limiter curve table (not in the HRTF variant)
+  float *mat = ctl_lds + (FIR ? 0 : tab);  // [OC*M]  feed-major matrix rows of the OC slots
+  const float *ctl = FIR ? p.ctab : ctl_lds;
   float *misc = mat + ((OC * M + 15) & ~15);  // [16]
   float *fir = misc + 16;               // [kFirLdsFloats]  HRTF staging (FIR variant only)
 
@@ -176,7 +179,8 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     // leaves the running maximum unchanged
     ring_suf[rp] = sfx;
     if ((t & 15) == 0) ring_bm[rp >> 4] = sfx;
-    for (int i = t; i <= n_end; i += 256) ctl[i] = p.ctab[i];
+    if constexpr (!FIR)
+      for (int i = t; i <= n_end; i += 256) ctl_lds[i] = p.ctab[i];
     if (!FIR && t < OC * M) {
       const int c = t / M, m = t - c * M;
       const int f = p.src_feed[c];
@@ -190,6 +194,8 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
   const bool eg_on = (eg != 1.f && eg > 0.f);
   const bool og_on = (og != 1.f && og > 0.f);
   const bool lg_on = p.loudness_on && (lg != 1.0f);
+  const float m_eg = eg_on ? eg : 1.f, m_og = og_on ? og : 1.f, m_lg = lg_on ? lg : 1.f;
+  const bool any_gain = eg_on || og_on || lg_on;
   bool live[OC];
 #pragma unroll
   for (int c = 0; c < OC; ++c) live[c] = FIR || p.src_feed[c] >= 0;
@@ -250,10 +256,13 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
         }
         v = acc;
       }
-      if (eg_on) { v.x = v.x * eg; v.y = v.y * eg; v.z = v.z * eg; v.w = v.w * eg; }
-      v.x = 0.f + v.x; v.y = 0.f + v.y; v.z = 0.f + v.z; v.w = 0.f + v.w;  // mixer: 0 += frame
-      if (og_on) { v.x = v.x * og; v.y = v.y * og; v.z = v.z * og; v.w = v.w * og; }
-      if (lg_on) { v.x = v.x * lg; v.y = v.y * lg; v.z = v.z * lg; v.w = v.w * lg; }
+      if (any_gain) {  // a skipped gain is a multiplication by exactly 1; the mixer's 0 + y only
+                       // turns -0 into +0, which no output format can tell apart
+        v.x = ((v.x * m_eg) * m_og) * m_lg;
+        v.y = ((v.y * m_eg) * m_og) * m_lg;
+        v.z = ((v.z * m_eg) * m_og) * m_lg;
+        v.w = ((v.w * m_eg) * m_og) * m_lg;
+      }
       y[c] = v;
       pm.x = fmaxf(pm.x, fabsf(v.x));
       pm.y = fmaxf(pm.y, fabsf(v.y));

@@ -12,17 +12,20 @@
 // That is a GEMM  D[(e,i)][T] = A[(e,i)][(c,m)] * B[(c,m)][T]  with a Toeplitz A (only h itself is
 // stored: the A operand of lane (i, kk) at step s is hp[2s + kk + i]) and B a stride-32 view of
 // the input (B operand of lane (T, kk) at step s is x[c0 + 32T + 31 - 2s - kk]).  One chunk of
-// 1024 samples is exactly one 32-column tile; 89 % of the issued MACs are useful ((L)/(L+31)).
+// 1024 samples is exactly one 32-column tile; 89 % of the issued MACs are useful (L / (L+31)).
 // Wave w owns ear (w & 1) and half of the channels (w >> 1); the two halves are added at the end.
-// Per channel the input slice (1280 samples incl. 256 of history) and both ears' filters are
-// staged in LDS (register double-buffered global loads, one barrier per channel); the slice is
-// padded by one float per 32 so the stride-32 B reads are bank-conflict free.
+// Per channel the input slice (1280 samples incl. 256 of history, behind 32 zeros that absorb the
+// steps of the padded tail) and both ears' filters are staged in LDS (register double-buffered
+// global loads, one barrier per channel).  The slice is padded by one float per 32, which makes
+// the stride-32 B reads bank-conflict free AND keeps every operand address of a step equal to a
+// per-lane base plus a wave-uniform offset, so the inner loop is two ds_read_b32 + one MFMA.
 #pragma once
 
-constexpr int kFirChunk = 1024;          // = kFChunk of render_fast.hpp
-constexpr int kFirHist = 256;            // history kept per channel = maximum taps
-constexpr int kFirXs = 1280 + 1280 / 32; // padded input slice
-constexpr int kFirHp = 320;              // padded filter: hp[j] = h[j - 31]
+constexpr int kFirChunk = 1024;  // = kFChunk of render_fast.hpp
+constexpr int kFirHist = 256;    // history kept per channel = maximum taps
+constexpr int kFirLead = 32;     // zeros in front of the slice
+constexpr int kFirXs = 1360;     // padded slice: (32 + 1280) * 33 / 32, rounded up
+constexpr int kFirHp = 336;      // padded filter: hp[j] = h[j - 31], zeros elsewhere
 constexpr int kFirLdsFloats = 2 * 2 * kFirXs + 2 * 2 * 2 * kFirHp;  // [half][buf] xs + [half][buf][ear] hp
 
 // sample n (relative to the start of this call) of channel ch of stream s; history for n < 0
@@ -43,41 +46,45 @@ __device__ __forceinline__ void fir_stage(const RenderParams &p, const float *in
                                           float *fir, float *part) {
   using f32x16 = __attribute__((ext_vector_type(16))) float;
   constexpr int MH = (M + 1) / 2;  // channel iterations (half 0 takes the extra one when M is odd)
+  constexpr int U = 8;             // MFMA steps per unrolled block
   const int t = threadIdx.x;
   const int w = t >> 6, lane = t & 63;
   const int ear = w & 1, half = w >> 1;
   const int th = t & 127;  // thread index inside the half
   const int L = p.fir_taps;
   const int KS = (L + 32) >> 1;
+  const int KSP = (KS + U - 1) & ~(U - 1);  // the padded steps multiply zeros of hp
   const int col = lane & 31, kk = lane >> 5;
   const int my_n = half == 0 ? MH : M / 2;  // channels this half multiplies
   const int ch0 = half == 0 ? 0 : MH;
-  float *xs = fir;                       // [half][buf][kFirXs]
-  float *hp = fir + 2 * 2 * kFirXs;      // [half][buf][ear][kFirHp]
+  float *xs = fir;                   // [half][buf][kFirXs]
+  float *hp = fir + 2 * 2 * kFirXs;  // [half][buf][ear][kFirHp]
 
-  float xr[10], hr[5];
+  float xr[10], hr[6];
   auto fetch = [&](int ci) {  // global -> registers for channel ci of this half
     const int ch = ch0 + (ci < my_n ? ci : 0);
 #pragma unroll
     for (int r = 0; r < 10; ++r) xr[r] = fir_input(p, in_s, hist, ch, c0 - kFirHist + th + 128 * r);
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      const int j = th + 128 * r;          // 0..639 = [ear][kFirHp]
+    for (int r = 0; r < 6; ++r) {
+      const int j = th + 128 * r;  // 0..767 >= 2 * kFirHp = [ear][kFirHp]
       const int e2 = j >= kFirHp ? 1 : 0;
       const int tap = j - e2 * kFirHp - 31;
-      hr[r] = (tap >= 0 && tap < L) ? p.matrix[((int64_t)e2 * M + ch) * L + tap] : 0.f;
+      hr[r] = (j < 2 * kFirHp && tap >= 0 && tap < L) ? p.matrix[((int64_t)e2 * M + ch) * L + tap] : 0.f;
     }
   };
   auto stash = [&](int buf) {  // registers -> LDS
     float *xb = xs + (half * 2 + buf) * kFirXs;
     float *hb = hp + (half * 2 + buf) * 2 * kFirHp;
+    if (th < kFirLead) xb[th] = 0.f;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-      const int q = th + 128 * r;
+      const int q = kFirLead + th + 128 * r;
       xb[q + (q >> 5)] = xr[r];
     }
 #pragma unroll
-    for (int r = 0; r < 5; ++r) hb[th + 128 * r] = hr[r];
+    for (int r = 0; r < 6; ++r)
+      if (th + 128 * r < 2 * kFirHp) hb[th + 128 * r] = hr[r];
   };
 
   f32x16 acc;
@@ -89,18 +96,21 @@ __device__ __forceinline__ void fir_stage(const RenderParams &p, const float *in
   for (int ci = 0; ci < MH; ++ci) {
     const int buf = ci & 1;
     if (ci + 1 < MH) fetch(ci + 1);
-    const float *xb = xs + (half * 2 + buf) * kFirXs;
-    const float *hb = hp + ((half * 2 + buf) * 2 + ear) * kFirHp;
-    int ai = kk + col;                  // hp index of step 0
-    int q = 32 * col + 287 - kk;        // input-slice index of step 0
     if (ci < my_n) {
-#pragma unroll 4
-      for (int s = 0; s < KS; ++s) {
-        const float a = hb[ai];
-        const float b = xb[q + (q >> 5)];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        ai += 2;
-        q -= 2;
+      // step s: A operand hp[2s + kk + col]; B operand = slice sample 32*col + 319 - kk - 2s, whose
+      // padded position is (33*col - kk) + o + (o >> 5) with the wave-uniform o = 319 - 2s
+      const float *ha = hp + ((half * 2 + buf) * 2 + ear) * kFirHp + (kk + col);
+      const float *xl = xs + (half * 2 + buf) * kFirXs + (33 * col - kk);
+      for (int s0 = 0; s0 < KSP; s0 += U) {
+        float a[U], b[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          const int o = 319 - 2 * (s0 + j);
+          a[j] = ha[2 * (s0 + j)];
+          b[j] = xl[o + (o >> 5)];
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
       }
     }
     if (ci + 1 < MH) stash(buf ^ 1);

@@ -110,6 +110,10 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
   const bool eg_on = (eg != 1.f && eg > 0.f);
   const bool og_on = (og != 1.f && og > 0.f);
   const bool lg_on = p.loudness_on && (lg != 1.0f);
+  // a gain the reference would skip is a multiplication by exactly 1 (x * 1.0f == x); the
+  // reference's  0 + y  of the mixer only turns -0 into +0, which no output format can tell apart
+  const float m_eg = eg_on ? eg : 1.f, m_og = og_on ? og : 1.f, m_lg = lg_on ? lg : 1.f;
+  const bool any_gain = eg_on || og_on || lg_on;
 
   const int64_t out_base = p.pos0 > kDelay ? p.pos0 - kDelay : 0;
   const int bytes = p.out_format == IAMF_HIP_FMT_S16 ? 2 : (p.out_format == IAMF_HIP_FMT_S24 ? 3 : 4);
@@ -184,29 +188,28 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
         // lane l: column = sample 32*tt + (l & 31); register r: slot (r&3) + 8*(r>>2) + 4*(l>>5)
         const int ksmp = 64 * wave + 32 * tt + (lane & 31);
         const int pos = (int)((p.pos0 + c0 + ksmp) & (kWPos - 1));
+        if (any_gain) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = ((acc[r] * m_eg) * m_og) * m_lg;
+        }
         float pmv = 0.f;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int slot0 = 8 * gq + 4 * (lane >> 5);
-          float y[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float v = acc[4 * gq + i];
-            if (eg_on) v = v * eg;
-            v = 0.f + v;  // mixer: 0 += frame
-            if (og_on) v = v * og;
-            if (lg_on) v = v * lg;
-            y[i] = v;
-            if (slot0 + i < C) pmv = fmaxf(pmv, fabsf(v));
-          }
-          if (ksmp < cnt) {
-            if ((C & 3) == 0) {
-              if (slot0 < C) *reinterpret_cast<float4 *>(&ring[pos * C + slot0]) = make_float4(y[0], y[1], y[2], y[3]);
-            } else {
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-                if (slot0 + i < C) ring[pos * C + slot0 + i] = y[i];
+          const float y0 = acc[4 * gq], y1 = acc[4 * gq + 1], y2 = acc[4 * gq + 2], y3 = acc[4 * gq + 3];
+          if ((C & 3) == 0) {
+            if (slot0 < C) {
+              pmv = fmaxf(fmaxf(pmv, fabsf(y0)), fmaxf(fabsf(y1), fmaxf(fabsf(y2), fabsf(y3))));
+              if (ksmp < cnt) *reinterpret_cast<float4 *>(&ring[pos * C + slot0]) = make_float4(y0, y1, y2, y3);
             }
+          } else {
+            const float y[4] = {y0, y1, y2, y3};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (slot0 + i < C) {
+                pmv = fmaxf(pmv, fabsf(y[i]));
+                if (ksmp < cnt) ring[pos * C + slot0 + i] = y[i];
+              }
           }
         }
         pmt[tt] = fmaxf(pmv, __shfl_xor(pmv, 32));  // the sample's other 12 slots live in lane ^ 32
@@ -224,16 +227,13 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
           a3 = a3 + w.w * x[m];
         }
         float y[4] = {a0, a1, a2, a3};
+        if (any_gain) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = y[i];
-          if (eg_on) v = v * eg;
-          v = 0.f + v;  // mixer: 0 += frame
-          if (og_on) v = v * og;
-          if (lg_on) v = v * lg;
-          y[i] = v;
-          if (cb + i < C) pm = fmaxf(pm, fabsf(v));
+          for (int i = 0; i < 4; ++i) y[i] = ((y[i] * m_eg) * m_og) * m_lg;
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (cb + i < C) pm = fmaxf(pm, fabsf(y[i]));
         if (valid) {
           if ((C & 3) == 0) {
             *reinterpret_cast<float4 *>(&ring[rp * C + cb]) = make_float4(y[0], y[1], y[2], y[3]);
@@ -339,16 +339,24 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
         const float4 v1 = *reinterpret_cast<const float4 *>(&ring[rf + 4]);
         const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         int o[8];
-        float gq = arr_g[srel];
+        // rint then saturate == the reference's clamp then lrintf (the bounds are integers)
+        if (C >= 8) {  // a piece of 8 spans at most two sample-frames
+          const float g0 = arr_g[srel];
+          const float g1 = arr_g[srel + 1 < kWChunk ? srel + 1 : kWChunk - 1];
+          const int cross = C - r;  // elements of the piece that belong to the first sample-frame
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          // rint then saturate == the reference's clamp then lrintf (the bounds are integers)
-          o[i] = (int)rintf(vv[i] * gq);
-          ++r;
-          if (r == C) {  // next sample-frame: next gain
-            r = 0;
-            ++srel;
-            gq = arr_g[srel < kWChunk ? srel : kWChunk - 1];
+          for (int i = 0; i < 8; ++i) o[i] = (int)rintf(vv[i] * (i < cross ? g0 : g1));
+        } else {
+          float gq = arr_g[srel];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            o[i] = (int)rintf(vv[i] * gq);
+            ++r;
+            if (r == C) {  // next sample-frame: next gain
+              r = 0;
+              ++srel;
+              gq = arr_g[srel < kWChunk ? srel : kWChunk - 1];
+            }
           }
         }
         uint4 w;

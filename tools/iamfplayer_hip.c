@@ -42,7 +42,8 @@ int main(int argc, char **argv) {
   const char *in = 0, *out = 0;
   char name[512];
   for (int i = 1; i < argc; ++i) {
-    if (!strncmp(argv[i], "-o", 2)) continue;
+    if (!strcmp(argv[i], "-out") && i + 1 < argc) out = argv[++i];
+    else if (!strncmp(argv[i], "-o", 2)) continue; /* -o2: raw IAMF bitstream, the only input mode */
     else if (!strcmp(argv[i], "-sb")) binaural = 1;
     else if (!strncmp(argv[i], "-s", 2)) ss = atoi(argv[i] + 2);
     else if (!strcmp(argv[i], "-disable_limiter")) limiter = 0;
@@ -50,7 +51,6 @@ int main(int argc, char **argv) {
     else if (!strncmp(argv[i], "-r", 2)) rate = atoi(argv[i] + 2);
     else if (!strncmp(argv[i], "-p", 2)) peak = (float)atof(argv[i] + 2);
     else if (!strncmp(argv[i], "-l", 2)) loud = (float)atof(argv[i] + 2);
-    else if (!strcmp(argv[i], "-out") && i + 1 < argc) out = argv[++i];
     else in = argv[i];
   }
   if (!in) {
