@@ -139,6 +139,8 @@ typedef struct {
   int layout, nb_coupled;              /* channel-based */
   int amb_channels;
   uint8_t amb_map[MAX_SUBSTREAMS];     /* scene-based, mono mapping */
+  int amb_projection, amb_coupled;     /* scene-based, projection mode */
+  float proj[MAX_SUBSTREAMS * 2 * 16]; /* [decoded channel][ambisonics channel] */
   int has_demix;
   uint64_t demix_pid;
   int demix_default_mode, demix_default_w;
@@ -321,11 +323,24 @@ static int parse_element(struct IAMF_Decoder *d, const Obu *o) { /* IAMF_OBU.c:3
     e.channels = k_layout_channels[e.layout];
     if (e.nsub + e.nb_coupled != e.channels) return IAMF_ERR_INVALID_PACKET;
   } else if (e.type == AUDIO_ELEMENT_SCENE_BASED) {
-    if (rd_leb128(&r) != AMBISONICS_MONO) return IAMF_ERR_UNIMPLEMENTED;
-    e.amb_channels = rd_u8(&r);
-    rd_u8(&r);
-    if (e.amb_channels > MAX_SUBSTREAMS) return IAMF_ERR_INVALID_PACKET;
-    for (int i = 0; i < e.amb_channels; ++i) e.amb_map[i] = rd_u8(&r);
+    uint64_t mode = rd_leb128(&r);
+    if (mode == AMBISONICS_MONO) {
+      e.amb_channels = rd_u8(&r);
+      rd_u8(&r);
+      if (e.amb_channels > MAX_SUBSTREAMS) return IAMF_ERR_INVALID_PACKET;
+      for (int i = 0; i < e.amb_channels; ++i) e.amb_map[i] = rd_u8(&r);
+    } else if (mode == AMBISONICS_PROJECTION) { /* IAMF_OBU.c:562-583, IAMF_core_decoder.c:228-252 */
+      int subs, l_in;
+      e.amb_projection = 1;
+      e.amb_channels = rd_u8(&r);
+      subs = rd_u8(&r);
+      e.amb_coupled = rd_u8(&r);
+      l_in = subs + e.amb_coupled;
+      if (e.amb_channels > 16 || l_in > MAX_SUBSTREAMS * 2 || subs != e.nsub) return IAMF_ERR_INVALID_PACKET;
+      for (int i = 0; i < l_in * e.amb_channels; ++i) e.proj[i] = q_to_float((int16_t)rd_u16(&r), 15);
+    } else {
+      return IAMF_ERR_UNIMPLEMENTED;
+    }
     e.channels = e.amb_channels;
     if (e.channels != 1 && e.channels != 4 && e.channels != 9 && e.channels != 16) return IAMF_ERR_UNIMPLEMENTED;
   } else {
@@ -633,6 +648,11 @@ static int element_matrix(const struct IAMF_Decoder *d, const Element *e, iamf_h
   return iamf_hip_get_m2m_matrix(e->channels == 1 ? IAMF_HIP_L_MONO : k_layer_rid[e->layout], out_id, mx);
 }
 
+/* channels per frame handed to the device: decoded channels for projection-mode ambisonics */
+static int element_in_channels(const Element *e) {
+  return e->amb_projection ? e->nsub + e->amb_coupled : e->channels;
+}
+
 static Element *find_element(struct IAMF_Decoder *d, uint64_t id) {
   for (int i = 0; i < d->nel; ++i)
     if (d->el[i].id == id) return &d->el[i];
@@ -718,6 +738,10 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   }
   if (!iamf_hip_format_bytes(cfg.out_format)) return IAMF_ERR_BAD_ARG; /* bit depth never set: IAMF_decoder.c:3726 */
   if (iamf_hip_batch_create(&cfg, &d->batch)) return IAMF_ERR_INTERNAL;
+  if (d->sel_el[0]->amb_projection &&
+      iamf_hip_batch_set_projection(d->batch, d->sel_el[0]->proj, element_in_channels(d->sel_el[0])))
+    return IAMF_ERR_INTERNAL;
+  if (p->nel == 2 && d->sel_el[1]->amb_projection) return IAMF_ERR_UNIMPLEMENTED;
   if (p->nel == 2) {
     iamf_hip_matrix m2;
     float one = 1.f;
@@ -756,7 +780,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   d->tmp = (float *)malloc(sizeof(float) * MAX_SUBSTREAMS * 2 * d->frame_size);
   if (!d->tmp) return IAMF_ERR_ALLOC_FAIL;
   for (int e = 0; e < p->nel; ++e) {
-    size_t bytes = sizeof(float) * d->sel_el[e]->channels * d->frame_size;
+    size_t bytes = sizeof(float) * (size_t)element_in_channels(d->sel_el[e]) * d->frame_size;
     if (hipHostMalloc((void **)&d->h_in[e], bytes, 0) != hipSuccess || hipMalloc((void **)&d->d_in[e], bytes) != hipSuccess)
       return IAMF_ERR_ALLOC_FAIL;
   }
@@ -835,13 +859,18 @@ static int unpack_element(struct IAMF_Decoder *d, int ei) {
   /* audio-layer order: coupled pairs first, then singles */
   int c = 0;
   for (int s = 0; s < e->nsub; ++s) {
-    const int w = (e->type == AUDIO_ELEMENT_CHANNEL_BASED && s < e->nb_coupled) ? 2 : 1;
+    const int w = ((e->type == AUDIO_ELEMENT_CHANNEL_BASED && s < e->nb_coupled) ||
+                   (e->amb_projection && s < e->amb_coupled)) ? 2 : 1;
     const int n = (int)(d->pkt_len[ei][s] / (uint32_t)(w * bps));
     if (ns < 0) ns = n;
     if (n != ns || n > fs) return IAMF_ERR_INVALID_PACKET;
     for (int i = 0; i < n; ++i)
       for (int k = 0; k < w; ++k) tmp[(size_t)(c + k) * fs + i] = lpcm_sample(d, d->pkt[ei][s] + (size_t)(i * w + k) * bps);
     c += w;
+  }
+  if (e->amb_projection) { /* decoded channel order goes to the device: the de-mapping runs there */
+    for (int l = 0; l < c; ++l) memcpy(dst + (size_t)l * fs, tmp + (size_t)l * fs, sizeof(float) * ns);
+    return ns;
   }
   for (int p = 0; p < e->channels; ++p) {
     int src = e->type == AUDIO_ELEMENT_CHANNEL_BASED ? k_al_of_pl[e->layout][p] : e->amb_map[p];
@@ -883,7 +912,7 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     return 0;
   }
   for (int e = 0; e < d->sel->nel; ++e) {
-    const int ch = d->sel_el[e]->channels;
+    const int ch = element_in_channels(d->sel_el[e]);
     if (s0)
       for (int c = 0; c < ch; ++c) memmove(d->h_in[e] + (size_t)c * fs, d->h_in[e] + (size_t)c * fs + s0, sizeof(float) * keep);
     if (hipMemcpyAsync(d->d_in[e], d->h_in[e], sizeof(float) * ch * fs, hipMemcpyHostToDevice, d->stream) != hipSuccess)
@@ -910,7 +939,7 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     }
   }
   a.d_in = d->d_in[0];
-  a.in_stream_stride = a.in_frame_stride = (int64_t)d->sel_el[0]->channels * fs;
+  a.in_stream_stride = a.in_frame_stride = (int64_t)element_in_channels(d->sel_el[0]) * fs;
   if (d->sel->nel > 1) {
     a.d_in2 = d->d_in[1];
     a.in2_stream_stride = a.in2_frame_stride = (int64_t)d->sel_el[1]->channels * fs;

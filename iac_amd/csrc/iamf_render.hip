@@ -129,6 +129,8 @@ struct iamf_hip_batch {
   int32_t *d_src_feed2 = nullptr, *d_dmx_tab = nullptr;
   bool dmx = false;
   int dmx_n_in = 0, dmx_n_out = 0;
+  float *d_pre = nullptr;
+  int pre_l = 0;
   bool fir = false;
   int fir_taps = 0;
   float *d_fir_hist[2] = {nullptr, nullptr};
@@ -217,7 +219,7 @@ void launch_wide_m(const RenderParams &p, dim3 grid, hipStream_t st) {
 bool fast_path_ok(const RenderParams &p) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
   if (!p.limiter_on || !p.in || p.out_ch > 2 || p.n_end + 1 > kFTabMax) return false;
-  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp) return false;
+  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix) return false;
   if ((p.pos0 & 15) || (p.total & 63) || (p.frame_size & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
@@ -228,7 +230,7 @@ bool fast_path_ok(const RenderParams &p) {
 bool wide_path_ok(const RenderParams &p, int m) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
   if (!p.limiter_on || !p.in || p.out_ch <= 2 || p.out_ch > kMaxOut || p.n_end < kWWin) return false;
-  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp) return false;
+  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix) return false;
   if ((p.pos0 & 15) || (p.total & 63)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
   return sizeof(float) * (size_t)wide_lds_floats(p.out_ch, m) <= 80 * 1024;
@@ -339,6 +341,10 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     p.dmx_n_in = b->dmx_n_in;
     p.dmx_n_out = b->dmx_n_out;
     p.dmx_tab = b->d_dmx_tab;
+  }
+  if (b->d_pre && a.d_in) {
+    p.pre_matrix = b->d_pre;
+    p.pre_l = b->pre_l;
   }
   if (b->fir) {
     p.fir_taps = b->fir_taps;
@@ -536,6 +542,7 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_ring_pm);
   (void)hipFree(b->d_src_feed);
   (void)hipFree(b->d_dmx_tab);
+  (void)hipFree(b->d_pre);
   (void)hipFree(b->d_fir_hist[0]);
   (void)hipFree(b->d_fir_hist[1]);
   (void)hipFree(b->d_matrix2);
@@ -628,6 +635,16 @@ int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *
   HIPCHK(hipMemcpy(b->d_src_feed2, feed, sizeof(feed), hipMemcpyHostToDevice));
   b->m2 = mx->m;
   b->has2 = true;
+  return IAMF_HIP_OK;
+}
+
+int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *matrix, int l_in) {
+  if (!b || !matrix || l_in <= 0 || l_in > kMaxIn || b->pos != 0 || b->dmx || b->fir) return IAMF_HIP_ERR_BAD_ARG;
+  (void)hipFree(b->d_pre);
+  b->d_pre = nullptr;
+  HIPCHK(hipMalloc(&b->d_pre, sizeof(float) * (size_t)l_in * b->m));
+  HIPCHK(hipMemcpy(b->d_pre, matrix, sizeof(float) * (size_t)l_in * b->m, hipMemcpyHostToDevice));
+  b->pre_l = l_in;
   return IAMF_HIP_OK;
 }
 

@@ -55,6 +55,9 @@ struct RenderParams {
   const iamf_hip_dmx_frame *dmx_frames;  // device [n_streams][frames of this call]
   int32_t dmx_n_in, dmx_n_out;
   const int32_t *dmx_tab;   // device [24]: IAChannel ids of the inputs, then (from [12]) of the outputs
+  // ---- ambisonics projection de-mapping in front of element 0 (generic kernel) ----
+  const float *pre_matrix;  // device [pre_l][M] or nullptr
+  int32_t pre_l;            // decoded channels per frame when pre_matrix is set
   // ---- HRTF FIR renderer (render_fast_kernel<M, 2, true>): matrix = h[2][M][fir_taps] ----
   int32_t fir_taps;
   const float *fir_hist;    // device [n_streams][M][256] input history before this call

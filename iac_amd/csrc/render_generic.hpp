@@ -71,7 +71,20 @@ __global__ __launch_bounds__(kChunk) void render_kernel(const RenderParams p) {
 
     // ---- load one sample of every input channel (coalesced: lane = sample) ----
     float x[M];
-    if (valid && p.in) {
+    if (valid && p.in && p.pre_matrix) {
+      // projection de-mapping (IAMF_core_decoder.c:116-130): x[r] = 0; x[r] += in[l] * P[l][r]
+      const int f = k / fs;
+      const int i = k - f * fs;
+      const float *src = p.in + (int64_t)s * p.in_stream_stride + (int64_t)f * p.in_frame_stride + i;
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = 0.f;
+      for (int l = 0; l < p.pre_l; ++l) {
+        const float v = src[(int64_t)l * fs];
+        const float *row = p.pre_matrix + l * M;
+#pragma unroll
+        for (int m = 0; m < M; ++m) x[m] = x[m] + v * row[m];
+      }
+    } else if (valid && p.in) {
       const int f = k / fs;
       const int i = k - f * fs;
       const float *src = p.in + (int64_t)s * p.in_stream_stride + (int64_t)f * p.in_frame_stride + i;

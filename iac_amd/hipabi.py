@@ -105,6 +105,7 @@ def lib():
         L.iamf_hip_resampler_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                                  C.c_void_p]
         L.iamf_hip_resampler_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.iamf_hip_batch_set_projection.argtypes = [C.c_void_p, FP, C.c_int]
         L.iamf_hip_dmx_valid.argtypes = [C.c_int, C.c_int]
         L.iamf_hip_dmx_layout_channels.argtypes = [C.c_int]
         L.iamf_hip_dmx_state_init.argtypes = [C.POINTER(DmxState)]
@@ -211,6 +212,13 @@ class Batch:
         r = lib().iamf_hip_batch_set_second_element(self.h, C.byref(matrix), _fparr(gains))
         if r != 0:
             raise IamfHipError(r, "iamf_hip_batch_set_second_element")
+
+    def set_projection(self, matrix):
+        """matrix: float32 [decoded channels][ambisonics channels] (IAMF_core_decoder.c:116-130)"""
+        rows = [list(r) for r in matrix]
+        r = lib().iamf_hip_batch_set_projection(self.h, _fparr([v for row in rows for v in row]), len(rows))
+        if r != 0:
+            raise IamfHipError(r, "iamf_hip_batch_set_projection")
 
     def flush(self, d_pcm, pcm_stream_stride_bytes, stream=None):
         r = lib().iamf_hip_batch_flush(self.h, d_pcm, pcm_stream_stride_bytes, stream)

@@ -175,6 +175,13 @@ void iamf_hip_dmx_coefficients(const iamf_hip_dmx_state *st, float out[5]);
 int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *mx,
                                       const float *element2_gain);
 
+/* Ambisonics projection de-mapping in front of element 0's renderer (projection-mode scene-based
+ * elements): x[r] = sum over the l_in decoded channels l, ascending, of in[l] * matrix[l*m + r]
+ * (iamf_core_decoder_convert_projection, src/iamf_dec/IAMF_core_decoder.c:116-130).  `matrix` is a
+ * host array of l_in * m floats (the Q15 demixing matrix of the bitstream as floats); afterwards
+ * element 0's input carries l_in channels per frame instead of m.  Call before the first render. */
+int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *matrix, int l_in);
+
 /* Everything one render call can take.  Unused pointers are NULL. */
 typedef struct {
   const float *d_in;            /* element 0 planar f32, layout as iamf_hip_batch_render */

@@ -61,6 +61,9 @@ CASES = {
                               out_rate=48000),
     # frame trimming: 100 samples off the first frame, 300 off the last
     "stereo_trim": dict(layout=_ss_layout("A"), bit_depth=16, frames=5, fs=1024, seed=54, trims={0: (100, 0), 4: (0, 300)}),
+    # projection-mode ambisonics: 10 sub-streams (6 coupled) -> 16 decoded channels -> Q15 de-mapping
+    # matrix -> 16 ambisonics channels (IAMF_core_decoder.c:116-130,228-252)
+    "toa_projection_B_s16": dict(layout=_ss_layout("B"), bit_depth=16, frames=5, fs=1024, seed=55),
 }
 
 
@@ -166,6 +169,29 @@ def build(name):
         for f in range(F):
             stream += W.temporal_delimiter()
             subs = [(i, W.lpcm_bytes(xq[i:i + 1, f * fs:(f + 1) * fs], ss)) for i in range(16)]
+            stream += W.audio_frames(subs)
+    elif name == "toa_projection_B_s16":
+        subs_n, coupled = 10, 6
+        rng = np.random.default_rng(c["seed"])
+        pq = rng.integers(-9000, 9000, size=(subs_n + coupled, 16)).astype(np.int16)
+        pq[np.arange(16), np.arange(16)] = 29000
+        xd = W.quantize(synth.hot(c["seed"], 16, n, sigma=0.12, burst_amp=0.5, burst_phase=700, burst_period=2500)
+                        .clip(-1, 1 - 2 ** -15).astype(np.float32), ss)   # decoded channels
+        stream += W.audio_element_ambisonics_projection(1, 0, 16, list(range(subs_n)), coupled, pq)
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100), default_q78=eg)],
+                                     dict(pdef=_pdef_static(101), default_q78=og), layouts_field)
+        pf = pq.astype(np.float32) * np.float32(2.0 ** -15)
+        xa = np.zeros((16, n), np.float32)
+        for l in range(subs_n + coupled):
+            xa = (xa + (xd[l][None, :] * pf[l][:, None]).astype(np.float32)).astype(np.float32)
+        info["elements"].append(dict(kind="scene", order=3, x=xa))
+        for f in range(F):
+            stream += W.temporal_delimiter()
+            subs, ch = [], 0
+            for i in range(subs_n):
+                w = 2 if i < coupled else 1
+                subs.append((i, W.lpcm_bytes(xd[ch:ch + w, f * fs:(f + 1) * fs], ss)))
+                ch += w
             stream += W.audio_frames(subs)
     elif name in ("l714_J_s24_gain", "l714_A_s16"):
         x = np.clip(synth.hot(c["seed"], 12, n, sigma=0.2, burst_amp=0.6, burst_phase=500, burst_period=3000),

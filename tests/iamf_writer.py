@@ -93,6 +93,21 @@ def audio_element_ambisonics_mono(eid, cid, channels, substream_ids):
     return obu(OBU_AUDIO_ELEMENT, p)
 
 
+def audio_element_ambisonics_projection(eid, cid, channels, substream_ids, coupled, matrix_q15):
+    """matrix_q15: int16 [substreams + coupled][channels] (decoded channel major, IAMF_core_decoder.c:116-130)"""
+    l_in = len(substream_ids) + coupled
+    m = np.asarray(matrix_q15, dtype=np.int16)
+    assert m.shape == (l_in, channels)
+    p = leb128(eid) + bytes([1 << 5]) + leb128(cid) + leb128(len(substream_ids))
+    for s in substream_ids:
+        p += leb128(s)
+    p += leb128(0)                      # no parameters
+    p += leb128(1)                      # ambisonics_mode = projection
+    p += bytes([channels, len(substream_ids), coupled])
+    p += m.astype(">i2").tobytes()
+    return obu(OBU_AUDIO_ELEMENT, p)
+
+
 def mix_presentation(mid, elements, output_gain, layouts, loudness_q78=0):
     """elements: list of dict(eid, gain_pdef(bytes), default_gain_q78, headphones_mode);
     output_gain: dict(pdef, default_q78); layouts: list of ('ss', n) / ('binaural',)"""

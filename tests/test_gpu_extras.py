@@ -154,6 +154,29 @@ def test_two_elements_with_limiter_vs_oracle(hip):
     assert np.array_equal(got, O.pack(z, 16))
 
 
+def test_projection_demapping_vs_oracle(hip):
+    """projection-mode ambisonics: 12 decoded channels -> 9 ambisonics channels (f32, decoded-channel
+    ascending, IAMF_core_decoder.c:116-130) -> H2M to 7.1.4 -> limiter, two streams"""
+    A, G, torch = hip
+    fs, F, S, L_in = 960, 3, 2, 12
+    n = fs * F
+    rng = np.random.default_rng(77)
+    P = (rng.integers(-12000, 12000, size=(L_in, 9)).astype(np.float32) * np.float32(2.0 ** -15)).astype(np.float32)
+    xd = np.stack([synth.hot(80 + s, L_in, n, sigma=0.15, burst_phase=200 + 300 * s, burst_period=1900) for s in range(S)])
+    oid = A.SS["J"]
+    b = A.Batch(S, A.get_h2m_matrix(2, oid), 12, frame_size=fs)
+    b.set_projection(P)
+    got = _run_ex(A, G, torch, b, S, L_in, xd, fs, 12, A.FMT_S16, calls=[1, 2])
+    b.close()
+    for s in range(S):
+        xa = np.zeros((9, n), np.float32)
+        for l in range(L_in):
+            xa = (xa + (xd[s][l][None, :] * P[l][:, None]).astype(np.float32)).astype(np.float32)
+        y = O.render(O.get_h2m(2, O.SS["J"]), xa, 12)
+        z, _ = O.limiter_run(y, [fs] * F)
+        assert np.array_equal(got[s], O.pack(z, 16)), s
+
+
 def test_mix_gain_ramps_vs_oracle(hip):
     """per-sample element / output gains (linear and quadratic-Bezier ramps built the way
     IAMF_decoder.c:639-664 builds them) are applied unconditionally, sample by sample"""
