@@ -25,6 +25,9 @@
 
 #include "../../include/iamf_hip.h"
 
+extern "C" int iamf_hip_wide4_has(int m, int c);                                      // iamf_render_wide4.hip
+extern "C" int iamf_hip_wide4_launch(const void *params, int m, hipStream_t st);      // iamf_render_wide4.hip
+
 namespace {
 
 #include "render_common.hpp"
@@ -236,6 +239,15 @@ bool wide_path_ok(const RenderParams &p, int m) {
   return sizeof(float) * (size_t)wide_lds_floats(p.out_ch, m) <= 80 * 1024;
 }
 
+// The 4-samples-per-lane wide kernel (render_wide4.hpp): 16-bit PCM, whole 1024-sample chunks,
+// 16-byte aligned planar input, an instantiated (inputs, outputs) pair.
+bool wide4_path_ok(const RenderParams &p, int m) {
+  if (getenv("IAMF_HIP_NO_WIDE4") || p.use_mfma) return false;
+  if (p.out_format != IAMF_HIP_FMT_S16 || (p.total & 1023) || (p.frame_size & 3) || p.n_end < 1088) return false;
+  if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
+  return iamf_hip_wide4_has(m, p.out_ch) != 0;
+}
+
 int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
   dim3 grid((unsigned)p.n_streams);
   if (p.fir_taps > 0 && p.in) {  // HRTF renderer: aligned calls only (the flush goes to the generic kernel)
@@ -252,6 +264,10 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
   }
   const bool fast = fast_path_ok(p);
   const bool wide = !fast && wide_path_ok(p, m);
+  if (wide && wide4_path_ok(p, m) && iamf_hip_wide4_launch(&p, m, st)) {
+    HIPCHK(hipGetLastError());
+    return IAMF_HIP_OK;
+  }
   switch (m) {
 #define CASE_M(v)                              \
   case v:                                      \
@@ -318,6 +334,7 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     if (env && !strcmp(env, "mfma")) mf = true;
     p.use_mfma = (mf && b->n_feeds <= 32) ? 1 : 0;
   }
+  { const char *d = getenv("IAMF_HIP_DBG"); p.dbg = d ? atoi(d) : 0; }
   p.n_atk = b->n_atk;
   p.n_end = b->n_end;
   p.thr = b->thr;

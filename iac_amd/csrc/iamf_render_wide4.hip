@@ -1,0 +1,59 @@
+// iamf_render_wide4.hip — instantiations of render_wide4_kernel<M, C> (render_wide4.hpp), in a
+// translation unit of their own so that the build compiles them next to iamf_render.hip.
+// Compiled with -ffp-contract=off like every kernel of the library: the projection is bit-exact.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/iamf_hip.h"
+
+namespace {
+
+#include "render_common.hpp"
+#include "render_fir.hpp"
+#include "render_fast.hpp"
+#include "render_wide4.hpp"
+
+template <int M, int C>
+void launch_mc(const RenderParams &p, hipStream_t st) {
+  const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M);
+  static bool opted = false;
+  if (!opted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    opted = true;
+  }
+  hipLaunchKernelGGL((render_wide4_kernel<M, C>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
+}
+
+template <int M>
+bool launch_m(const RenderParams &p, hipStream_t st) {
+  switch (p.out_ch) {
+    case 6: launch_mc<M, 6>(p, st); return true;
+    case 8: launch_mc<M, 8>(p, st); return true;
+    case 10: launch_mc<M, 10>(p, st); return true;
+    case 12: launch_mc<M, 12>(p, st); return true;
+    case 14: launch_mc<M, 14>(p, st); return true;
+    case 24: launch_mc<M, 24>(p, st); return true;
+    default: return false;
+  }
+}
+
+}  // namespace
+
+// 1 if a render_wide4_kernel instance exists for m inputs and c output channels
+extern "C" __attribute__((visibility("hidden"))) int iamf_hip_wide4_has(int m, int c) {
+  return (m == 12 || m == 16) && (c == 6 || c == 8 || c == 10 || c == 12 || c == 14 || c == 24);
+}
+
+// params: the caller's RenderParams (same definition, render_common.hpp); returns 1 if launched
+extern "C" __attribute__((visibility("hidden"))) int iamf_hip_wide4_launch(const void *params, int m, hipStream_t st) {
+  RenderParams p;
+  memcpy(&p, params, sizeof(p));
+  switch (m) {
+    case 12: return launch_m<12>(p, st) ? 1 : 0;
+    case 16: return launch_m<16>(p, st) ? 1 : 0;
+    default: return 0;
+  }
+}

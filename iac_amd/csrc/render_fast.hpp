@@ -91,9 +91,21 @@ __device__ __forceinline__ void limiter_wave(const float *arr_p, float *arr_g,
       float G = gs;
       float ep = dpp_wave_shr1(e);
       ep = lane <= f ? gs : ep;
-      for (int it = f + 1; it < 64; ++it) {
-        const float gsft = dpp_wave_shr1(G);
-        G = gsft - a1 * (gsft - ep);
+      // One sweep = G <- shr(G) - a1 * (shr(G) - ep) with the lane shift folded into the two
+      // subtractions (DPP on src0; lane 0 has no source lane and keeps its value, it is a fixed
+      // point anyway).  s_nop 1 = the two wait states a DPP read needs after a VALU write of the
+      // same register.  Sweeps beyond the 63 - f needed ones leave every lane unchanged.
+      for (int it = f + 1; it < 64; it += 8) {
+        float tmp;
+#define IAMF_SWEEP                                                              \
+  "s_nop 1\n\t"                                                                 \
+  "v_sub_f32_dpp %[t], %[g], %[ep] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"   \
+  "v_mul_f32_e32 %[t], %[a1], %[t]\n\t"                                         \
+  "v_sub_f32_dpp %[g], %[g], %[t] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        asm volatile(IAMF_SWEEP IAMF_SWEEP IAMF_SWEEP IAMF_SWEEP IAMF_SWEEP IAMF_SWEEP IAMF_SWEEP IAMF_SWEEP
+                     : [g] "+v"(G), [t] "=&v"(tmp)
+                     : [ep] "v"(ep), [a1] "v"(a1));
+#undef IAMF_SWEEP
       }
       const bool tr2 = pk * G > thr;
       const unsigned long long stop = __ballot(lane > f && !tr2);

@@ -64,7 +64,7 @@ def lib_path():
 def build(force=False):
     """Compile every HIP/C source for gfx950 into iac_amd/lib/libiamf_hip.so (hipcc cross-compiles
     without a GPU)."""
-    args = ["make", "-C", CSRC]
+    args = ["make", "-j4", "-C", CSRC]
     if force:
         subprocess.check_call(args + ["clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
