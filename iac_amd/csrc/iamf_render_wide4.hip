@@ -20,11 +20,16 @@ void launch_mc(const RenderParams &p, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M);
   static bool opted = false;
   if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     opted = true;
   }
-  hipLaunchKernelGGL((render_wide4_kernel<M, C>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
+  if (p.use_mfma)
+    hipLaunchKernelGGL((render_wide4_kernel<M, C, true>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
+  else
+    hipLaunchKernelGGL((render_wide4_kernel<M, C, false>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
 }
 
 template <int M>
@@ -34,7 +39,6 @@ bool launch_m(const RenderParams &p, hipStream_t st) {
     case 8: launch_mc<M, 8>(p, st); return true;
     case 10: launch_mc<M, 10>(p, st); return true;
     case 12: launch_mc<M, 12>(p, st); return true;
-    case 14: launch_mc<M, 14>(p, st); return true;
     case 24: launch_mc<M, 24>(p, st); return true;
     default: return false;
   }
@@ -44,7 +48,7 @@ bool launch_m(const RenderParams &p, hipStream_t st) {
 
 // 1 if a render_wide4_kernel instance exists for m inputs and c output channels
 extern "C" __attribute__((visibility("hidden"))) int iamf_hip_wide4_has(int m, int c) {
-  return (m == 12 || m == 16) && (c == 6 || c == 8 || c == 10 || c == 12 || c == 14 || c == 24);
+  return (m == 12 || m == 16) && (c == 6 || c == 8 || c == 10 || c == 12 || c == 24);
 }
 
 // params: the caller's RenderParams (same definition, render_common.hpp); returns 1 if launched

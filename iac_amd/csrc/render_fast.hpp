@@ -130,6 +130,30 @@ __device__ __forceinline__ void limiter_wave(const float *arr_p, float *arr_g,
   g_last = readlane_f(gacc, 63);
 }
 
+// Which of the workgroup's 4 waves runs the serial limiter recurrence.  Workgroups that share a CU
+// tend to reach that phase together; if both ran it on "wave 0" the two dependent chains would
+// sit on the same SIMD and each would get half its issue slots.  Every wave publishes its SIMD
+// and its wave slot on that SIMD (HW_ID bits 5:4 and 3:0); co-resident workgroups hold different
+// slots, so keying the choice on (simd - slot) spreads their chain waves over different SIMDs.
+// slots4 = 4 LDS words; call before a __syncthreads(), read with chain_wave_pick() after it.
+__device__ __forceinline__ void chain_wave_publish(float *slots4) {
+  const unsigned simd = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);  // HW_ID[5:4]
+  const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_ID[3:0]
+  if ((threadIdx.x & 63) == 0) slots4[threadIdx.x >> 6] = __int_as_float((int)((simd - slot) & 3u));
+}
+__device__ __forceinline__ int chain_wave_pick(const float *slots4) {
+  int best = 0, key = __float_as_int(slots4[0]);
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const int k = __float_as_int(slots4[w]);
+    if (k < key) {
+      key = k;
+      best = w;
+    }
+  }
+  return best;
+}
+
 // LDS floats the fast kernel needs for an OC-channel layout, M inputs and a limiter table of
 // `tab` entries (host and device use the same carve-up)
 __host__ __device__ constexpr int fast_lds_floats(int oc, int m, int tab, bool fir = false) {
@@ -198,6 +222,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
       const int f = p.src_feed[c];
       mat[t] = f >= 0 ? p.matrix[f * M + m] : 0.f;
     }
+    chain_wave_publish(misc + 12);
   }
   LimState ls = p.lim[s];
   float g_cur = ls.g, gs = ls.gs, ge = ls.ge;
@@ -234,6 +259,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     }
   }
   __syncthreads();
+  const int cw = chain_wave_pick(misc + 12);
 
   for (int c0 = 0; c0 < p.total; c0 += kFChunk) {
     const int cnt = p.total - c0 < kFChunk ? p.total - c0 : kFChunk;  // multiple of 64
@@ -365,7 +391,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
       n_st = n_st + cnt < n_end ? n_st + cnt : n_end;
     } else {
       const int b0 = kf >> 6;
-      if (wave == 0) {
+      if (wave == cw) {
         int ln = n_st + 64 * b0 < n_end ? n_st + 64 * b0 : n_end;
         float lgs = gs, lge = ge, lgl = g_cur;
         limiter_wave(arr_p, arr_g, [ctl](int ci) { return ctl[ci]; }, b0, cnt >> 6, ln, lgs, lge, lgl,

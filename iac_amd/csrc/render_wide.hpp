@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
         mat[i] = f >= 0 ? p.matrix[f * M + m] : 0.f;
       }
     }
+    chain_wave_publish(misc + 12);
   }
   // MFMA A operand: lane l holds W[slot = l & 31][in = 2*ks + (l >> 5)]
   float aw[KS];
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
   };
   load_chunk(0);
   __syncthreads();
+  const int cw = chain_wave_pick(misc + 12);
 
   for (int c0 = 0; c0 < p.total; c0 += kWChunk) {
     const int cnt = p.total - c0 < kWChunk ? p.total - c0 : kWChunk;  // multiple of 64
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
       n_st = n_st + cnt < n_end ? n_st + cnt : n_end;
     } else {
       const int b0 = kf >> 6;
-      if (wave == 0) {
+      if (wave == cw) {
         const int n_chunk = n_st;
         int ln = n_st + 64 * b0 < n_end ? n_st + 64 * b0 : n_end;
         float lgs = gs, lge = ge, lgl = g_cur;

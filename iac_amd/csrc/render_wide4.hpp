@@ -25,11 +25,44 @@ constexpr int kW4Win = 1088;        // staged table window / head length (> chun
 constexpr int kW4TailLanes = 60;    // lanes holding the chunk's last 240 samples
 constexpr int kW4FirstTail = 256 - kW4TailLanes;
 
+__host__ __device__ constexpr int wide4_base_floats(int c, int m) {
+  return 4 * kW4TailLanes * c + 2 * kFRing + 2 * (kFRing / 16) + 2 * kFChunk + 2 * kW4Win + ((c + 3) & ~3) * m + 16;
+}
+// PCM staging (per wave): a lane's 8*C output bytes = C/2 16-byte pieces, lane stride padded to an
+// odd number of pieces (conflict-free).  All 64 lanes at once if that fits 80 KB, else 32 per round.
+__host__ __device__ constexpr int wide4_stage_stride(int c) { return ((c / 2) & 1) ? c / 2 : c / 2 + 1; }
+__host__ __device__ constexpr int wide4_stage_lanes(int c, int m) {
+  return wide4_base_floats(c, m) + 4 * 64 * wide4_stage_stride(c) * 4 <= 20480 ? 64 : 32;
+}
 __host__ __device__ constexpr int wide4_lds_floats(int c, int m) {
-  return 4 * kW4TailLanes * c + 2 * kFRing + kFRing / 16 + 2 * kFChunk + 2 * kW4Win + ((c + 3) & ~3) * m + 16;
+  return wide4_base_floats(c, m) + 4 * wide4_stage_lanes(c, m) * wide4_stage_stride(c) * 4;
 }
 
-template <int M, int C>
+using w4_f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ float w4_comp(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+__device__ __forceinline__ void w4_set(float4 &v, int i, float f) {
+  if (i == 0) v.x = f;
+  else if (i == 1) v.y = f;
+  else if (i == 2) v.z = f;
+  else v.w = f;
+}
+// 4x4 transpose across the wave's four 16-lane rows: on entry register a holds, in row b, element
+// (a, b); on exit register a holds, in row b, element (b, a).  v_permlane32_swap exchanges rows 2,3
+// of its first operand with rows 0,1 of its second; v_permlane16_swap rows 1,3 with rows 0,2.
+__device__ __forceinline__ void w4_transpose_rows(float &r0, float &r1, float &r2, float &r3) {
+  using u2 = __attribute__((ext_vector_type(2))) unsigned;
+  u2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
+  u2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
+  u2 c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+  u2 d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+  r0 = __uint_as_float(c[0]);
+  r1 = __uint_as_float(c[1]);
+  r2 = __uint_as_float(d[0]);
+  r3 = __uint_as_float(d[1]);
+}
+
+template <int M, int C, bool MFMA>
 __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams p) {
   static_assert((C & 1) == 0 && C >= 4 && C <= 24, "even channel counts");
   extern __shared__ float lds[];
@@ -39,13 +72,15 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
   float4 *tail = reinterpret_cast<float4 *>(lds);   // [C][60]  lane-private: previous chunk's last 240 samples
   float *ring_pm = lds + 4 * kW4TailLanes * C;      // [R]     max |y| over channels
   float *ring_suf = ring_pm + R;                    // [R]     suffix maxima inside aligned 16-blocks
-  float *ring_bm = ring_suf + R;                    // [R/16]  maxima of aligned 16-blocks
-  float *arr_p = ring_bm + NB;                      // [1024]  window maxima of the chunk
+  float *ring_bm = ring_suf + R;                    // [2][R/16] maxima of aligned 16-blocks, stored twice so
+                                                    //           that 'block b - j' needs no wrap
+  float *arr_p = ring_bm + 2 * NB;                     // [1024]  window maxima of the chunk
   float *arr_g = arr_p + kFChunk;                   // [1024]  limiter gains of the chunk
   float *win = arr_g + kFChunk;                     // [kW4Win] ctab[min(n_st + i, n_end)]
   float *head = win + kW4Win;                       // [kW4Win] ctab[i]
   float *mat = head + kW4Win;                       // [M][C4] weights, input-major
   float *misc = mat + C4 * M;                       // [16]
+  uint4 *stage = reinterpret_cast<uint4 *>(misc + 16);  // [4 waves][LR][S] packed PCM on its way out
 
   const int s = blockIdx.x;
   const int t = threadIdx.x;
@@ -77,13 +112,14 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
     sfx = fmaxf(sfx, __shfl_down(sfx, 4, 16));
     sfx = fmaxf(sfx, __shfl_down(sfx, 8, 16));
     ring_suf[rp] = sfx;
-    if ((t & 15) == 0) ring_bm[rp >> 4] = sfx;
+    if ((t & 15) == 0) ring_bm[rp >> 4] = ring_bm[(rp >> 4) + NB] = sfx;
     for (int i = t; i < kW4Win; i += 256) head[i] = p.ctab[i < n_end ? i : n_end];
     for (int i = t; i < C4 * M; i += 256) {
       const int m = i / C4, c = i - m * C4;
       const int f = c < C ? p.src_feed[c] : -1;
       mat[i] = f >= 0 ? p.matrix[f * M + m] : 0.f;
     }
+    chain_wave_publish(misc + 12);
   }
   LimState ls = p.lim[s];
   float g_cur = ls.g, gs = ls.gs, ge = ls.ge;
@@ -97,88 +133,199 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
   const float m_eg = eg_on ? eg : 1.f, m_og = og_on ? og : 1.f, m_lg = lg_on ? lg : 1.f;
   const bool any_gain = eg_on || og_on || lg_on;
 
-  const int64_t out_base = p.pos0 > kDelay ? p.pos0 - kDelay : 0;
+  const int lead = p.pos0 > kDelay ? kDelay : (int)p.pos0;  // pos0 - (first sample of the output buffer)
+  const int pos_small = p.pos0 > (1 << 20) ? (1 << 20) : (int)p.pos0;
   uint8_t *pcm = p.pcm + (int64_t)s * p.pcm_stream_stride;
   const float *in_s = p.in + (int64_t)s * p.in_stream_stride;
 
-  float4 x[M];
-  {
-    const int k = 4 * t;  // total >= 1024
-    const int f = k / fs;
-    const int i = k - f * fs;
-    const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
+  // Input registers.
+  //   VALU variant: x[m] = this lane's 4 samples of channel m.
+  //   MFMA variant (v_mfma_f32_16x16x4_f32, D[channel][sample] = W[channel][input] * X[input][sample]):
+  //   the B operand of lane (j = lane & 15, kg = lane >> 4) at k-step ks for sample column j of
+  //   column group cg is X[4*ks + kg][...], so the lane loads, instead of all channels of its own
+  //   samples, the channels = kg (mod 4) of the samples owned by lanes 16*cg + j, cg = 0..3:
+  //   x[4*ks + cg] — the same number of 16-byte loads, already in operand layout.
+  constexpr int KS = (M + 3) / 4, RT = (C + 15) / 16;
+  constexpr int NX = MFMA ? 4 * KS : M;
+  float4 x[NX];
+  auto load_x = [&](int cbase, int tt) {
+    if constexpr (MFMA) {
+      const int j = tt & 15, kg = (tt >> 4) & 3, wv_ = tt >> 6;
 #pragma unroll
-    for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
+      for (int cg = 0; cg < 4; ++cg) {
+        const int k = cbase + 256 * wv_ + 4 * (16 * cg + j);
+        const int f = k / fs;
+        const int i = k - f * fs;
+        const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int m = 4 * ks + kg;
+          x[4 * ks + cg] = (M % 4 == 0 || m < M) ? ld_stream4(src + (int64_t)m * fs) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    } else {
+      const int k = cbase + 4 * tt;
+      const int f = k / fs;
+      const int i = k - f * fs;
+      const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
+    }
+  };
+  load_x(0, t);  // total >= 1024
+  // MFMA A operand: lane (i = lane & 15, kg = lane >> 4) holds W[slot 16*rt + i][input 4*ks + kg]
+  float aw[MFMA ? RT * KS : 1];
+  if constexpr (MFMA) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int slot = 16 * rt + (lane & 15);
+      const int f = slot < C ? p.src_feed[slot] : -1;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int m = 4 * ks + (lane >> 4);
+        aw[rt * KS + ks] = (f >= 0 && m < M) ? p.matrix[f * M + m] : 0.f;
+      }
+    }
   }
   __syncthreads();
+  const int cw = chain_wave_pick(misc + 12);
+
+  // Table window the next chunk can reach without a trigger: win[i] = ctab[min(n_st + i, n_end)].
+  // Fetched BEFORE the chunk's PCM stores are issued: vector-memory operations retire in order, so
+  // a load issued after the stores could only be waited for by draining the stores as well.
+  float wv[5];
+  auto fetch_window = [&](int n0, int tt) {
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int i = n0 + tt + 256 * r;
+      wv[r] = 1.0f;
+      if (n0 < n_end && tt + 256 * r < kW4Win) wv[r] = p.ctab[i < n_end ? i : n_end];
+    }
+  };
+  fetch_window(n_st, t);
 
   float4 y[C];
   for (int c0 = 0; c0 < p.total; c0 += kFChunk) {
-    const int k = c0 + 4 * t;
-    const int64_t gk = p.pos0 + k;
-    const int rp = ring_wrap(base + 4 * t);
-
-    // table window this chunk can reach without a trigger (older than the prefetch in the in-order
-    // vmcnt queue, so waiting for it does not drain the prefetch)
-    float wv[5];
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      const int i = n_st + t + 256 * r;
-      wv[r] = 1.0f;
-      if (n_st < n_end && t + 256 * r < kW4Win) wv[r] = p.ctab[i < n_end ? i : n_end];
-    }
+    // opaque per-chunk copy of the thread index: address arithmetic derived from it is recomputed
+    // per chunk (a few dozen VALU ops) instead of being hoisted into ~60 loop-invariant registers
+    int tv = threadIdx.x;
+    asm volatile("" : "+v"(tv));
+    const int lane = tv & 63, q = tv & 3;
+    const bool is_tail = tv >= kW4FirstTail;
+    const int tl = is_tail ? tv - kW4FirstTail : 0;
+    const int k = c0 + 4 * tv;
+    const int rp = ring_wrap(base + 4 * tv);
 
     // ---- element renderer + gains (reference operation order), 4 slots x 4 samples at a time ----
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.dbg & 2) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) { y[c] = x[c % M]; pm.x = fmaxf(pm.x, fabsf(y[c].x)); pm.y = fmaxf(pm.y, fabsf(y[c].y)); pm.z = fmaxf(pm.z, fabsf(y[c].z)); pm.w = fmaxf(pm.w, fabsf(y[c].w)); }
-    } else
-#pragma unroll
-    for (int cb = 0; cb < C4; cb += 4) {
-      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        const float4 w = *reinterpret_cast<const float4 *>(&mat[m * C4 + cb]);
-        a0.x = a0.x + w.x * x[m].x; a0.y = a0.y + w.x * x[m].y; a0.z = a0.z + w.x * x[m].z; a0.w = a0.w + w.x * x[m].w;
-        a1.x = a1.x + w.y * x[m].x; a1.y = a1.y + w.y * x[m].y; a1.z = a1.z + w.y * x[m].z; a1.w = a1.w + w.y * x[m].w;
-        if (cb + 2 < C) {
-          a2.x = a2.x + w.z * x[m].x; a2.y = a2.y + w.z * x[m].y; a2.z = a2.z + w.z * x[m].z; a2.w = a2.w + w.z * x[m].w;
-          a3.x = a3.x + w.w * x[m].x; a3.y = a3.y + w.w * x[m].y; a3.z = a3.z + w.w * x[m].z; a3.w = a3.w + w.w * x[m].w;
-        }
-      }
-      const float4 acc[4] = {a0, a1, a2, a3};
+    if constexpr (MFMA) {
+      // One sample position i of every lane's quad at a time: 4 column groups x RT row tiles.  Lane
+      // (j, g) receives channels 16*rt + 4*g + r of the sample owned by lane 16*cg + j; the row
+      // transpose hands every lane all channels of its own sample.  Exact f32 products in a
+      // k-ordered fma chain: <= 1 ulp per term away from the reference's separately rounded
+      // multiply and add (tests/test_gpu_mfma.py: +-1 LSB of the PCM).
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (cb + i < C) {
-          float4 v = acc[i];
-          if (any_gain) {
-            v.x = ((v.x * m_eg) * m_og) * m_lg;
-            v.y = ((v.y * m_eg) * m_og) * m_lg;
-            v.z = ((v.z * m_eg) * m_og) * m_lg;
-            v.w = ((v.w * m_eg) * m_og) * m_lg;
+        w4_f32x4 acc[4][RT];
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc[cg][rt] = w4_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+              acc[cg][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[rt * KS + ks], w4_comp(x[4 * ks + cg], i), acc[cg][rt], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float r0 = acc[0][rt][r], r1 = acc[1][rt][r], r2 = acc[2][rt][r], r3 = acc[3][rt][r];
+            w4_transpose_rows(r0, r1, r2, r3);
+            const float rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              if (16 * rt + 4 * g + r < C) w4_set(y[16 * rt + 4 * g + r], i, rr[g]);
           }
-          y[cb + i] = v;
-          pm.x = fmaxf(pm.x, fabsf(v.x));
-          pm.y = fmaxf(pm.y, fabsf(v.y));
-          pm.z = fmaxf(pm.z, fabsf(v.z));
-          pm.w = fmaxf(pm.w, fabsf(v.w));
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float4 v = y[c];
+        if (any_gain) {
+          v.x = ((v.x * m_eg) * m_og) * m_lg;
+          v.y = ((v.y * m_eg) * m_og) * m_lg;
+          v.z = ((v.z * m_eg) * m_og) * m_lg;
+          v.w = ((v.w * m_eg) * m_og) * m_lg;
+        }
+        y[c] = v;
+        pm.x = fmaxf(pm.x, fabsf(v.x));
+        pm.y = fmaxf(pm.y, fabsf(v.y));
+        pm.z = fmaxf(pm.z, fabsf(v.z));
+        pm.w = fmaxf(pm.w, fabsf(v.w));
+      }
+    } else if (p.dbg & 2) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) { y[c] = x[c % M]; pm.x = fmaxf(pm.x, fabsf(y[c].x)); pm.y = fmaxf(pm.y, fabsf(y[c].y)); pm.z = fmaxf(pm.z, fabsf(y[c].z)); pm.w = fmaxf(pm.w, fabsf(y[c].w)); }
+    } else {
+      // weights of MB inputs x 4 slots per LDS batch, the next batch fetched while this one is
+      // multiplied (explicit double buffer: left alone the scheduler hoists a whole group's
+      // weight reads and runs out of registers)
+      constexpr int MB = C >= 24 ? 1 : 2, NB_M = M / MB, G = C4 / 4;
+      static_assert(M % MB == 0, "inputs per batch");
+      float4 wc[MB], wn[MB];
+#pragma unroll
+      for (int j = 0; j < MB; ++j) wc[j] = *reinterpret_cast<const float4 *>(&mat[j * C4]);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        constexpr float4 z4 = {0.f, 0.f, 0.f, 0.f};
+        float4 a0 = z4, a1 = z4, a2 = z4, a3 = z4;
+#pragma unroll
+        for (int b = 0; b < NB_M; ++b) {
+          const int nb = b + 1 < NB_M ? b + 1 : 0, ng = b + 1 < NB_M ? g : g + 1;
+          if (ng < G) {
+#pragma unroll
+            for (int j = 0; j < MB; ++j) wn[j] = *reinterpret_cast<const float4 *>(&mat[(nb * MB + j) * C4 + 4 * ng]);
+          }
+#pragma unroll
+          for (int j = 0; j < MB; ++j) {
+            const float4 w = wc[j];
+            const float4 xv = x[b * MB + j];
+            a0.x = a0.x + w.x * xv.x; a0.y = a0.y + w.x * xv.y; a0.z = a0.z + w.x * xv.z; a0.w = a0.w + w.x * xv.w;
+            a1.x = a1.x + w.y * xv.x; a1.y = a1.y + w.y * xv.y; a1.z = a1.z + w.y * xv.z; a1.w = a1.w + w.y * xv.w;
+            if (4 * g + 2 < C) {
+              a2.x = a2.x + w.z * xv.x; a2.y = a2.y + w.z * xv.y; a2.z = a2.z + w.z * xv.z; a2.w = a2.w + w.z * xv.w;
+              a3.x = a3.x + w.w * xv.x; a3.y = a3.y + w.w * xv.y; a3.z = a3.z + w.w * xv.z; a3.w = a3.w + w.w * xv.w;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < MB; ++j) wc[j] = wn[j];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const float4 acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (4 * g + i < C) {
+            float4 v = acc[i];
+            if (any_gain) {
+              v.x = ((v.x * m_eg) * m_og) * m_lg;
+              v.y = ((v.y * m_eg) * m_og) * m_lg;
+              v.z = ((v.z * m_eg) * m_og) * m_lg;
+              v.w = ((v.w * m_eg) * m_og) * m_lg;
+            }
+            y[4 * g + i] = v;
+            pm.x = fmaxf(pm.x, fabsf(v.x));
+            pm.y = fmaxf(pm.y, fabsf(v.y));
+            pm.z = fmaxf(pm.z, fabsf(v.z));
+            pm.w = fmaxf(pm.w, fabsf(v.w));
+          }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);  // keep the weight loads of later groups from piling up in registers
     }
 
     // ---- prefetch the next chunk's input ----
-    {
-      const int kn = k + kFChunk;
-      if (kn < p.total) {
-        const int f = kn / fs;
-        const int i = kn - f * fs;
-        const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
-#pragma unroll
-        for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
-      }
-    }
+    if (c0 + kFChunk < p.total) load_x(c0 + kFChunk, tv);
 
     // ---- per-16 prefix / suffix / block maxima: 4 lanes x 4 samples = one aligned block ----
     const float i0 = pm.x, i1 = fmaxf(i0, pm.y), i2 = fmaxf(i1, pm.z), i3 = fmaxf(i2, pm.w);
@@ -191,22 +338,18 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
     *reinterpret_cast<float4 *>(&ring_pm[rp]) = pm;
     *reinterpret_cast<float4 *>(&ring_suf[rp]) =
         make_float4(fmaxf(s0, after), fmaxf(s1, after), fmaxf(s2, after), fmaxf(s3, after));
-    if (q == 0) ring_bm[rp >> 4] = fmaxf(fmaxf(qa, qb), fmaxf(qc, qd));
+    if (q == 0) ring_bm[rp >> 4] = ring_bm[(rp >> 4) + NB] = fmaxf(fmaxf(qa, qb), fmaxf(qc, qd));
 #pragma unroll
     for (int r = 0; r < 5; ++r)
-      if (t + 256 * r < kW4Win) win[t + 256 * r] = wv[r];
+      if (tv + 256 * r < kW4Win) win[tv + 256 * r] = wv[r];
     __syncthreads();  // (1) maxima and table window visible
 
     // ---- 240-sample window maximum = tail of block b-15, blocks b-14..b-1, head of block b ----
-    const int bpos = rp >> 4;
+    const float *bmp = ring_bm + (rp >> 4) + NB;  // the copy at +NB: bmp[-j] is block b - j
     float w14 = 0.f;
 #pragma unroll
-    for (int j = 1; j <= 14; ++j) {
-      int bi = bpos - j;
-      bi = bi < 0 ? bi + NB : bi;
-      w14 = fmaxf(w14, ring_bm[bi]);
-    }
-    const int rd = ring_wrap(base + 4 * t - kDelay);
+    for (int j = 1; j <= 14; ++j) w14 = fmaxf(w14, bmp[-j]);
+    const int rd = ring_wrap(base + 4 * tv - kDelay);
     const float4 so = *reinterpret_cast<const float4 *>(&ring_suf[rd]);
     float4 pk;
     pk.x = fmaxf(fmaxf(so.x, w14), pre_ex.x);
@@ -217,34 +360,34 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
     float gh[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int np = n_st + 4 * t + j;
+      int np = n_st + 4 * tv + j;
       np = np < n_end ? np : n_end;
-      gh[j] = gain_at(np, gs, ge, win[4 * t + j + 1], n_atk, n_end);
+      gh[j] = gain_at(np, gs, ge, win[4 * tv + j + 1], n_atk, n_end);
     }
     const float4 g = make_float4(gh[0], gh[1], gh[2], gh[3]);
     int kfirst = kBig;
-    if (pk.w * g.w > thr) kfirst = 4 * t + 3;
-    if (pk.z * g.z > thr) kfirst = 4 * t + 2;
-    if (pk.y * g.y > thr) kfirst = 4 * t + 1;
-    if (pk.x * g.x > thr) kfirst = 4 * t + 0;
-    *reinterpret_cast<float4 *>(&arr_p[4 * t]) = pk;
-    *reinterpret_cast<float4 *>(&arr_g[4 * t]) = g;
+    if (pk.w * g.w > thr) kfirst = 4 * tv + 3;
+    if (pk.z * g.z > thr) kfirst = 4 * tv + 2;
+    if (pk.y * g.y > thr) kfirst = 4 * tv + 1;
+    if (pk.x * g.x > thr) kfirst = 4 * tv + 0;
+    *reinterpret_cast<float4 *>(&arr_p[4 * tv]) = pk;
+    *reinterpret_cast<float4 *>(&arr_g[4 * tv]) = g;
     {
       const unsigned long long any = __ballot(kfirst != kBig);
       if (lane == 0) misc[wave] = __int_as_float(any ? __builtin_amdgcn_readlane(kfirst, __builtin_ctzll(any)) : kBig);
-      if (t == 255) misc[8] = g.w;  // gain of the chunk's last sample under the hypothesis
+      if (tv == 255) misc[8] = g.w;  // gain of the chunk's last sample under the hypothesis
     }
     __syncthreads();  // (2) vote, gains and window maxima visible
     int kf = __float_as_int(misc[0]);
     kf = min(kf, __float_as_int(misc[1]));
     kf = min(kf, __float_as_int(misc[2]));
     kf = min(kf, __float_as_int(misc[3]));
-    if (kf == kBig) {
+    if (kf == kBig || (p.dbg & 4)) {
       g_cur = misc[8];
       n_st = n_st + kFChunk < n_end ? n_st + kFChunk : n_end;
     } else {
       const int b0 = kf >> 6;
-      if (wave == 0) {
+      if (wave == cw) {
         const int n_chunk = n_st;
         int ln = n_st + 64 * b0 < n_end ? n_st + 64 * b0 : n_end;
         float lgs = gs, lge = ge, lgl = g_cur;
@@ -269,46 +412,80 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
 
     // ---- emit 4 sample-frames per lane: lanes < 196 their own (gains at +240 in this chunk),
     //      tail lanes the previous chunk's (gains at 4t - 784), leaving their own in the slot ----
-    float4 gq = *reinterpret_cast<const float4 *>(&arr_g[is_tail ? 4 * t - (kFChunk - kDelay) : 4 * t + kDelay]);
-    gq = make_float4(gq.x * 32768.f, gq.y * 32768.f, gq.z * 32768.f, gq.w * 32768.f);  // exact scaling
-    const int64_t j0 = is_tail ? gk - kFChunk : gk;
-    uint32_t od[2 * C];
+    if (c0 + kFChunk < p.total) fetch_window(n_st, tv);  // for the next chunk, ahead of the stores
+    float4 gq = *reinterpret_cast<const float4 *>(&arr_g[is_tail ? 4 * tv - (kFChunk - kDelay) : 4 * tv + kDelay]);
+    const float gs4[4] = {gq.x * 32768.f, gq.y * 32768.f, gq.z * 32768.f, gq.w * 32768.f};  // exact scaling
+    if (c0 + kFChunk >= p.total && tv >= 192) {
+      // last chunk of the call: its last 256 rendered samples are the stream state the next call
+      // (any kernel) starts from.  Written here so that y is dead once it has been packed below.
+      float *sy = p.ring_y + (int64_t)s * C * kSave;
 #pragma unroll
-    for (int c = 0; c < C; c += 2) {
-      float4 ya = y[c], yb = y[c + 1];
-      if (is_tail) {
-        float4 *sa = &tail[c * kW4TailLanes + tl], *sb = &tail[(c + 1) * kW4TailLanes + tl];
-        const float4 ta = *sa, tb = *sb;
-        *sa = ya;
-        *sb = yb;
-        ya = ta;
-        yb = tb;
-      }
-      // rint then saturate == the reference's clamp then lrintf (the bounds are integers)
-      od[0 * (C / 2) + c / 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)rintf(ya.x * gq.x), (int)rintf(yb.x * gq.x)));
-      od[1 * (C / 2) + c / 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)rintf(ya.y * gq.y), (int)rintf(yb.y * gq.y)));
-      od[2 * (C / 2) + c / 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)rintf(ya.z * gq.z), (int)rintf(yb.z * gq.z)));
-      od[3 * (C / 2) + c / 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)rintf(ya.w * gq.w), (int)rintf(yb.w * gq.w)));
+      for (int c = 0; c < C; ++c) *reinterpret_cast<float4 *>(&sy[c * kSave + 4 * (tv - 192)]) = y[c];
     }
-    if (j0 >= 0 && !((p.dbg & 1) && od[0] != 0x12345u)) {
-      uint4 *dst = reinterpret_cast<uint4 *>(pcm + (j0 - out_base) * (int64_t)C * 2);
+    if (is_tail) {  // swap in place: y <- previous tail, slot <- this chunk's samples
 #pragma unroll
-      for (int i = 0; i < C / 2; ++i) dst[i] = make_uint4(od[4 * i], od[4 * i + 1], od[4 * i + 2], od[4 * i + 3]);
+      for (int c = 0; c < C; ++c) {
+        float4 *sl = &tail[c * kW4TailLanes + tl];
+        const float4 old = *sl;
+        *sl = y[c];
+        y[c] = old;
+      }
+    }
+    {
+      // Pack to s16 (rint then saturate == the reference's clamp then lrintf: the bounds are
+      // integers).  Piece k of a lane = dwords 4k..4k+3 of its 8*C bytes; dword d = sample
+      // d / (C/2), channels 2*(d % (C/2)) and +1.
+      constexpr int H2 = C / 2, S = wide4_stage_stride(C), LR = wide4_stage_lanes(C, M);
+      uint32_t od[4 * H2];  // filled channel pair by channel pair so that y dies as od is born
+#pragma unroll
+      for (int c = 0; c < C; c += 2) {
+        const float4 ya = y[c], yb = y[c + 1];
+        od[0 * H2 + c / 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)rintf(ya.x * gs4[0]), (int)rintf(yb.x * gs4[0])));
+        od[1 * H2 + c / 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)rintf(ya.y * gs4[1]), (int)rintf(yb.y * gs4[1])));
+        od[2 * H2 + c / 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)rintf(ya.z * gs4[2]), (int)rintf(yb.z * gs4[2])));
+        od[3 * H2 + c / 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)rintf(ya.w * gs4[3]), (int)rintf(yb.w * gs4[3])));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // Through the wave's staging area so that every store instruction writes one contiguous run:
+      // in output order the chunk is [tail lanes 196..255 | lanes 0..195], so the lanes of a round
+      // cover at most two contiguous stretches of the PCM stream.
+      uint4 *stg = stage + wave * (LR * S);
+      const int lane_e = lane;
+#pragma unroll
+      for (int r = 0; r < 64 / LR; ++r) {
+        if (LR == 64 || (lane_e >> 5) == r) {
+#pragma unroll
+          for (int k = 0; k < H2; ++k)
+            stg[(lane_e & (LR - 1)) * S + k] = make_uint4(od[4 * k], od[4 * k + 1], od[4 * k + 2], od[4 * k + 3]);
+        }
+        // other lanes of this wave read what was just written: LDS executes a wave's accesses in
+        // order, the fence keeps the compiler from reordering them
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < (LR * H2 + 63) / 64; ++i) {
+          const int j = i * 64 + lane_e;
+          if ((LR * H2) % 64 == 0 || j < LR * H2) {
+            const int l2 = j / H2, k = j - l2 * H2;
+            const uint4 v = stg[l2 * S + k];
+            const int t2 = wave * 64 + r * LR + l2;
+            const int rel = c0 + 4 * t2 - (t2 >= kW4FirstTail ? kFChunk : 0);  // sample, relative to pos0
+            if (rel + pos_small >= 0 && !((p.dbg & 1) && v.x != 0x12345u))
+              *reinterpret_cast<uint4 *>(pcm + (uint32_t)((rel + lead) * (C * 2) + k * 16)) = v;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next round overwrites the staging area
+        __builtin_amdgcn_wave_barrier();
+      }
     }
     base = base + kFChunk >= R ? base + kFChunk - R : base + kFChunk;
     // no barrier here: the next chunk writes ring_* / win before its barrier (1), whose readers
     // all finished before barrier (2)/(3) of this chunk; arr_* / misc are written after (1)
   }
 
-  // ---- persist stream state (same format as the generic kernel): y of the last 256 samples sits
-  //      in the registers of lanes 192..255 ----
+  // ---- persist the rest of the stream state (same format as the generic kernel) ----
   {
-    float *sy = p.ring_y + (int64_t)s * C * kSave;
     float *spm = p.ring_pm + (int64_t)s * kSave;
-    if (t >= 192) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) *reinterpret_cast<float4 *>(&sy[c * kSave + 4 * (t - 192)]) = y[c];
-    }
     const int rp = ring_wrap(base - kSave + t);  // base = ring position of sample pos0 + total
     spm[t] = ring_pm[rp];
     if (t == 0) {
