@@ -1,0 +1,83 @@
+"""-m gpu: render_wide4_kernel (iac_amd/csrc/render_wide4.hpp) — even 6..24-channel layouts, 16-bit
+PCM, whole 1024-sample chunks.  The VALU variant must be bit-exact against the oracle; state must
+carry over between calls that take different kernels (wide4 <-> wide <-> generic)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available()
+    import iac_amd as A
+    import gpu_util as G
+    return A, G
+
+
+LAYOUTS = ["B", "C", "D", "J", "H"]  # 6, 8, 10, 12, 24 channels
+
+
+@pytest.mark.parametrize("out", LAYOUTS)
+@pytest.mark.parametrize("src", ["L714", "TOA"])
+def test_wide4_exact_multi_stream_multi_call(hip, src, out):
+    A, G = hip
+    S, fs, F = 3, 1024, 5
+    oid = A.SS[out]
+    ch = A.layout_channels(oid)
+    if src == "TOA":
+        m, mx, omx = 16, A.get_h2m_matrix(3, oid), O.get_h2m(3, O.SS[out])
+    else:
+        m, mx, omx = 12, A.get_m2m_matrix(A.SS["L714"], oid), O.get_m2m(O.SS["L714"], O.SS[out])
+    x = np.stack([synth.hot(900 + 7 * s, m, F * fs, sigma=0.22, burst_phase=150 + 400 * s, burst_period=2300)
+                  for s in range(S)])
+    eg, og = [0.8, 1.0, 1.2], [1.0, 0.9, 1.0]
+    got = G.hip_render(mx, ch, x, frame_size=fs, flush=True, frames_per_call=[1, 2, 1, 1],
+                       gains=dict(element=eg, output=og), projection=A.PROJ_EXACT)
+    for s in range(S):
+        want = O.stream_run(omx, ch, x[s], fs, element_gain=eg[s], output_gain=og[s])
+        assert got[s].shape == want.shape
+        assert np.array_equal(got[s], want), (src, out, s)
+
+
+def test_wide4_state_handoff_between_kernels(hip):
+    """512-sample frames: calls of 1, 2, 3, 4 frames alternate between the 256-sample-chunk wide
+    kernel (total % 1024 != 0) and wide4 (total % 1024 == 0); the flush takes the generic kernel"""
+    A, G = hip
+    fs, calls = 512, [1, 2, 3, 4, 2, 1]
+    F = sum(calls)
+    x = synth.hot(321, 12, F * fs, sigma=0.25, burst_phase=333, burst_period=1700)[None]
+    oid = A.SS["J"]
+    got = G.hip_render(A.get_m2m_matrix(A.SS["L714"], oid), 12, x, frame_size=fs, flush=True,
+                       frames_per_call=calls)[0]
+    want = O.stream_run(O.get_m2m(O.SS["L714"], O.SS["J"]), 12, x[0], fs)
+    assert np.array_equal(got, want)
+
+
+def test_wide4_mfma_state_handoff_within_1lsb(hip):
+    A, G = hip
+    fs, calls = 1024, [1, 3, 2]
+    F = sum(calls)
+    x = synth.hot(77, 16, F * fs, sigma=0.2, burst_phase=500, burst_period=2100)[None]
+    for out in ("B", "J", "H"):
+        oid = A.SS[out]
+        ch = A.layout_channels(oid)
+        got = G.hip_render(A.get_h2m_matrix(3, oid), ch, x, frame_size=fs, flush=True, frames_per_call=calls,
+                           projection=A.PROJ_MFMA)[0]
+        want = O.stream_run(O.get_h2m(3, O.SS[out]), ch, x[0], fs)
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert got.shape == want.shape and d.max() <= 1, (out, int(d.max()))
+
+
+def test_wide4_quiet_signal_never_triggers(hip):
+    A, G = hip
+    fs, F = 1024, 3
+    x = synth.quiet(5, 12, F * fs)[None]
+    oid = A.SS["J"]
+    got = G.hip_render(A.get_m2m_matrix(A.SS["L714"], oid), 12, x, frame_size=fs, flush=True)[0]
+    want = O.stream_run(O.get_m2m(O.SS["L714"], O.SS["J"]), 12, x[0], fs)
+    assert np.array_equal(got, want)
