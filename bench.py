@@ -211,8 +211,8 @@ def main():
             ktag = "render_fast_kernel<%d, 2, true>" % in_ch
         elif out_ch <= 2:
             ktag = "render_fast_kernel<%d, %d, false>" % (in_ch, out_ch)
-        else:
-            ktag = "render_wide_kernel<%d" % in_ch
+        else:   # whole 1024-sample chunks of s16: the 4-samples-per-lane kernel (else render_wide_kernel)
+            ktag = "render_wide4_kernel<%d, %d" % (in_ch, out_ch)
         traffic = measured_traffic(ktag, sf_per_step)
         out = {
             "metric": "Msamples/s rendered (3rd-order HOA->binaural, 48 kHz)",

@@ -334,7 +334,6 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     if (env && !strcmp(env, "mfma")) mf = true;
     p.use_mfma = (mf && b->n_feeds <= 32) ? 1 : 0;
   }
-  { const char *d = getenv("IAMF_HIP_DBG"); p.dbg = d ? atoi(d) : 0; }
   p.n_atk = b->n_atk;
   p.n_end = b->n_end;
   p.thr = b->thr;

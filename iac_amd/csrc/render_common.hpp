@@ -62,7 +62,6 @@ struct RenderParams {
   int32_t fir_taps;
   const float *fir_hist;    // device [n_streams][M][256] input history before this call
   float *fir_hist_next;     // device, same shape: history after this call
-  int32_t dbg;
 };
 
 // IAChannel ids (reference IAMF_types.h:61-90; L5/R5 alias L7/R7)

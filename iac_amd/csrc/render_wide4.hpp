@@ -265,9 +265,6 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
         pm.z = fmaxf(pm.z, fabsf(v.z));
         pm.w = fmaxf(pm.w, fabsf(v.w));
       }
-    } else if (p.dbg & 2) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) { y[c] = x[c % M]; pm.x = fmaxf(pm.x, fabsf(y[c].x)); pm.y = fmaxf(pm.y, fabsf(y[c].y)); pm.z = fmaxf(pm.z, fabsf(y[c].z)); pm.w = fmaxf(pm.w, fabsf(y[c].w)); }
     } else {
       // weights of MB inputs x 4 slots per LDS batch, the next batch fetched while this one is
       // multiplied (explicit double buffer: left alone the scheduler hoists a whole group's
@@ -382,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
     kf = min(kf, __float_as_int(misc[1]));
     kf = min(kf, __float_as_int(misc[2]));
     kf = min(kf, __float_as_int(misc[3]));
-    if (kf == kBig || (p.dbg & 4)) {
+    if (kf == kBig) {
       g_cur = misc[8];
       n_st = n_st + kFChunk < n_end ? n_st + kFChunk : n_end;
     } else {
@@ -470,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
             const uint4 v = stg[l2 * S + k];
             const int t2 = wave * 64 + r * LR + l2;
             const int rel = c0 + 4 * t2 - (t2 >= kW4FirstTail ? kFChunk : 0);  // sample, relative to pos0
-            if (rel + pos_small >= 0 && !((p.dbg & 1) && v.x != 0x12345u))
+            if (rel + pos_small >= 0)
               *reinterpret_cast<uint4 *>(pcm + (uint32_t)((rel + lead) * (C * 2) + k * 16)) = v;
           }
         }

@@ -19,7 +19,7 @@ import sys
 
 def main():
     src, out = sys.argv[1], sys.argv[2]
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     summary = {}
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
@@ -39,7 +39,7 @@ def main():
                     "max_ns": int(r["MaxNs"])}
     pmc = {}
     for kind, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        files = glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))
+        files = glob.glob(os.path.join(src, kind, "**", "*counter_collection.csv"), recursive=True)
         if not files:
             continue
         agg = collections.defaultdict(list)
