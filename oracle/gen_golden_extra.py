@@ -22,7 +22,20 @@ import e2e_cases  # noqa: E402
 from decoder_driver import decode_stream as ref_decode  # noqa: E402
 
 
+def generate_demix(ref, manifest, gold_dir):
+    import demix_cases as D
+    out = {}
+    for name, c in D.STAGE_CASES.items():
+        y = D.drive_demixer(ref, "demixer_", c, D.case_input(c))
+        out[name] = y
+        manifest["demix/" + name] = dict(layers=c["layers"], order=c["order"], recon=c["recon"], flags=c["flags"],
+                                         fs=c["fs"], seed=c["seed"], frames=len(c["schedule"]))
+        print("  demix %-16s -> %s" % (name, y.shape))
+    np.savez_compressed(os.path.join(gold_dir, "demix.npz"), **out)
+
+
 def generate(ref, manifest, gold_dir, synth):
+    generate_demix(ref, manifest, gold_dir)
     out = {}
     for name, case in e2e_cases.CASES.items():
         stream, _ = e2e_cases.build(name)

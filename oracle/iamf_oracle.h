@@ -90,6 +90,21 @@ int orc_dmx_set_mode_weight(orc_downmixer *d, int mode, int w_idx);
 int orc_dmx_downmix(orc_downmixer *d, const float *in, float *out, int s, int duration, int size);
 int orc_dmx_w_idx(const orc_downmixer *d);
 
+/* demixer of scalable channel audio (iamf_oracle_demix.c; reference src/iamf_dec/demixer.c) */
+typedef struct orc_demixer orc_demixer;
+orc_demixer *orc_demixer_open(int frame_size);
+void orc_demixer_close(orc_demixer *d);
+int orc_demixer_set_frame_offset(orc_demixer *d, unsigned offset);
+int orc_demixer_set_channel_layout(orc_demixer *d, int layout);
+int orc_demixer_set_channels_order(orc_demixer *d, const int *chs, int count);
+int orc_demixer_set_output_gain(orc_demixer *d, const int *chs, const float *gain, int count);
+int orc_demixer_set_demixing_info(orc_demixer *d, int mode, int w_idx);
+int orc_demixer_set_recon_gain(orc_demixer *d, int count, const int *chs, const float *gain, unsigned flags);
+int orc_demixer_demix(orc_demixer *d, float *dst, float *src, int size);
+void orc_demixer_state(const orc_demixer *d, int *mode, int *last_mode, int *w_idx, int *last_w_idx, int *skip);
+const float *orc_demixer_window(const orc_demixer *d, int stop);
+float orc_demixer_last_sfavg(const orc_demixer *d, int ch);
+
 /* ---- speex-derived resampler (oracle/iamf_oracle_resample.c) ---- reference resample.c */
 typedef struct orc_resampler orc_resampler;
 orc_resampler *orc_resampler_open(int channels, int in_rate, int out_rate, int quality);

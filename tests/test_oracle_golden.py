@@ -97,6 +97,16 @@ def test_downmix_bit_exact(golden):
         assert np.array_equal(y.view(np.uint32), g[name].view(np.uint32)), name
 
 
+def test_demixer_bit_exact(golden):
+    """scalable channel audio: oracle/iamf_oracle_demix.c against the real demixer_* (demixer.c)"""
+    import demix_cases as D
+    gold = golden.npz("demix")
+    for name, c in D.STAGE_CASES.items():
+        got = D.drive_demixer(O.lib(), "orc_demixer_", c, D.case_input(c))
+        assert got.shape == gold[name].shape
+        assert np.array_equal(got.view(np.uint32), gold[name].view(np.uint32)), name
+
+
 def test_downmix_invalid_pairs_refused(golden):
     for a, b in golden.manifest["dmx/_invalid"]:
         assert not O.Downmixer(a, b).ok(), (a, b)
