@@ -20,6 +20,9 @@ from .hipabi import (  # noqa: F401
     SS,
     Batch,
     BatchConfig,
+    DemixConfig,
+    DemixFrame,
+    DemixState,
     DmxFrame,
     DmxState,
     RenderArgs,

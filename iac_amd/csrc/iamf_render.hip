@@ -134,6 +134,10 @@ struct iamf_hip_batch {
   int dmx_n_in = 0, dmx_n_out = 0;
   float *d_pre = nullptr;
   int pre_l = 0;
+  bool demix = false;
+  int demix_steps = 0, demix_skip = 0;
+  int32_t *d_demix_tab = nullptr;
+  float *d_demix_ftab = nullptr;
   bool fir = false;
   int fir_taps = 0;
   float *d_fir_hist[2] = {nullptr, nullptr};
@@ -222,7 +226,7 @@ void launch_wide_m(const RenderParams &p, dim3 grid, hipStream_t st) {
 bool fast_path_ok(const RenderParams &p) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
   if (!p.limiter_on || !p.in || p.out_ch > 2 || p.n_end + 1 > kFTabMax) return false;
-  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix) return false;
+  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix || p.demix_on) return false;
   if ((p.pos0 & 15) || (p.total & 63) || (p.frame_size & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
@@ -233,7 +237,7 @@ bool fast_path_ok(const RenderParams &p) {
 bool wide_path_ok(const RenderParams &p, int m) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
   if (!p.limiter_on || !p.in || p.out_ch <= 2 || p.out_ch > kMaxOut || p.n_end < kWWin) return false;
-  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix) return false;
+  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix || p.demix_on) return false;
   if ((p.pos0 & 15) || (p.total & 63)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
   return sizeof(float) * (size_t)wide_lds_floats(p.out_ch, m) <= 80 * 1024;
@@ -362,13 +366,21 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     p.pre_matrix = b->d_pre;
     p.pre_l = b->pre_l;
   }
+  if (b->demix && a.d_in) {
+    p.demix_on = 1;
+    p.demix_steps = b->demix_steps;
+    p.demix_skip = b->demix_skip;
+    p.demix_tab = b->d_demix_tab;
+    p.demix_ftab = b->d_demix_ftab;
+    p.demix_frames = a.d_demix_frames;
+  }
   if (b->fir) {
     p.fir_taps = b->fir_taps;
     p.fir_hist = b->d_fir_hist[b->fir_cur];
     p.fir_hist_next = b->d_fir_hist[b->fir_cur ^ 1];
   }
   const size_t lds = sizeof(float) * ((size_t)(p.out_ch + 2) * kRing + 3 * kChunk + kHead + 4 +
-                                      (b->dmx ? (size_t)kChCount * kChunk : 0));
+                                      ((b->dmx || b->demix) ? (size_t)kChCount * kChunk : 0));
   const int r = launch(p, b->m, lds, static_cast<hipStream_t>(a.stream));
   if (r != IAMF_HIP_OK) return r;
   if (b->fir && p.in) b->fir_cur ^= 1;
@@ -559,6 +571,8 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_src_feed);
   (void)hipFree(b->d_dmx_tab);
   (void)hipFree(b->d_pre);
+  (void)hipFree(b->d_demix_tab);
+  (void)hipFree(b->d_demix_ftab);
   (void)hipFree(b->d_fir_hist[0]);
   (void)hipFree(b->d_fir_hist[1]);
   (void)hipFree(b->d_matrix2);
@@ -583,6 +597,7 @@ int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *a) {
   if (a->n_frames == 0) return 0;
   if (b->has2 && !a->d_in2) return IAMF_HIP_ERR_BAD_ARG;
   if (b->dmx && !a->d_dmx_frames) return IAMF_HIP_ERR_BAD_ARG;
+  if (b->demix && a->d_in && !a->d_demix_frames) return IAMF_HIP_ERR_BAD_ARG;
   if ((a->d_element_ramp || a->d_element2_ramp || a->d_output_ramp) &&
       a->ramp_stream_stride < (int64_t)a->n_frames * b->cfg.frame_size && b->cfg.n_streams > 1)
     return IAMF_HIP_ERR_BAD_ARG;
@@ -609,7 +624,7 @@ int iamf_hip_batch_render(iamf_hip_batch *b, const float *d_in, int64_t in_strea
   a.d_pcm = d_pcm;
   a.pcm_stream_stride_bytes = pcm_stream_stride_bytes;
   a.stream = stream;
-  if (b && (b->has2 || b->dmx)) return IAMF_HIP_ERR_BAD_ARG;  // those need iamf_hip_batch_render_ex
+  if (b && (b->has2 || b->dmx || b->demix)) return IAMF_HIP_ERR_BAD_ARG;  // those need iamf_hip_batch_render_ex
   return iamf_hip_batch_render_ex(b, &a);
 }
 
@@ -662,6 +677,165 @@ int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *matrix, int l_
   HIPCHK(hipMemcpy(b->d_pre, matrix, sizeof(float) * (size_t)l_in * b->m, hipMemcpyHostToDevice));
   b->pre_l = l_in;
   return IAMF_HIP_OK;
+}
+
+/* ---- demixer of scalable channel audio (reference src/iamf_dec/demixer.c) ---- */
+
+int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *c) {
+  if (!b || !c || b->pos != 0 || b->fir || b->d_pre) return IAMF_HIP_ERR_BAD_ARG;
+  if (c->layout < 0 || c->layout > 8 || c->n_in != kLayoutCount[c->layout] || c->n_in != b->m ||
+      c->n_gain < 0 || c->n_gain > 12 || c->n_recon < 0 || c->n_recon > 12)
+    return IAMF_HIP_ERR_BAD_ARG;
+  // which de-mix steps run: the reference reconstructs on demand (dmx_channel, demixer.c:379-424);
+  // a step is skipped when its right-hand output is already there
+  bool have[kChCount];
+  for (int i = 0; i < kChCount; ++i) have[i] = false;
+  for (int i = 0; i < c->n_in; ++i) {
+    if (c->chs_in[i] <= 0 || c->chs_in[i] >= kChCount || have[c->chs_in[i]]) return IAMF_HIP_ERR_BAD_ARG;
+    have[c->chs_in[i]] = true;
+  }
+  int steps = 0;
+  bool ok = true;
+  auto s2 = [&]() { if (!have[kChL2]) { ok = false; return; } if (have[kChR2]) return;
+                    if (!have[kChMono]) { ok = false; return; } steps |= 1; have[kChR2] = true; };
+  auto s3 = [&]() { if (have[kChR3]) return; s2(); if (!ok) return; if (!have[kChC]) { ok = false; return; }
+                    steps |= 2; have[kChL3] = have[kChR3] = true; };
+  auto s5 = [&]() { if (have[kChSR5]) return; s3(); if (!ok) return;
+                    if (!have[kChL7] || !have[kChR7]) { ok = false; return; }
+                    steps |= 4; have[kChSL5] = have[kChSR5] = true; };
+  auto s7 = [&]() { if (have[kChBR7]) return; s5(); if (!ok) return;
+                    if (!have[kChSL7] || !have[kChSR7]) { ok = false; return; }
+                    steps |= 8; have[kChBL7] = have[kChBR7] = true; };
+  auto h2 = [&]() { if (have[kChHR]) return; if (!have[kChTL] || !have[kChTR]) { ok = false; return; }
+                    s5(); if (!ok) return; steps |= 16; have[kChHL] = have[kChHR] = true; };
+  auto h4 = [&]() { if (have[kChHBR]) return; h2(); if (!ok) return;
+                    if (!have[kChHFR] || !have[kChHFL]) { ok = false; return; }
+                    steps |= 32; have[kChHBL] = have[kChHBR] = true; };
+  int32_t tab[50];
+  memset(tab, 0, sizeof(tab));
+  for (int i = 0; i < c->n_in; ++i) {
+    const int ch = kLayoutCh[c->layout][i];
+    tab[i] = c->chs_in[i];
+    tab[12 + i] = ch;
+    if (have[ch]) continue;
+    switch (ch) {
+      case kChR2: s2(); break;
+      case kChL3: case kChR3: s3(); break;
+      case kChSL5: case kChSR5: s5(); break;
+      case kChBL7: case kChBR7: s7(); break;
+      case kChHL: case kChHR: h2(); break;
+      case kChHBL: case kChHBR: h4(); break;
+      default: ok = false; break;
+    }
+    if (!ok || !have[ch]) return IAMF_HIP_ERR_BAD_ARG;
+  }
+  const int fs = b->cfg.frame_size;
+  std::vector<float> ft(12 + 2 * (size_t)fs, 0.f);
+  int ng = 0;
+  for (int i = 0; i < c->n_gain; ++i) {  // dmx_gainup touches only channels that were decoded
+    const int ch = c->gain_ch[i];
+    bool decoded = false;
+    for (int k = 0; k < c->n_in; ++k) decoded = decoded || c->chs_in[k] == ch;
+    if (ch <= 0 || ch >= kChCount) return IAMF_HIP_ERR_BAD_ARG;
+    if (!decoded) continue;
+    tab[25 + ng] = ch;
+    ft[ng] = c->gain[i];
+    ++ng;
+  }
+  tab[24] = ng;
+  tab[37] = c->n_recon;
+  for (int i = 0; i < c->n_recon; ++i) {
+    if (c->recon_ch[i] <= 0 || c->recon_ch[i] >= kChCount || !have[c->recon_ch[i]]) return IAMF_HIP_ERR_BAD_ARG;
+    tab[38 + i] = c->recon_ch[i];
+  }
+  // demixer_open + demixer_set_frame_offset (demixer.c:476-567): Hann cross-fade of fs/16 samples
+  // behind the first `skip` samples of every frame
+  float *start = ft.data() + 12, *stop = start + fs;
+  for (int i = 0; i < fs; ++i) {
+    start[i] = 1;
+    stop[i] = 0;
+  }
+  const int wl = fs / 8, ov = wl / 2, pre = (int)(c->frame_offset % (uint32_t)fs);
+  if (pre + ov <= fs) {
+    std::vector<float> hann((size_t)(wl > 0 ? wl : 1));
+    for (int i = 0; i < wl; ++i) hann[i] = (float)(0.5 * (1.0 - cos(2.0 * M_PI * (double)i / (double)(wl - 1))));
+    for (int i = 0; i < pre; ++i) {
+      start[i] = 0;
+      stop[i] = 1;
+    }
+    for (int i = pre, j = 0; j < ov; ++i, ++j) {
+      start[i] = hann[j];
+      stop[i] = hann[j + ov];
+    }
+  }
+  (void)hipFree(b->d_demix_tab);
+  (void)hipFree(b->d_demix_ftab);
+  b->d_demix_tab = nullptr;
+  b->d_demix_ftab = nullptr;
+  HIPCHK(hipMalloc(&b->d_demix_tab, sizeof(tab)));
+  HIPCHK(hipMemcpy(b->d_demix_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&b->d_demix_ftab, sizeof(float) * ft.size()));
+  HIPCHK(hipMemcpy(b->d_demix_ftab, ft.data(), sizeof(float) * ft.size(), hipMemcpyHostToDevice));
+  b->demix = true;
+  b->demix_steps = steps;
+  b->demix_skip = pre;
+  return IAMF_HIP_OK;
+}
+
+namespace {
+// demixer.c:66-78 (double literals narrowed to float) and fixedp11_5.c:81-82
+const struct { float alpha, beta, gamma, delta; int woff; } kDemixMat[7] = {
+    {1.0, 1.0, (float)0.707, (float)0.707, -1}, {(float)0.707, (float)0.707, (float)0.707, (float)0.707, -1},
+    {1.0, (float)0.866, (float)0.866, (float)0.866, -1}, {0, 0, 0, 0, 0},
+    {1.0, 1.0, (float)0.707, (float)0.707, 1}, {(float)0.707, (float)0.707, (float)0.707, (float)0.707, 1},
+    {1.0, (float)0.866, (float)0.866, (float)0.866, 1}};
+const float kDemixW[11] = {0.0, (float)0.0179, (float)0.0391, (float)0.0658, (float)0.1038, 0.25,
+                           (float)0.3962, (float)0.4342, (float)0.4609, (float)0.4821, 0.5};
+void demix_factors(int mode, int w_idx, float out[5]) {
+  out[0] = kDemixMat[mode].alpha;
+  out[1] = kDemixMat[mode].beta;
+  out[2] = kDemixMat[mode].gamma;
+  out[3] = kDemixMat[mode].delta;
+  out[4] = kDemixW[w_idx < 0 ? 0 : (w_idx > 10 ? 10 : w_idx)];
+}
+}  // namespace
+
+void iamf_hip_demix_state_init(iamf_hip_demix_state *st) {
+  memset(st, 0, sizeof(*st));
+  for (int i = 0; i < 24; ++i) st->last_sfavg[i] = 1.0f;
+}
+
+int iamf_hip_demix_set_info(iamf_hip_demix_state *st, int mode, int w_idx) {
+  if (!st || mode < 0 || mode == 3 || mode > 6) return IAMF_HIP_ERR_BAD_ARG;
+  if (w_idx < 0 || w_idx > 10) {
+    st->last_mode = st->mode;
+    st->mode = mode;
+    st->last_w_idx = st->w_idx;
+    if (kDemixMat[mode].woff > 0)
+      st->w_idx = st->last_w_idx + 1 < 10 ? st->last_w_idx + 1 : 10;
+    else
+      st->w_idx = st->last_w_idx - 1 > 0 ? st->last_w_idx - 1 : 0;
+  } else {
+    if (mode != st->mode) st->last_mode = st->mode = mode;
+    if (st->w_idx != w_idx) st->last_w_idx = st->w_idx = w_idx;
+  }
+  return IAMF_HIP_OK;
+}
+
+void iamf_hip_demix_frame_fill(iamf_hip_demix_state *st, int n_recon, const int32_t *recon_ch,
+                               const float *recon_gain, iamf_hip_demix_frame *out) {
+  memset(out, 0, sizeof(*out));
+  demix_factors(st->last_mode, st->last_w_idx, out->prev);
+  demix_factors(st->mode, st->w_idx, out->cur);
+  const float N = 7;
+  for (int i = 0; i < n_recon && i < 12; ++i) {  // dmx_rms, demixer.c:447-478
+    const int ch = recon_ch[i];
+    const float sf = recon_gain ? recon_gain[i] : 1.0f;
+    const float sfavg = (2 / (N + 1)) * sf + (1 - 2 / (N + 1)) * st->last_sfavg[ch];
+    out->recon_prev[i] = st->last_sfavg[ch];
+    out->recon_cur[i] = sfavg;
+    st->last_sfavg[ch] = sfavg;
+  }
 }
 
 /* ---- down-mixer control plane (downmix_renderer.c:77-91,131-216; IAMF_utils.c:234-245;

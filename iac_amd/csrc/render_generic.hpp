@@ -95,9 +95,61 @@ __global__ __launch_bounds__(kChunk) void render_kernel(const RenderParams p) {
       for (int m = 0; m < M; ++m) x[m] = 0.f;
     }
 
-    // ---- element renderer(s) + gains; the rendered sample goes to the LDS delay ring ----
     const int fcur = valid ? k / fs : 0;
     const int icur = k - fcur * fs;
+    if (p.demix_on && valid && p.in) {
+      // Demixer of scalable channel audio (demixer.c:636-664), one sample per thread; the thread's
+      // channel file (indexed by IAChannel) lives in its own LDS column.  x[] arrives in decoded
+      // order and leaves in the target layout's playback order.
+      const iamf_hip_demix_frame *fr = p.demix_frames + (int64_t)s * ((p.total + fs - 1) / fs) + fcur;
+      const bool use_prev = icur < p.demix_skip;
+      float cf[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) cf[j] = use_prev ? fr->prev[j] : fr->cur[j];
+      const float alpha = cf[0], beta = cf[1], gamma = cf[2], delta = cf[3], w = cf[4];
+      auto CH = [&](int c) -> float & { return dmx_ch[c * kChunk + t]; };
+#pragma unroll
+      for (int m = 0; m < M; ++m) CH(p.demix_tab[m]) = x[m];
+      const int n_gain = p.demix_tab[24];
+      for (int g = 0; g < n_gain; ++g) {  // dmx_gainup (:426-435)
+        float &v = CH(p.demix_tab[25 + g]);
+        v = v * p.demix_ftab[g];
+      }
+      const int steps = p.demix_steps;
+      if (steps & 1) CH(kChR2) = 2 * CH(kChMono) - CH(kChL2);                       // S1to2 (:126-147)
+      if (steps & 2) {  // S2to3 (:152-181): the reference's 0.707 literal makes this double arithmetic
+        const double c = 0.707 * (double)CH(kChC);
+        CH(kChL3) = (float)((double)CH(kChL2) - c);
+        CH(kChR3) = (float)((double)CH(kChR2) - c);
+      }
+      if (steps & 4) {  // S3to5 (:186-230)
+        CH(kChSL5) = (CH(kChL3) - CH(kChL7)) / delta;
+        CH(kChSR5) = (CH(kChR3) - CH(kChR7)) / delta;
+      }
+      if (steps & 8) {  // S5to7 (:236-284)
+        CH(kChBL7) = (CH(kChSL5) - CH(kChSL7) * alpha) / beta;
+        CH(kChBR7) = (CH(kChSR5) - CH(kChSR7) * alpha) / beta;
+      }
+      if (steps & 16) {  // TF2toT2 (:290-335)
+        CH(kChHL) = CH(kChTL) - delta * w * CH(kChSL5);
+        CH(kChHR) = CH(kChTR) - delta * w * CH(kChSR5);
+      }
+      if (steps & 32) {  // T2toT4 (:340-377)
+        CH(kChHBL) = (CH(kChHL) - CH(kChHFL)) / gamma;
+        CH(kChHBR) = (CH(kChHR) - CH(kChHFR)) / gamma;
+      }
+      const int n_recon = p.demix_tab[37];
+      const float wstart = p.demix_ftab[12 + icur], wstop = p.demix_ftab[12 + fs + icur];
+      for (int r = 0; r < n_recon; ++r) {  // dmx_rms (:447-478)
+        const float filt = fr->recon_prev[r] * wstop + fr->recon_cur[r] * wstart;
+        float &v = CH(p.demix_tab[38 + r]);
+        v = v * filt;
+      }
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = CH(p.demix_tab[12 + m]);
+    }
+
+    // ---- element renderer(s) + gains; the rendered sample goes to the LDS delay ring ----
     float er = 1.f, er2 = 1.f, orr = 1.f;  // per-sample mix gains of this call, when given
     if (valid) {
       if (p.elem_ramp) er = p.elem_ramp[(int64_t)s * p.ramp_stream_stride + k];

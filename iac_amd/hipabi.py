@@ -54,7 +54,24 @@ class RenderArgs(C.Structure):
                 ("d_element_ramp", C.c_void_p), ("d_element2_ramp", C.c_void_p),
                 ("d_output_ramp", C.c_void_p), ("ramp_stream_stride", C.c_int64),
                 ("d_dmx_frames", C.c_void_p), ("n_frames", C.c_int32), ("n_samples", C.c_int32),
-                ("d_pcm", C.c_void_p), ("pcm_stream_stride_bytes", C.c_int64), ("stream", C.c_void_p)]
+                ("d_pcm", C.c_void_p), ("pcm_stream_stride_bytes", C.c_int64), ("stream", C.c_void_p),
+                ("d_demix_frames", C.c_void_p)]
+
+
+class DemixConfig(C.Structure):
+    _fields_ = [("layout", C.c_int32), ("n_in", C.c_int32), ("chs_in", C.c_int32 * 12), ("n_gain", C.c_int32),
+                ("gain_ch", C.c_int32 * 12), ("gain", C.c_float * 12), ("n_recon", C.c_int32),
+                ("recon_ch", C.c_int32 * 12), ("frame_offset", C.c_uint32)]
+
+
+class DemixState(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("last_mode", C.c_int32), ("w_idx", C.c_int32), ("last_w_idx", C.c_int32),
+                ("last_sfavg", C.c_float * 24)]
+
+
+class DemixFrame(C.Structure):
+    _fields_ = [("prev", C.c_float * 5), ("cur", C.c_float * 5), ("recon_prev", C.c_float * 12),
+                ("recon_cur", C.c_float * 12)]
 
 
 def lib_path():
@@ -106,6 +123,13 @@ def lib():
                                                  C.c_void_p]
         L.iamf_hip_resampler_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.iamf_hip_batch_set_projection.argtypes = [C.c_void_p, FP, C.c_int]
+        L.iamf_hip_batch_set_demixer.argtypes = [C.c_void_p, C.POINTER(DemixConfig)]
+        L.iamf_hip_demix_state_init.argtypes = [C.POINTER(DemixState)]
+        L.iamf_hip_demix_state_init.restype = None
+        L.iamf_hip_demix_set_info.argtypes = [C.POINTER(DemixState), C.c_int, C.c_int]
+        L.iamf_hip_demix_frame_fill.argtypes = [C.POINTER(DemixState), C.c_int, C.POINTER(C.c_int32), FP,
+                                                C.POINTER(DemixFrame)]
+        L.iamf_hip_demix_frame_fill.restype = None
         L.iamf_hip_dmx_valid.argtypes = [C.c_int, C.c_int]
         L.iamf_hip_dmx_layout_channels.argtypes = [C.c_int]
         L.iamf_hip_dmx_state_init.argtypes = [C.POINTER(DmxState)]
@@ -219,6 +243,20 @@ class Batch:
         r = lib().iamf_hip_batch_set_projection(self.h, _fparr([v for row in rows for v in row]), len(rows))
         if r != 0:
             raise IamfHipError(r, "iamf_hip_batch_set_projection")
+
+    def set_demixer(self, layout, chs_in, gains=(), recon=(), frame_offset=0):
+        """gains: [(IAChannel, linear gain)], recon: [IAChannel] (reference demixer.c)"""
+        c = DemixConfig()
+        c.layout, c.n_in, c.n_gain, c.n_recon, c.frame_offset = layout, len(chs_in), len(gains), len(recon), frame_offset
+        for i, ch in enumerate(chs_in):
+            c.chs_in[i] = ch
+        for i, (ch, g) in enumerate(gains):
+            c.gain_ch[i], c.gain[i] = ch, g
+        for i, ch in enumerate(recon):
+            c.recon_ch[i] = ch
+        r = lib().iamf_hip_batch_set_demixer(self.h, C.byref(c))
+        if r != 0:
+            raise IamfHipError(r, "iamf_hip_batch_set_demixer")
 
     def flush(self, d_pcm, pcm_stream_stride_bytes, stream=None):
         r = lib().iamf_hip_batch_flush(self.h, d_pcm, pcm_stream_stride_bytes, stream)

@@ -182,6 +182,52 @@ int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *
  * element 0's input carries l_in channels per frame instead of m.  Call before the first render. */
 int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *matrix, int l_in);
 
+/* ------------------------------------------------------------------------------------------
+ * Demixer of scalable channel audio in front of element 0's renderer (reference
+ * src/iamf_dec/demixer.c, driven per frame by iamf_stream_scale_decoder_demix,
+ * IAMF_decoder.c:2324-2349).  Element 0's input then carries the decoded channels of all layers up
+ * to the chosen one in their bitstream order; the demixer applies the layers' output gains,
+ * reconstructs the channels the target layout lacks (S1to2 ... S5to7, TF2toT2, T2toT4 with the
+ * frame's demixing mode), smooths the recon gains and hands the renderer the target layout in
+ * playback order.  Channel ids are IAChannel values (IAMF_types.h:61-90).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct iamf_hip_demix_config {
+  int32_t layout;         /* target IAChannelLayoutType 0..8 (demixer_set_channel_layout) */
+  int32_t n_in;           /* decoded channels = channels of `layout` (demixer_set_channels_order) */
+  int32_t chs_in[12];
+  int32_t n_gain;         /* demixer_set_output_gain */
+  int32_t gain_ch[12];
+  float gain[12];
+  int32_t n_recon;        /* channels of demixer_set_recon_gain */
+  int32_t recon_ch[12];
+  uint32_t frame_offset;  /* demixer_set_frame_offset: the codec's delay (0 for LPCM) */
+} iamf_hip_demix_config;
+
+/* Call before the first render; the batch's matrix must take the target layout's channels. */
+int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *cfg);
+
+/* Host-side state of one stream's demixer (demixer_set_demixing_info, demixer.c:592-618, and the
+ * recon-gain smoothing of dmx_rms, :447-478). */
+typedef struct iamf_hip_demix_state {
+  int32_t mode, last_mode, w_idx, last_w_idx;
+  float last_sfavg[24];
+} iamf_hip_demix_state;
+
+/* What the kernel needs for one frame of one stream (device array [n_streams][n_frames]). */
+typedef struct iamf_hip_demix_frame {
+  float prev[5], cur[5];            /* alpha, beta, gamma, delta, w of the previous / current mode:
+                                       the first frame_offset % frame_size samples use prev */
+  float recon_prev[12], recon_cur[12]; /* per recon channel: smoothed gain of the last frame / of this one */
+} iamf_hip_demix_frame;
+
+void iamf_hip_demix_state_init(iamf_hip_demix_state *st);
+/* replaces demixer_set_demixing_info: 0 or IAMF_HIP_ERR_BAD_ARG (then nothing changes) */
+int iamf_hip_demix_set_info(iamf_hip_demix_state *st, int mode, int w_idx);
+/* fills one frame record from the state and the recon gains valid for this frame (recon_gain[i]
+ * belongs to recon_ch[i] of the config; NULL = no recon channels), and advances the smoothing */
+void iamf_hip_demix_frame_fill(iamf_hip_demix_state *st, int n_recon, const int32_t *recon_ch,
+                               const float *recon_gain, iamf_hip_demix_frame *out);
+
 /* Everything one render call can take.  Unused pointers are NULL. */
 typedef struct {
   const float *d_in;            /* element 0 planar f32, layout as iamf_hip_batch_render */
@@ -201,6 +247,7 @@ typedef struct {
   void *d_pcm;
   int64_t pcm_stream_stride_bytes;
   void *stream;
+  const iamf_hip_demix_frame *d_demix_frames; /* with a demixer: [n_streams][n_frames] on the device */
 } iamf_hip_render_args;
 
 /* Extended form of iamf_hip_batch_render; same return value. */

@@ -293,3 +293,44 @@ def test_resampled_pipeline_vs_oracle(hip):
     want = O.pack(zl, 16)
     assert got.shape == want.shape
     assert np.array_equal(got, want)
+
+
+def test_demixer_stage_matches_reference(hip, golden):
+    """scalable channel audio (N2): demixer in front of an identity renderer, f32 out, limiter off,
+    against the REAL reference demixer_* outputs (tests/golden/demix.npz); per-frame records built
+    with the ABI's own host control plane (iamf_hip_demix_*)"""
+    import ctypes as C
+    import demix_cases as D
+    A, G, torch = hip
+    gold = golden.npz("demix")
+    for name, c in D.STAGE_CASES.items():
+        x = D.case_input(c)                      # [frames][ch][fs]
+        F, ch, fs = x.shape
+        b = A.Batch(1, G.identity_matrix(ch), ch, frame_size=fs, out_format=A.FMT_F32, limiter=False)
+        b.set_demixer(c["layout"], c["order"], c["gains"], c["recon"], c["offset"])
+        st = A.DemixState()
+        A.lib().iamf_hip_demix_state_init(C.byref(st))
+        A.lib().iamf_hip_demix_set_info(C.byref(st), c["default"][0], c["default"][1])
+        frames = (A.DemixFrame * F)()
+        rec = (C.c_int32 * 12)(*c["recon"])
+        cur = [1.0] * len(c["recon"])
+        for f, (mode, rg) in enumerate(c["schedule"]):
+            if rg is not None:
+                cur = rg
+            if mode > -1:
+                A.lib().iamf_hip_demix_set_info(C.byref(st), mode, -1)
+            A.lib().iamf_hip_demix_frame_fill(C.byref(st), len(cur), rec, (C.c_float * 12)(*cur), C.byref(frames[f]))
+        d_fr = torch.from_numpy(np.frombuffer(bytes(frames), dtype=np.uint8).copy()).cuda()
+        xin = torch.from_numpy(np.ascontiguousarray(x[None])).cuda()     # [1][F][ch][fs]
+        pcm = torch.zeros((1, F * fs * ch * 4), dtype=torch.uint8, device="cuda")
+        a = A.RenderArgs()
+        a.d_in, a.in_stream_stride, a.in_frame_stride = xin.data_ptr(), F * ch * fs, ch * fs
+        a.n_frames, a.d_pcm, a.pcm_stream_stride_bytes = F, pcm.data_ptr(), F * fs * ch * 4
+        a.d_demix_frames = d_fr.data_ptr()
+        a.stream = torch.cuda.current_stream().cuda_stream
+        n = b.render_ex(a)
+        torch.cuda.synchronize()
+        b.close()
+        assert n == F * fs
+        got = pcm.cpu().numpy().view(np.float32).reshape(F, fs, ch).transpose(0, 2, 1)
+        assert np.array_equal(got, gold[name]), name
