@@ -118,6 +118,12 @@ typedef struct {
 } GainSeg;
 
 #define MAX_QUEUE 64
+#define MAX_LAYERS 6
+/* recon-gain segment (IAMF_OBU.c:1142-1195): per layer the flags and the gains of the flagged channels */
+typedef struct {
+  uint32_t flags[MAX_LAYERS];
+  float gain[MAX_LAYERS][12];
+} ReconSeg;
 /* One parameter's timeline, kept the way the reference's database keeps it (IAMF_decoder.c:984-1125):
  * a FIFO of segments; `timestamp` is the start time of the oldest queued segment and only moves
  * when iamf_database_parameters_time_elapse pops fully elapsed segments after a frame. */
@@ -129,7 +135,15 @@ typedef struct {
   uint64_t timestamp, duration, elapse;
   int qn;
   GainSeg q[MAX_QUEUE]; /* demixing segments use .anim as the mode */
+  ReconSeg *rq;         /* recon-gain parameters: [MAX_QUEUE], parallel to q */
 } Param;
+
+/* one layer of a scalable channel audio element (IAMF_OBU.c:491-530) */
+typedef struct {
+  int layout, out_gain_flag, recon_flag, nsub, ncoupled;
+  int gain_flags; /* 6 bits over IAOutputGainChannel */
+  int16_t gain_q;
+} Layer;
 
 typedef struct {
   uint64_t id;
@@ -145,6 +159,10 @@ typedef struct {
   uint64_t demix_pid;
   int demix_default_mode, demix_default_w;
   int channels;
+  int nlayers;
+  Layer layer[MAX_LAYERS];
+  int has_recon;
+  uint64_t recon_pid;
 } Element;
 
 typedef struct {
@@ -190,6 +208,16 @@ struct IAMF_Decoder {
   iamf_hip_resampler *rs;
   iamf_hip_dmx_state dmx;
   int use_dmx, dmx_mode;
+  /* demixer of a scalable (or gain-carrying) channel element 0 (IAMF_decoder.c:2324-2386) */
+  int use_demix, demix_layer, demix_nsub, demix_nch;
+  iamf_hip_demix_state dmst;
+  uint32_t rec_flags;
+  int rec_n;
+  int32_t rec_ch[12];
+  float rec_gain[12];
+  uint32_t layer_rec_flags[MAX_LAYERS]; /* latest recon-gain block, per layer (ctx->conf_s[i].recon_gain) */
+  float layer_rec_gain[MAX_LAYERS][12];
+  iamf_hip_demix_frame *d_demix;
   /* packets of the temporal unit being assembled */
   uint8_t *pkt[2][MAX_SUBSTREAMS];
   uint32_t pkt_len[2][MAX_SUBSTREAMS];
@@ -226,6 +254,109 @@ static const int k_al_of_pl[9][12] = {
     {0}, {0, 1}, {0, 1, 4, 5, 2, 3}, {0, 1, 6, 7, 2, 3, 4, 5}, {0, 1, 8, 9, 2, 3, 4, 5, 6, 7},
     {0, 1, 6, 7, 2, 3, 4, 5}, {0, 1, 8, 9, 2, 3, 4, 5, 6, 7}, {0, 1, 10, 11, 2, 3, 4, 5, 6, 7, 8, 9},
     {0, 1, 4, 5, 2, 3}};
+
+/* IAChannel ids (IAMF_types.h:61-90) */
+enum {
+  CH_INVALID, CH_L7, CH_R7, CH_C, CH_LFE, CH_SL7, CH_SR7, CH_BL7, CH_BR7, CH_HFL, CH_HFR, CH_HBL,
+  CH_HBR, CH_MONO, CH_L2, CH_R2, CH_TL, CH_TR, CH_L3, CH_R3, CH_SL5, CH_SR5, CH_HL, CH_HR,
+  CH_L5 = CH_L7, CH_R5 = CH_R7
+};
+static const int k_layout_surround[9] = {1, 2, 5, 5, 5, 7, 7, 7, 3}; /* IAMF_utils.c:157-161 */
+static const int k_layout_top[9] = {0, 0, 0, 2, 4, 0, 2, 4, 2};
+static const int k_al_channels[9][12] = { /* audio-layer order, IAMF_utils.c:181-196 */
+    {CH_MONO},
+    {CH_L2, CH_R2},
+    {CH_L5, CH_R5, CH_SL5, CH_SR5, CH_C, CH_LFE},
+    {CH_L5, CH_R5, CH_SL5, CH_SR5, CH_HL, CH_HR, CH_C, CH_LFE},
+    {CH_L5, CH_R5, CH_SL5, CH_SR5, CH_HFL, CH_HFR, CH_HBL, CH_HBR, CH_C, CH_LFE},
+    {CH_L7, CH_R7, CH_SL7, CH_SR7, CH_BL7, CH_BR7, CH_C, CH_LFE},
+    {CH_L7, CH_R7, CH_SL7, CH_SR7, CH_BL7, CH_BR7, CH_HL, CH_HR, CH_C, CH_LFE},
+    {CH_L7, CH_R7, CH_SL7, CH_SR7, CH_BL7, CH_BR7, CH_HFL, CH_HFR, CH_HBL, CH_HBR, CH_C, CH_LFE},
+    {CH_L3, CH_R3, CH_TL, CH_TR, CH_C, CH_LFE}};
+/* layer layout -> IAMF_SoundSystem (iamf_layer_layout_convert_sound_system, IAMF_decoder.c:268-275) */
+static const int k_layout_ss[9] = {SOUND_SYSTEM_MONO, SOUND_SYSTEM_A, SOUND_SYSTEM_B, SOUND_SYSTEM_C, SOUND_SYSTEM_D,
+                                   SOUND_SYSTEM_I, SOUND_SYSTEM_EXT_712, SOUND_SYSTEM_J, SOUND_SYSTEM_EXT_312};
+
+/* iamf_channel_layout_get_new_channels, IAMF_decoder.c:450-531: the channels a layer adds, in
+ * the order its sub-streams decode to */
+static int layer_new_channels(int last, int cur, int32_t *out) {
+  int n = 0;
+  if (last < 0) {
+    for (int i = 0; i < k_layout_channels[cur]; ++i) out[n++] = k_al_channels[cur][i];
+    return n;
+  }
+  {
+    const int s1 = k_layout_surround[last], s2 = k_layout_surround[cur];
+    const int t1 = k_layout_top[last], t2 = k_layout_top[cur];
+    if (s1 < 5 && 5 <= s2) { out[n++] = CH_L5; out[n++] = CH_R5; }
+    if (s1 < 7 && 7 <= s2) { out[n++] = CH_SL7; out[n++] = CH_SR7; }
+    if (t2 != t1 && t2 == 4) { out[n++] = CH_HFL; out[n++] = CH_HFR; }
+    if (t2 - t1 == 4) {
+      out[n++] = CH_HBL; out[n++] = CH_HBR;
+    } else if (!t1 && t2 - t1 == 2) {
+      if (s2 < 5) { out[n++] = CH_TL; out[n++] = CH_TR; } else { out[n++] = CH_HL; out[n++] = CH_HR; }
+    }
+    if (s1 < 3 && 3 <= s2) { out[n++] = CH_C; out[n++] = CH_LFE; }
+    if (s1 < 2 && 2 <= s2) out[n++] = CH_L2;
+  }
+  return n;
+}
+
+/* iamf_output_gain_channel_map, IAMF_decoder.c:533-600; g over IAOutputGainChannel
+ * (RTF, LTF, RS, LS, R, L; IAMF_decoder_private.h:62-70) */
+static int output_gain_channel(int layout, int g) {
+  const int s = k_layout_surround[layout];
+  switch (g) {
+    case 5: return layout == 0 ? CH_MONO : layout == 1 ? CH_L2 : layout == 8 ? CH_L3 : CH_INVALID;
+    case 4: return layout == 1 ? CH_R2 : layout == 8 ? CH_R3 : CH_INVALID;
+    case 3: return s == 5 ? CH_SL5 : CH_INVALID;
+    case 2: return s == 5 ? CH_SR5 : CH_INVALID;
+    case 1: return s < 5 ? CH_TL : CH_HL;
+    case 0: return s < 5 ? CH_TR : CH_HR;
+    default: return CH_INVALID;
+  }
+}
+
+/* iamf_recon_channels_get_flags, IAMF_decoder.c:371-407 (bits over IAReconChannel, IAMF_types.h:37-60) */
+static uint32_t recon_default_flags(int l1, int l2) {
+  uint32_t f = 0;
+  int s1, s2, t1, t2;
+  if (l1 == l2) return 0;
+  s1 = k_layout_surround[l1]; s2 = k_layout_surround[l2];
+  t1 = k_layout_top[l1]; t2 = k_layout_top[l2];
+  if (s1 != s2) {
+    if (s2 <= 3) f |= (1u << 0) | (1u << 2);
+    else if (s2 == 5) f |= (1u << 3) | (1u << 4);
+    else if (s2 == 7) f |= (1u << 7) | (1u << 8);
+  }
+  if (t2 != t1 && t2 == 4) f |= (1u << 9) | (1u << 10);
+  if (s2 == 5 && t1 && t2 == t1) f |= (1u << 5) | (1u << 6);
+  return f;
+}
+
+/* iamf_recon_channels_order_update, IAMF_decoder.c:409-448 */
+static int recon_channel_order(int layout, uint32_t flags, int32_t *out) {
+  static const int map[9][12] = {
+      {CH_MONO, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+      {CH_L2, 0, CH_R2, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+      {CH_L5, CH_C, CH_R5, CH_SL5, CH_SR5, 0, 0, 0, 0, 0, 0, CH_LFE},
+      {CH_L5, CH_C, CH_R5, CH_SL5, CH_SR5, CH_HL, CH_HR, 0, 0, 0, 0, CH_LFE},
+      {CH_L5, CH_C, CH_R5, CH_SL5, CH_SR5, CH_HFL, CH_HFR, 0, 0, CH_HBL, CH_HBR, CH_LFE},
+      {CH_L7, CH_C, CH_R7, CH_SL7, CH_SR7, 0, 0, CH_BL7, CH_BR7, 0, 0, CH_LFE},
+      {CH_L7, CH_C, CH_R7, CH_SL7, CH_SR7, CH_HL, CH_HR, CH_BL7, CH_BR7, 0, 0, CH_LFE},
+      {CH_L7, CH_C, CH_R7, CH_SL7, CH_SR7, CH_HFL, CH_HFR, CH_BL7, CH_BR7, CH_HBL, CH_HBR, CH_LFE},
+      {CH_L3, CH_C, CH_R3, 0, 0, CH_TL, CH_TR, 0, 0, 0, 0, CH_LFE}};
+  int n = 0;
+  for (int c = 0; c < 12; ++c) /* recon_channel_order[] is the enum order */
+    if (flags & (1u << c)) out[n++] = map[layout][c];
+  return n;
+}
+
+static int popcount32(uint32_t v) {
+  int n = 0;
+  for (; v; ++n) v &= v - 1;
+  return n;
+}
 
 static float q_to_float(int16_t q, int frac) { return ((float)q) * powf(2.0f, (float)-frac); } /* fixedp11_5.c:45 */
 static float qf_to_float(uint8_t q, int frac) { return ((float)q / (pow(2.0f, (float)frac) - 1.0)); } /* :53 */
@@ -306,22 +437,43 @@ static int parse_element(struct IAMF_Decoder *d, const Obu *o) { /* IAMF_OBU.c:3
         e.demix_default_mode = rd_u8(&r) >> 5;
         e.demix_default_w = rd_u8(&r) >> 4;
         if (!param_get(d, &def, IAMF_PARAMETER_TYPE_DEMIXING)) return IAMF_ERR_ALLOC_FAIL;
+      } else {
+        Param *rp = param_get(d, &def, IAMF_PARAMETER_TYPE_RECON_GAIN);
+        if (!rp) return IAMF_ERR_ALLOC_FAIL;
+        if (!rp->rq) rp->rq = (ReconSeg *)calloc(MAX_QUEUE, sizeof(ReconSeg));
+        if (!rp->rq) return IAMF_ERR_ALLOC_FAIL;
+        e.has_recon = 1;
+        e.recon_pid = def.id;
       }
     } else {
       rd_skip(&r, rd_leb128(&r));
     }
   }
   if (e.type == AUDIO_ELEMENT_CHANNEL_BASED) {
-    int layers = rd_u8(&r) >> 5;
-    if (layers != 1) return IAMF_ERR_UNIMPLEMENTED; /* scalable layers need the demixer (upstream) */
-    uint8_t b = rd_u8(&r);
-    e.layout = b >> 4;
-    if ((b >> 3) & 1) return IAMF_ERR_UNIMPLEMENTED; /* output_gain_flag: demixer territory */
-    rd_u8(&r);                  /* substream count of the layer */
-    e.nb_coupled = rd_u8(&r);
-    if (e.layout > IA_CHANNEL_LAYOUT_312) return IAMF_ERR_UNIMPLEMENTED;
+    int layers = rd_u8(&r) >> 5, subs = 0;
+    if (layers < 1 || layers > MAX_LAYERS) return IAMF_ERR_UNIMPLEMENTED;
+    e.nlayers = layers;
+    for (int i = 0; i < layers; ++i) { /* IAMF_OBU.c:505-530 */
+      Layer *l = &e.layer[i];
+      uint8_t b = rd_u8(&r);
+      l->layout = b >> 4;
+      l->out_gain_flag = (b >> 3) & 1;
+      l->recon_flag = (b >> 2) & 1;
+      l->nsub = rd_u8(&r);
+      l->ncoupled = rd_u8(&r);
+      if (l->out_gain_flag) {
+        l->gain_flags = rd_u8(&r) >> 2;
+        l->gain_q = (int16_t)rd_u16(&r);
+      }
+      if (l->layout > IA_CHANNEL_LAYOUT_312) return IAMF_ERR_UNIMPLEMENTED;
+      subs += l->nsub;
+    }
+    if (subs != e.nsub) return IAMF_ERR_INVALID_PACKET;
+    /* the highest layer until an output layout selects another (iamf_stream_new, IAMF_decoder.c:1721-1724) */
+    e.layout = e.layer[layers - 1].layout;
+    e.nb_coupled = e.layer[0].ncoupled;
     e.channels = k_layout_channels[e.layout];
-    if (e.nsub + e.nb_coupled != e.channels) return IAMF_ERR_INVALID_PACKET;
+    if (layers == 1 && e.nsub + e.nb_coupled != e.channels) return IAMF_ERR_INVALID_PACKET;
   } else if (e.type == AUDIO_ELEMENT_SCENE_BASED) {
     uint64_t mode = rd_leb128(&r);
     if (mode == AMBISONICS_MONO) {
@@ -448,6 +600,20 @@ static int parse_parameter_block(struct IAMF_Decoder *d, const Obu *o) {
       }
     } else if (p->type == IAMF_PARAMETER_TYPE_DEMIXING) {
       g.anim = rd_u8(&r) >> 5;
+    } else if (p->type == IAMF_PARAMETER_TYPE_RECON_GAIN) { /* IAMF_OBU.c:1142-1195 */
+      const Element *re = 0;
+      ReconSeg *rs = &p->rq[p->qn];
+      for (int k = 0; k < d->nel; ++k)
+        if (d->el[k].has_recon && d->el[k].recon_pid == p->id) re = &d->el[k];
+      memset(rs, 0, sizeof(*rs));
+      for (int k = 0; re && k < re->nlayers; ++k) {
+        int n;
+        if (!re->layer[k].recon_flag) continue;
+        rs->flags[k] = (uint32_t)rd_leb128(&r);
+        n = popcount32(rs->flags[k]);
+        if (n > 12) return IAMF_ERR_INVALID_PACKET;
+        for (int t = 0; t < n; ++t) rs->gain[k][t] = qf_to_float(rd_u8(&r), 8);
+      }
     }
     if (r.err) return IAMF_ERR_INVALID_PACKET;
     /* iamf_database_parameter_add, IAMF_decoder.c:1042-1071 */
@@ -455,6 +621,26 @@ static int parse_parameter_block(struct IAMF_Decoder *d, const Obu *o) {
     p->duration += iv;
   }
   p->use_default = 0;
+  /* iamf_stream_decoder_update_parameter, IAMF_decoder.c:2141-2148: a recon-gain block updates the
+   * per-layer gains from the segment covering the middle of the current frame */
+  if (p->type == IAMF_PARAMETER_TYPE_RECON_GAIN && d->sel_el[0] && d->sel_el[0]->has_recon &&
+      d->sel_el[0]->recon_pid == p->id) {
+    const uint64_t pts = d->timestamp + d->frame_size / 2;
+    if (pts > p->timestamp && pts <= p->timestamp + p->duration) {
+      uint64_t start = pts - p->timestamp;
+      for (int i = 0; i < p->qn; ++i) {
+        if (start < p->q[i].interval) { /* iamf_stream_scale_decoder_update_recon_gain, :2238-2274 */
+          for (int k = 0; k < d->sel_el[0]->nlayers; ++k) {
+            if (!d->sel_el[0]->layer[k].recon_flag) continue;
+            d->layer_rec_flags[k] = p->rq[i].flags[k];
+            memcpy(d->layer_rec_gain[k], p->rq[i].gain[k], sizeof(d->layer_rec_gain[k]));
+          }
+          break;
+        }
+        start -= p->q[i].interval;
+      }
+    }
+  }
   /* iamf_stream_decoder_update_parameter, IAMF_decoder.c:2130-2151: a demixing block sets the
    * element's mode from the segment covering the middle of the current frame */
   if (p->type == IAMF_PARAMETER_TYPE_DEMIXING && d->sel_el[0] && d->sel_el[0]->has_demix &&
@@ -490,6 +676,7 @@ static void params_time_elapse(struct IAMF_Decoder *d, uint64_t duration) {
       p->duration -= p->q[0].interval;
       p->elapse -= p->q[0].interval;
       memmove(&p->q[0], &p->q[1], sizeof(GainSeg) * (size_t)(p->qn - 1));
+      if (p->rq) memmove(&p->rq[0], &p->rq[1], sizeof(ReconSeg) * (size_t)(p->qn - 1));
       p->qn--;
     }
   }
@@ -618,6 +805,8 @@ static void free_runtime(struct IAMF_Decoder *d) {
   if (d->d_mid) (void)hipFree(d->d_mid);
   if (d->d_res) (void)hipFree(d->d_res);
   if (d->d_dmx) (void)hipFree(d->d_dmx);
+  if (d->d_demix) (void)hipFree(d->d_demix);
+  d->d_demix = 0;
   if (d->d_pcm) (void)hipFree(d->d_pcm);
   d->d_mid = d->d_res = 0;
   d->d_dmx = 0;
@@ -651,6 +840,17 @@ static int element_matrix(const struct IAMF_Decoder *d, const Element *e, iamf_h
 /* channels per frame handed to the device: decoded channels for projection-mode ambisonics */
 static int element_in_channels(const Element *e) {
   return e->amb_projection ? e->nsub + e->amb_coupled : e->channels;
+}
+
+/* iamf_stream_set_output_layout, IAMF_decoder.c:1776-1822: which layer of a scalable element is decoded */
+static int select_layer(const struct IAMF_Decoder *d, const Element *e) {
+  if (e->nlayers == 1) return 0;
+  if (d->out_type == IAMF_LAYOUT_TYPE_BINAURAL) return e->nlayers - 1;
+  for (int i = 0; i < e->nlayers; ++i)
+    if (k_layout_ss[e->layer[i].layout] == (int)d->out_ss) return i;
+  for (int i = 0; i < e->nlayers; ++i)
+    if (k_layout_channels[e->layer[i].layout] > k_ss_channels[d->out_ss]) return i;
+  return e->nlayers - 1;
 }
 
 static Element *find_element(struct IAMF_Decoder *d, uint64_t id) {
@@ -708,6 +908,22 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
    * is a smaller IAMF layout (iamf_stream_renderer_enable_downmix, IAMF_decoder.c:2448-2478) */
   d->use_dmx = 0;
   d->demix_p = 0;
+  d->use_demix = 0;
+  for (int i = 0; i < p->nel; ++i) {
+    Element *e = d->sel_el[i];
+    if (e->type != AUDIO_ELEMENT_CHANNEL_BASED) continue;
+    {
+      int lay = select_layer(d, e), gains = 0;
+      for (int k = 0; k <= lay; ++k) gains |= e->layer[k].out_gain_flag;
+      e->layout = e->layer[lay].layout;
+      e->channels = k_layout_channels[e->layout];
+      if (e->nlayers > 1 || gains) {
+        if (i > 0) return IAMF_ERR_UNIMPLEMENTED; /* the batch runs the demixer in front of element 0 only */
+        d->use_demix = 1;
+        d->demix_layer = lay;
+      }
+    }
+  }
   {
     Element *e0 = d->sel_el[0];
     int out_layout = d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION ? k_ss_layout[d->out_ss] : -1;
@@ -741,6 +957,46 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   if (d->sel_el[0]->amb_projection &&
       iamf_hip_batch_set_projection(d->batch, d->sel_el[0]->proj, element_in_channels(d->sel_el[0])))
     return IAMF_ERR_INTERNAL;
+  if (d->use_demix) { /* iamf_stream_scale_demixer_configure, IAMF_decoder.c:2351-2386 */
+    const Element *e0 = d->sel_el[0];
+    iamf_hip_demix_config dc;
+    int last = -1;
+    memset(&dc, 0, sizeof(dc));
+    dc.layout = e0->layout;
+    d->demix_nsub = 0;
+    for (int l = 0; l <= d->demix_layer; ++l) {
+      const Layer *L = &e0->layer[l];
+      int n = layer_new_channels(last, L->layout, dc.chs_in + dc.n_in);
+      if (n != L->nsub + L->ncoupled || dc.n_in + n > 12) return IAMF_ERR_INVALID_PACKET;
+      dc.n_in += n;
+      d->demix_nsub += L->nsub;
+      last = L->layout;
+      if (L->out_gain_flag)
+        for (int c = 0; c < 6; ++c)
+          if (L->gain_flags & (1 << c)) {
+            int ch = output_gain_channel(L->layout, c);
+            if (ch != CH_INVALID) {
+              dc.gain_ch[dc.n_gain] = ch;
+              dc.gain[dc.n_gain++] = db2lin(q_to_float(L->gain_q, 8));
+            }
+          }
+    }
+    if (dc.n_in != k_layout_channels[e0->layout]) return IAMF_ERR_INVALID_PACKET;
+    d->demix_nch = dc.n_in;
+    /* iamf_stream_scale_decoder_set_default_recon_gain, :2202-2236 */
+    d->rec_flags = d->demix_layer > 0 ? recon_default_flags(e0->layer[0].layout, e0->layout) : 0;
+    d->rec_n = recon_channel_order(e0->layout, d->rec_flags, d->rec_ch);
+    for (int i = 0; i < 12; ++i) d->rec_gain[i] = 1.f;
+    memset(d->layer_rec_flags, 0, sizeof(d->layer_rec_flags));
+    dc.frame_offset = 0; /* LPCM has no decoder delay: demixer_set_frame_offset(0), IAMF_decoder.c:2175-2183 */
+    if (iamf_hip_batch_set_demixer(d->batch, &dc)) return IAMF_ERR_INTERNAL;
+    iamf_hip_demix_state_init(&d->dmst);
+    if (e0->has_demix) iamf_hip_demix_set_info(&d->dmst, e0->demix_default_mode, e0->demix_default_w);
+    d->dmx_mode = -1;
+    for (int i = 0; i < d->nparam; ++i)
+      if (e0->has_demix && d->param[i].id == e0->demix_pid) d->demix_p = &d->param[i];
+    if (hipMalloc((void **)&d->d_demix, sizeof(iamf_hip_demix_frame)) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+  }
   if (p->nel == 2 && d->sel_el[1]->amb_projection) return IAMF_ERR_UNIMPLEMENTED;
   if (p->nel == 2) {
     iamf_hip_matrix m2;
@@ -858,9 +1114,18 @@ static int unpack_element(struct IAMF_Decoder *d, int ei) {
   float *tmp = d->tmp;
   /* audio-layer order: coupled pairs first, then singles */
   int c = 0;
-  for (int s = 0; s < e->nsub; ++s) {
-    const int w = ((e->type == AUDIO_ELEMENT_CHANNEL_BASED && s < e->nb_coupled) ||
-                   (e->amb_projection && s < e->amb_coupled)) ? 2 : 1;
+  const int demix = ei == 0 && d->use_demix;
+  const int nsub = demix ? d->demix_nsub : e->nsub;
+  int lay = 0, lay_s0 = 0; /* layer of sub-stream s and its first sub-stream */
+  for (int s = 0; s < nsub; ++s) {
+    int w;
+    if (demix) { /* every layer: coupled sub-streams first (iamf_stream_scale_decoder_decode, :2276-2322) */
+      while (s >= lay_s0 + e->layer[lay].nsub) lay_s0 += e->layer[lay++].nsub;
+      w = s - lay_s0 < e->layer[lay].ncoupled ? 2 : 1;
+    } else {
+      w = ((e->type == AUDIO_ELEMENT_CHANNEL_BASED && s < e->nb_coupled) ||
+           (e->amb_projection && s < e->amb_coupled)) ? 2 : 1;
+    }
     const int n = (int)(d->pkt_len[ei][s] / (uint32_t)(w * bps));
     if (ns < 0) ns = n;
     if (n != ns || n > fs) return IAMF_ERR_INVALID_PACKET;
@@ -868,7 +1133,7 @@ static int unpack_element(struct IAMF_Decoder *d, int ei) {
       for (int k = 0; k < w; ++k) tmp[(size_t)(c + k) * fs + i] = lpcm_sample(d, d->pkt[ei][s] + (size_t)(i * w + k) * bps);
     c += w;
   }
-  if (e->amb_projection) { /* decoded channel order goes to the device: the de-mapping runs there */
+  if (e->amb_projection || demix) { /* decoded channel order goes to the device: de-mapping / demixer run there */
     for (int l = 0; l < c; ++l) memcpy(dst + (size_t)l * fs, tmp + (size_t)l * fs, sizeof(float) * ns);
     return ns;
   }
@@ -961,6 +1226,24 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     iamf_hip_dmx_coefficients(&d->dmx, fr.cur);
     if (hipMemcpyAsync(d->d_dmx, &fr, sizeof(fr), hipMemcpyHostToDevice, d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
     a.d_dmx_frames = d->d_dmx;
+  }
+  if (d->use_demix) { /* iamf_stream_scale_decoder_demix, IAMF_decoder.c:2324-2349 */
+    const Element *e0 = d->sel_el[0];
+    iamf_hip_demix_frame fr;
+    if (e0->layer[d->demix_layer].recon_flag) { /* demixer_set_recon_gain, demixer.c:620-634 */
+      const uint32_t lf = d->layer_rec_flags[d->demix_layer];
+      const int cnt = popcount32(lf);
+      if (lf && (lf ^ d->rec_flags)) {
+        d->rec_n = recon_channel_order(e0->layout, lf, d->rec_ch);
+        d->rec_flags = lf;
+      }
+      for (int i = 0; i < cnt && i < 12; ++i) d->rec_gain[i] = d->layer_rec_gain[d->demix_layer][i];
+    }
+    if (d->dmx_mode > -1) iamf_hip_demix_set_info(&d->dmst, d->dmx_mode, -1);
+    iamf_hip_demix_frame_fill(&d->dmst, d->rec_n, d->rec_ch, d->rec_gain, &fr);
+    if (hipMemcpyAsync(d->d_demix, &fr, sizeof(fr), hipMemcpyHostToDevice, d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
+    a.d_demix_frames = d->d_demix;
+    a.demix_sample0 = s0;
   }
   a.n_frames = 1;
   a.n_samples = keep < fs ? keep : 0;

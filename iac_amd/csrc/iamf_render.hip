@@ -373,6 +373,7 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     p.demix_tab = b->d_demix_tab;
     p.demix_ftab = b->d_demix_ftab;
     p.demix_frames = a.d_demix_frames;
+    p.demix_i0 = a.n_frames == 1 ? a.demix_sample0 : 0;
   }
   if (b->fir) {
     p.fir_taps = b->fir_taps;
@@ -597,7 +598,9 @@ int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *a) {
   if (a->n_frames == 0) return 0;
   if (b->has2 && !a->d_in2) return IAMF_HIP_ERR_BAD_ARG;
   if (b->dmx && !a->d_dmx_frames) return IAMF_HIP_ERR_BAD_ARG;
-  if (b->demix && a->d_in && !a->d_demix_frames) return IAMF_HIP_ERR_BAD_ARG;
+  if (b->demix && a->d_in && (!a->d_demix_frames || a->demix_sample0 < 0 ||
+                              a->demix_sample0 + (a->n_samples ? a->n_samples : 1) > b->cfg.frame_size))
+    return IAMF_HIP_ERR_BAD_ARG;
   if ((a->d_element_ramp || a->d_element2_ramp || a->d_output_ramp) &&
       a->ramp_stream_stride < (int64_t)a->n_frames * b->cfg.frame_size && b->cfg.n_streams > 1)
     return IAMF_HIP_ERR_BAD_ARG;
@@ -684,7 +687,7 @@ int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *matrix, int l_
 int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *c) {
   if (!b || !c || b->pos != 0 || b->fir || b->d_pre) return IAMF_HIP_ERR_BAD_ARG;
   if (c->layout < 0 || c->layout > 8 || c->n_in != kLayoutCount[c->layout] || c->n_in != b->m ||
-      c->n_gain < 0 || c->n_gain > 12 || c->n_recon < 0 || c->n_recon > 12)
+      c->n_gain < 0 || c->n_gain > 12)
     return IAMF_HIP_ERR_BAD_ARG;
   // which de-mix steps run: the reference reconstructs on demand (dmx_channel, demixer.c:379-424);
   // a step is skipped when its right-hand output is already there
@@ -711,7 +714,7 @@ int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *c
   auto h4 = [&]() { if (have[kChHBR]) return; h2(); if (!ok) return;
                     if (!have[kChHFR] || !have[kChHFL]) { ok = false; return; }
                     steps |= 32; have[kChHBL] = have[kChHBR] = true; };
-  int32_t tab[50];
+  int32_t tab[40];
   memset(tab, 0, sizeof(tab));
   for (int i = 0; i < c->n_in; ++i) {
     const int ch = kLayoutCh[c->layout][i];
@@ -743,11 +746,6 @@ int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *c
     ++ng;
   }
   tab[24] = ng;
-  tab[37] = c->n_recon;
-  for (int i = 0; i < c->n_recon; ++i) {
-    if (c->recon_ch[i] <= 0 || c->recon_ch[i] >= kChCount || !have[c->recon_ch[i]]) return IAMF_HIP_ERR_BAD_ARG;
-    tab[38 + i] = c->recon_ch[i];
-  }
   // demixer_open + demixer_set_frame_offset (demixer.c:476-567): Hann cross-fade of fs/16 samples
   // behind the first `skip` samples of every frame
   float *start = ft.data() + 12, *stop = start + fs;
@@ -828,8 +826,10 @@ void iamf_hip_demix_frame_fill(iamf_hip_demix_state *st, int n_recon, const int3
   demix_factors(st->last_mode, st->last_w_idx, out->prev);
   demix_factors(st->mode, st->w_idx, out->cur);
   const float N = 7;
-  for (int i = 0; i < n_recon && i < 12; ++i) {  // dmx_rms, demixer.c:447-478
-    const int ch = recon_ch[i];
+  out->n_recon = n_recon < 0 ? 0 : (n_recon > 12 ? 12 : n_recon);
+  for (int i = 0; i < out->n_recon; ++i) {  // dmx_rms, demixer.c:447-478
+    const int ch = recon_ch[i] > 0 && recon_ch[i] < 24 ? recon_ch[i] : 0;
+    out->recon_ch[i] = ch;
     const float sf = recon_gain ? recon_gain[i] : 1.0f;
     const float sfavg = (2 / (N + 1)) * sf + (1 - 2 / (N + 1)) * st->last_sfavg[ch];
     out->recon_prev[i] = st->last_sfavg[ch];

@@ -62,8 +62,8 @@ struct RenderParams {
   int32_t demix_on;
   int32_t demix_steps;      // bit 0 S1to2, 1 S2to3, 2 S3to5, 3 S5to7, 4 TF2toT2, 5 T2toT4
   int32_t demix_skip;       // samples at the start of every frame that use the previous mode
-  const int32_t *demix_tab; // device: [0..12) chs_in, [12..24) chs_out, [24] n_gain, [25..37) gain_ch,
-                            //         [37] n_recon, [38..50) recon_ch
+  int32_t demix_i0;         // frame position of the call's first sample (trimmed single-frame calls)
+  const int32_t *demix_tab; // device: [0..12) chs_in, [12..24) chs_out, [24] n_gain, [25..37) gain_ch
   const float *demix_ftab;  // device: [0..12) gains, then start_window[frame_size], stop_window[frame_size]
   const iamf_hip_demix_frame *demix_frames;  // device [n_streams][frames of this call]
   // ---- HRTF FIR renderer (render_fast_kernel<M, 2, true>): matrix = h[2][M][fir_taps] ----

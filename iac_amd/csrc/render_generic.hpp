@@ -102,7 +102,8 @@ __global__ __launch_bounds__(kChunk) void render_kernel(const RenderParams p) {
       // channel file (indexed by IAChannel) lives in its own LDS column.  x[] arrives in decoded
       // order and leaves in the target layout's playback order.
       const iamf_hip_demix_frame *fr = p.demix_frames + (int64_t)s * ((p.total + fs - 1) / fs) + fcur;
-      const bool use_prev = icur < p.demix_skip;
+      const int iw = icur + p.demix_i0;  // position inside the frame (windows, previous-mode prefix)
+      const bool use_prev = iw < p.demix_skip;
       float cf[5];
 #pragma unroll
       for (int j = 0; j < 5; ++j) cf[j] = use_prev ? fr->prev[j] : fr->cur[j];
@@ -138,11 +139,11 @@ __global__ __launch_bounds__(kChunk) void render_kernel(const RenderParams p) {
         CH(kChHBL) = (CH(kChHL) - CH(kChHFL)) / gamma;
         CH(kChHBR) = (CH(kChHR) - CH(kChHFR)) / gamma;
       }
-      const int n_recon = p.demix_tab[37];
-      const float wstart = p.demix_ftab[12 + icur], wstop = p.demix_ftab[12 + fs + icur];
+      const int n_recon = fr->n_recon;
+      const float wstart = p.demix_ftab[12 + iw], wstop = p.demix_ftab[12 + fs + iw];
       for (int r = 0; r < n_recon; ++r) {  // dmx_rms (:447-478)
         const float filt = fr->recon_prev[r] * wstop + fr->recon_cur[r] * wstart;
-        float &v = CH(p.demix_tab[38 + r]);
+        float &v = CH(fr->recon_ch[r]);
         v = v * filt;
       }
 #pragma unroll

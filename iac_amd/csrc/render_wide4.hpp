@@ -86,7 +86,6 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
   const int t = threadIdx.x;
   const int wave = t >> 6;
   const int lane = t & 63;
-  const int q = t & 3;
   const int fs = p.frame_size;
   const float thr = p.thr;
   const int n_atk = p.n_atk, n_end = p.n_end;
@@ -213,7 +212,6 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
     const int lane = tv & 63, q = tv & 3;
     const bool is_tail = tv >= kW4FirstTail;
     const int tl = is_tail ? tv - kW4FirstTail : 0;
-    const int k = c0 + 4 * tv;
     const int rp = ring_wrap(base + 4 * tv);
 
     // ---- element renderer + gains (reference operation order), 4 slots x 4 samples at a time ----

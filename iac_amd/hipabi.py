@@ -55,13 +55,12 @@ class RenderArgs(C.Structure):
                 ("d_output_ramp", C.c_void_p), ("ramp_stream_stride", C.c_int64),
                 ("d_dmx_frames", C.c_void_p), ("n_frames", C.c_int32), ("n_samples", C.c_int32),
                 ("d_pcm", C.c_void_p), ("pcm_stream_stride_bytes", C.c_int64), ("stream", C.c_void_p),
-                ("d_demix_frames", C.c_void_p)]
+                ("d_demix_frames", C.c_void_p), ("demix_sample0", C.c_int32)]
 
 
 class DemixConfig(C.Structure):
     _fields_ = [("layout", C.c_int32), ("n_in", C.c_int32), ("chs_in", C.c_int32 * 12), ("n_gain", C.c_int32),
-                ("gain_ch", C.c_int32 * 12), ("gain", C.c_float * 12), ("n_recon", C.c_int32),
-                ("recon_ch", C.c_int32 * 12), ("frame_offset", C.c_uint32)]
+                ("gain_ch", C.c_int32 * 12), ("gain", C.c_float * 12), ("frame_offset", C.c_uint32)]
 
 
 class DemixState(C.Structure):
@@ -70,8 +69,8 @@ class DemixState(C.Structure):
 
 
 class DemixFrame(C.Structure):
-    _fields_ = [("prev", C.c_float * 5), ("cur", C.c_float * 5), ("recon_prev", C.c_float * 12),
-                ("recon_cur", C.c_float * 12)]
+    _fields_ = [("prev", C.c_float * 5), ("cur", C.c_float * 5), ("n_recon", C.c_int32),
+                ("recon_ch", C.c_int32 * 12), ("recon_prev", C.c_float * 12), ("recon_cur", C.c_float * 12)]
 
 
 def lib_path():
@@ -244,16 +243,14 @@ class Batch:
         if r != 0:
             raise IamfHipError(r, "iamf_hip_batch_set_projection")
 
-    def set_demixer(self, layout, chs_in, gains=(), recon=(), frame_offset=0):
-        """gains: [(IAChannel, linear gain)], recon: [IAChannel] (reference demixer.c)"""
+    def set_demixer(self, layout, chs_in, gains=(), frame_offset=0):
+        """gains: [(IAChannel, linear gain)] (reference demixer.c)"""
         c = DemixConfig()
-        c.layout, c.n_in, c.n_gain, c.n_recon, c.frame_offset = layout, len(chs_in), len(gains), len(recon), frame_offset
+        c.layout, c.n_in, c.n_gain, c.frame_offset = layout, len(chs_in), len(gains), frame_offset
         for i, ch in enumerate(chs_in):
             c.chs_in[i] = ch
         for i, (ch, g) in enumerate(gains):
             c.gain_ch[i], c.gain[i] = ch, g
-        for i, ch in enumerate(recon):
-            c.recon_ch[i] = ch
         r = lib().iamf_hip_batch_set_demixer(self.h, C.byref(c))
         if r != 0:
             raise IamfHipError(r, "iamf_hip_batch_set_demixer")

@@ -198,8 +198,6 @@ typedef struct iamf_hip_demix_config {
   int32_t n_gain;         /* demixer_set_output_gain */
   int32_t gain_ch[12];
   float gain[12];
-  int32_t n_recon;        /* channels of demixer_set_recon_gain */
-  int32_t recon_ch[12];
   uint32_t frame_offset;  /* demixer_set_frame_offset: the codec's delay (0 for LPCM) */
 } iamf_hip_demix_config;
 
@@ -217,14 +215,16 @@ typedef struct iamf_hip_demix_state {
 typedef struct iamf_hip_demix_frame {
   float prev[5], cur[5];            /* alpha, beta, gamma, delta, w of the previous / current mode:
                                        the first frame_offset % frame_size samples use prev */
+  int32_t n_recon;                  /* channels of demixer_set_recon_gain valid for this frame: decoded or */
+  int32_t recon_ch[12];             /* reconstructed channels of the target layout */
   float recon_prev[12], recon_cur[12]; /* per recon channel: smoothed gain of the last frame / of this one */
 } iamf_hip_demix_frame;
 
 void iamf_hip_demix_state_init(iamf_hip_demix_state *st);
 /* replaces demixer_set_demixing_info: 0 or IAMF_HIP_ERR_BAD_ARG (then nothing changes) */
 int iamf_hip_demix_set_info(iamf_hip_demix_state *st, int mode, int w_idx);
-/* fills one frame record from the state and the recon gains valid for this frame (recon_gain[i]
- * belongs to recon_ch[i] of the config; NULL = no recon channels), and advances the smoothing */
+/* fills one frame record from the state and the recon channels / gains valid for this frame
+ * (recon_gain[i] belongs to recon_ch[i]), and advances the smoothing */
 void iamf_hip_demix_frame_fill(iamf_hip_demix_state *st, int n_recon, const int32_t *recon_ch,
                                const float *recon_gain, iamf_hip_demix_frame *out);
 
@@ -248,6 +248,8 @@ typedef struct {
   int64_t pcm_stream_stride_bytes;
   void *stream;
   const iamf_hip_demix_frame *d_demix_frames; /* with a demixer: [n_streams][n_frames] on the device */
+  int32_t demix_sample0;        /* with a demixer and n_frames == 1: position inside its frame of the call's
+                                   first sample (a frame whose start was trimmed before the call) */
 } iamf_hip_render_args;
 
 /* Extended form of iamf_hip_batch_render; same return value. */

@@ -64,7 +64,27 @@ CASES = {
     # projection-mode ambisonics: 10 sub-streams (6 coupled) -> 16 decoded channels -> Q15 de-mapping
     # matrix -> 16 ambisonics channels (IAMF_core_decoder.c:116-130,228-252)
     "toa_projection_B_s16": dict(layout=_ss_layout("B"), bit_depth=16, frames=5, fs=1024, seed=55),
+    # scalable channel audio (N2): stereo -> 5.1.2 -> 7.1.4 with output gains on the first two layers,
+    # recon-gain and demixing parameter blocks; the output layout selects the layer that is decoded
+    # (IAMF_decoder.c:1776-1822), the demixer rebuilds the rest (demixer.c)
+    "scalable_J_s16": dict(layout=_ss_layout("J"), bit_depth=16, frames=8, fs=1024, seed=56, scalable=True),
+    "scalable_C_s16": dict(layout=_ss_layout("C"), bit_depth=16, frames=8, fs=1024, seed=56, scalable=True),
+    "scalable_A_s16": dict(layout=_ss_layout("A"), bit_depth=16, frames=8, fs=1024, seed=56, scalable=True),
+    "scalable_binaural_s24": dict(layout=("binaural",), bit_depth=24, frames=8, fs=1024, seed=56, scalable=True),
+    "scalable_B_s16": dict(layout=_ss_layout("B"), bit_depth=16, frames=8, fs=1024, seed=56, scalable=True),
+    # 3.1.2 output: no layer matches -> 5.1.2 is decoded and demixed, then the parametric down-mixer
+    # renders 5.1.2 -> 3.1.2 with the same demixing modes
+    "scalable_312_dmx_s16": dict(layout=("ss", 11), bit_depth=16, frames=8, fs=1024, seed=56, scalable=True),
 }
+
+SCALABLE_LAYERS = [1, 3, 7]
+SCALABLE_GAINS = {0: (0b110000, -768), 1: (0b001111, 384)}   # layer -> (flags, q7.8 dB)
+SCALABLE_MODES = [1, 1, 2, 4, 5, 6, 0, 2]
+
+
+def scalable_recon_bytes(frame, n):
+    rng = np.random.default_rng(5600 + frame)
+    return [int(v) for v in rng.integers(100, 256, size=n)]
 
 
 def _channel_element(eid, layout, x_playback, first_sid, sample_size):
@@ -169,6 +189,39 @@ def build(name):
         for f in range(F):
             stream += W.temporal_delimiter()
             subs = [(i, W.lpcm_bytes(xq[i:i + 1, f * fs:(f + 1) * fs], ss)) for i in range(16)]
+            stream += W.audio_frames(subs)
+    elif c.get("scalable"):
+        import demix_cases as D
+        layers = SCALABLE_LAYERS
+        order, per_layer = D.channels_order(layers)
+        xd = W.quantize(synth.hot(c["seed"], len(order), n, sigma=0.15, burst_amp=0.45, burst_phase=600,
+                                  burst_period=2700).clip(-1, 1 - 2 ** -15).astype(np.float32), ss)
+        wl, sid = [], 0
+        for li, (lay, pl) in enumerate(zip(layers, per_layer)):
+            # recon gains ride on the layers above the first: flags = what that layer needs rebuilt
+            rf = D.recon_flags(layers[0], lay) if li else 0
+            wl.append(dict(layout=lay, nsub=pl["substreams"], ncoupled=pl["coupled"],
+                           out_gain=SCALABLE_GAINS.get(li), recon=bool(rf), recon_flags=rf))
+        nsub = sum(l["nsub"] for l in wl)
+        stream += W.audio_element_scalable(1, 0, wl, list(range(nsub)),
+                                           demixing=dict(pid=200, rate=rate, frame=fs, mode=1, w=3),
+                                           recon=dict(pid=201, rate=rate, frame=fs))
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100), default_q78=eg)],
+                                     dict(pdef=_pdef_static(101), default_q78=og), layouts_field)
+        info["elements"].append(dict(kind="scalable", layers=layers, order=order, x=xd, wl=wl))
+        for f in range(F):
+            stream += W.temporal_delimiter()
+            stream += W.demixing_block(200, SCALABLE_MODES[f])
+            if True:   # a block per frame: the reference's parameter timeline does not survive gaps
+                stream += W.recon_gain_block(201, [(l["recon_flags"], scalable_recon_bytes(f, bin(l["recon_flags"]).count("1")))
+                                                   for l in wl if l["recon"]])
+            subs, ch, sid = [], 0, 0
+            for l in wl:
+                for k in range(l["nsub"]):
+                    w = 2 if k < l["ncoupled"] else 1
+                    subs.append((sid, W.lpcm_bytes(xd[ch:ch + w, f * fs:(f + 1) * fs], ss)))
+                    ch += w
+                    sid += 1
             stream += W.audio_frames(subs)
     elif name == "toa_projection_B_s16":
         subs_n, coupled = 10, 6

@@ -29,6 +29,51 @@ def element_matrix(el, out_id):
     return O.get_m2m(LAYOUT_RID[el["layout"]], out_id)
 
 
+LAYOUT_SS = [12, 0, 1, 2, 3, 8, 10, 9, 11]   # layer layout -> IAMF_SoundSystem (IAMF_decoder.c:268-275)
+LAYOUT_CH = [1, 2, 6, 8, 10, 8, 10, 12, 6]
+SS_CH = [2, 6, 8, 10, 11, 12, 14, 24, 8, 12, 10, 6, 1]
+
+
+def select_layer(layers, layout):
+    """iamf_stream_set_output_layout, IAMF_decoder.c:1776-1822"""
+    if len(layers) == 1:
+        return 0
+    if layout[0] != "ss":
+        return len(layers) - 1
+    for i, l in enumerate(layers):
+        if LAYOUT_SS[l] == layout[1]:
+            return i
+    for i, l in enumerate(layers):
+        if LAYOUT_CH[l] > SS_CH[layout[1]]:
+            return i
+    return len(layers) - 1
+
+
+def demix_scalable(el, c):
+    """decoded channels of the layers up to the selected one -> target layout in playback order, frame
+    by frame through the oracle's demixer the way IAMF_decoder.c:2324-2386 drives the reference's"""
+    import demix_cases as D
+    import e2e_cases
+    li = select_layer(el["layers"], c["layout"])
+    layers = el["layers"][:li + 1]
+    order, _ = D.channels_order(layers)
+    layout = layers[-1]
+    gains = D.output_gain_list(layers, {k: (f, q78_to_lin(q)) for k, (f, q) in e2e_cases.SCALABLE_GAINS.items() if k <= li})
+    flags = D.recon_flags(layers[0], layout) if li else 0
+    rec = D.recon_order(layout, flags)
+    sched = []
+    for f in range(c["frames"]):
+        rg = None
+        if rec and el["wl"][li]["recon"]:   # qf_to_float(byte, 8): double division, then float (fixedp11_5.c:53)
+            rg = [float(np.float32(np.float64(np.float32(v)) / 255.0)) for v in e2e_cases.scalable_recon_bytes(f, len(rec))]
+        sched.append((e2e_cases.SCALABLE_MODES[f], rg))
+    case = dict(layout=layout, order=order, gains=gains, default=(1, 3), recon=rec, flags=flags, offset=0,
+                fs=c["fs"], schedule=sched)
+    x = el["x"][:len(order)].reshape(len(order), c["frames"], c["fs"]).transpose(1, 0, 2)
+    y = D.drive_demixer(O.lib(), "orc_demixer_", case, x)
+    return layout, np.ascontiguousarray(y.transpose(1, 0, 2).reshape(len(order), -1))
+
+
 def run_case(info):
     c = info["case"]
     out_id = out_id_of(c["layout"])
@@ -37,7 +82,11 @@ def run_case(info):
     gains_q = [c.get("element_gain_q78", 0)] + [0] * (len(info["elements"]) - 1)
     ys = []
     for el, gq in zip(info["elements"], gains_q):
-        y = O.render(element_matrix(el, out_id), el["x"], ch)
+        if el["kind"] == "scalable":
+            layout, xd = demix_scalable(el, c)
+            y = O.render(O.get_m2m(LAYOUT_RID[layout], out_id), xd, ch)
+        else:
+            y = O.render(element_matrix(el, out_id), el["x"], ch)
         g = q78_to_lin(gq)
         O.lib().orc_frame_gain_const(O.fp(y), ch, y.shape[1], g)
         ys.append(y)

@@ -130,6 +130,41 @@ def mix_presentation(mid, elements, output_gain, layouts, loudness_q78=0):
     return obu(OBU_MIX_PRESENTATION, p)
 
 
+def audio_element_scalable(eid, cid, layers, substream_ids, demixing=None, recon=None):
+    """scalable channel audio (IAMF_OBU.c:491-530): layers = [dict(layout, nsub, ncoupled,
+    out_gain=(6-bit flags, q7.8 dB) or None, recon=bool)]; demixing / recon = dict(pid, rate, frame, ...)"""
+    p = leb128(eid) + bytes([0 << 5]) + leb128(cid) + leb128(len(substream_ids))
+    for s in substream_ids:
+        p += leb128(s)
+    p += leb128((1 if demixing else 0) + (1 if recon else 0))
+    if demixing:
+        p += leb128(1)
+        p += param_definition(demixing["pid"], demixing["rate"], mode=0, duration=demixing["frame"],
+                              constant_interval=demixing["frame"])
+        p += bytes([(demixing["mode"] & 7) << 5, (demixing["w"] & 15) << 4])
+    if recon:
+        p += leb128(2)
+        p += param_definition(recon["pid"], recon["rate"], mode=0, duration=recon["frame"],
+                              constant_interval=recon["frame"])
+    p += bytes([len(layers) << 5])
+    for l in layers:
+        og = l.get("out_gain")
+        p += bytes([(l["layout"] << 4) | ((1 if og else 0) << 3) | ((1 if l.get("recon") else 0) << 2)])
+        p += bytes([l["nsub"], l["ncoupled"]])
+        if og:
+            p += bytes([(og[0] & 0x3f) << 2]) + struct.pack(">h", og[1])
+    return obu(OBU_AUDIO_ELEMENT, p)
+
+
+def recon_gain_block(pid, per_layer):
+    """per_layer: for every layer WITH recon_gain_flag, in layer order, (flags, [gain bytes])"""
+    p = leb128(pid)
+    for flags, gains in per_layer:
+        assert bin(flags).count("1") == len(gains)
+        p += leb128(flags) + bytes(gains)
+    return obu(OBU_PARAMETER_BLOCK, p)
+
+
 def mix_gain_block(pid, segments, mode1=None):
     """segments: list of dict(anim, start, end=, control=, rel_time=) in q7.8 dB; when the
     parameter definition has mode 1 the block carries duration/interval itself (mode1 =

@@ -307,7 +307,7 @@ def test_demixer_stage_matches_reference(hip, golden):
         x = D.case_input(c)                      # [frames][ch][fs]
         F, ch, fs = x.shape
         b = A.Batch(1, G.identity_matrix(ch), ch, frame_size=fs, out_format=A.FMT_F32, limiter=False)
-        b.set_demixer(c["layout"], c["order"], c["gains"], c["recon"], c["offset"])
+        b.set_demixer(c["layout"], c["order"], c["gains"], c["offset"])
         st = A.DemixState()
         A.lib().iamf_hip_demix_state_init(C.byref(st))
         A.lib().iamf_hip_demix_set_info(C.byref(st), c["default"][0], c["default"][1])
