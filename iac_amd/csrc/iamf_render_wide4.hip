@@ -48,7 +48,8 @@ bool launch_m(const RenderParams &p, hipStream_t st) {
 
 // 1 if a render_wide4_kernel instance exists for m inputs and c output channels
 extern "C" __attribute__((visibility("hidden"))) int iamf_hip_wide4_has(int m, int c) {
-  return (m == 12 || m == 16) && (c == 6 || c == 8 || c == 10 || c == 12 || c == 24);
+  return (m == 4 || m == 6 || m == 8 || m == 9 || m == 10 || m == 12 || m == 16) &&
+         (c == 6 || c == 8 || c == 10 || c == 12 || c == 24);
 }
 
 // params: the caller's RenderParams (same definition, render_common.hpp); returns 1 if launched
@@ -56,6 +57,11 @@ extern "C" __attribute__((visibility("hidden"))) int iamf_hip_wide4_launch(const
   RenderParams p;
   memcpy(&p, params, sizeof(p));
   switch (m) {
+    case 4: return launch_m<4>(p, st) ? 1 : 0;
+    case 6: return launch_m<6>(p, st) ? 1 : 0;
+    case 8: return launch_m<8>(p, st) ? 1 : 0;
+    case 9: return launch_m<9>(p, st) ? 1 : 0;
+    case 10: return launch_m<10>(p, st) ? 1 : 0;
     case 12: return launch_m<12>(p, st) ? 1 : 0;
     case 16: return launch_m<16>(p, st) ? 1 : 0;
     default: return 0;

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       // weights of MB inputs x 4 slots per LDS batch, the next batch fetched while this one is
       // multiplied (explicit double buffer: left alone the scheduler hoists a whole group's
       // weight reads and runs out of registers)
-      constexpr int MB = C >= 24 ? 1 : 2, NB_M = M / MB, G = C4 / 4;
+      constexpr int MB = (C >= 24 || (M & 1)) ? 1 : 2, NB_M = M / MB, G = C4 / 4;
       static_assert(M % MB == 0, "inputs per batch");
       float4 wc[MB], wn[MB];
 #pragma unroll

@@ -22,17 +22,25 @@ def hip():
 LAYOUTS = ["B", "C", "D", "J", "H"]  # 6, 8, 10, 12, 24 channels
 
 
+SOURCES = dict(L714=12, L514=10, L71=8, L51=6, TOA=16, SOA=9, FOA=4)
+
+
 @pytest.mark.parametrize("out", LAYOUTS)
-@pytest.mark.parametrize("src", ["L714", "TOA"])
+@pytest.mark.parametrize("src", sorted(SOURCES))
 def test_wide4_exact_multi_stream_multi_call(hip, src, out):
     A, G = hip
     S, fs, F = 3, 1024, 5
     oid = A.SS[out]
     ch = A.layout_channels(oid)
-    if src == "TOA":
-        m, mx, omx = 16, A.get_h2m_matrix(3, oid), O.get_h2m(3, O.SS[out])
+    m = SOURCES[src]
+    if src in ("TOA", "SOA", "FOA"):
+        order = {"TOA": 3, "SOA": 2, "FOA": 1}[src]
+        mx, omx = A.get_h2m_matrix(order, oid), O.get_h2m(order, O.SS[out])
     else:
-        m, mx, omx = 12, A.get_m2m_matrix(A.SS["L714"], oid), O.get_m2m(O.SS["L714"], O.SS[out])
+        try:
+            mx, omx = A.get_m2m_matrix(A.SS[src], oid), O.get_m2m(O.SS[src], O.SS[out])
+        except KeyError:
+            pytest.skip("the reference has no %s -> %s matrix" % (src, out))
     x = np.stack([synth.hot(900 + 7 * s, m, F * fs, sigma=0.22, burst_phase=150 + 400 * s, burst_period=2300)
                   for s in range(S)])
     eg, og = [0.8, 1.0, 1.2], [1.0, 0.9, 1.0]
@@ -63,14 +71,16 @@ def test_wide4_mfma_state_handoff_within_1lsb(hip):
     fs, calls = 1024, [1, 3, 2]
     F = sum(calls)
     x = synth.hot(77, 16, F * fs, sigma=0.2, burst_phase=500, burst_period=2100)[None]
-    for out in ("B", "J", "H"):
-        oid = A.SS[out]
-        ch = A.layout_channels(oid)
-        got = G.hip_render(A.get_h2m_matrix(3, oid), ch, x, frame_size=fs, flush=True, frames_per_call=calls,
-                           projection=A.PROJ_MFMA)[0]
-        want = O.stream_run(O.get_h2m(3, O.SS[out]), ch, x[0], fs)
-        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
-        assert got.shape == want.shape and d.max() <= 1, (out, int(d.max()))
+    for order in (3, 2, 1):
+        m = (order + 1) ** 2
+        for out in ("B", "J", "H"):
+            oid = A.SS[out]
+            ch = A.layout_channels(oid)
+            got = G.hip_render(A.get_h2m_matrix(order, oid), ch, x[:, :m], frame_size=fs, flush=True,
+                               frames_per_call=calls, projection=A.PROJ_MFMA)[0]
+            want = O.stream_run(O.get_h2m(order, O.SS[out]), ch, x[0, :m], fs)
+            d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+            assert got.shape == want.shape and d.max() <= 1, (order, out, int(d.max()))
 
 
 def test_wide4_quiet_signal_never_triggers(hip):
