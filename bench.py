@@ -175,6 +175,8 @@ def main():
     for i in range(args.warmup):
         pipe.step(render_into)
     pipe.drain()
+    if world > 1 and args.gather == "final":   # untimed: sets up RCCL's point-to-point connections
+        dist.gather(pcm[0], final_recv, dst=0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -186,14 +188,22 @@ def main():
     for i in range(args.steps):
         emitted += pipe.step(lambda buf, i=i: render_into(buf, ev[i]))
     pipe.drain()
-    if world > 1 and args.gather == "final":
-        # the job's one exchange: every rank's packed PCM of the last step -> rank 0 (RCCL over xGMI)
-        dist.gather(pcm[(args.steps - 1) % 2], final_recv, dst=0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gather_ms = None
+    if world > 1 and args.gather == "final":
+        # the job's one exchange: every rank's packed PCM of the last step -> rank 0 (RCCL over xGMI).
+        # It happens once per job whatever the number of steps, so it is timed on its own and
+        # reported beside the K-step rate instead of being folded into it.
+        tg = time.perf_counter()
+        dist.gather(pcm[(args.steps - 1) % 2], final_recv, dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
     assert emitted >= args.steps * F * fs - 240, "every step must emit its F*fs sample-frames per stream"
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -226,6 +236,8 @@ def main():
                        "out_channels": out_ch, "pcm": "s16", "limiter": "-1 dBFS, 240 look-ahead",
                        "signal": "hot (sigma 0.25 + 1.5 bursts)" if args.signal == "hot" else "quiet (sigma 0.05)", "parallelism": "streams sharded, dp%d" % world,
                        "gather": args.gather if world > 1 else "n/a (1 GPU)"},
+            "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "gather_bytes_per_rank": stride_bytes * S if world > 1 and args.gather == "final" else None,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": round(traffic[0]) if traffic else None,
