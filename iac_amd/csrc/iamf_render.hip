@@ -256,6 +256,8 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
   dim3 grid((unsigned)p.n_streams);
   if (p.fir_taps > 0 && p.in) {  // HRTF renderer: aligned calls only (the flush goes to the generic kernel)
     if (!fast_path_ok(p)) return IAMF_HIP_ERR_UNIMPLEMENTED;
+    // the FIR stage keeps input offsets of one stream as 32-bit integers
+    if (((int64_t)(p.total / p.frame_size) + 1) * p.in_frame_stride >= (int64_t)1 << 31) return IAMF_HIP_ERR_BAD_ARG;
     switch (m) {
       case 1: launch_fir_m<1>(p, grid, st); break;
       case 4: launch_fir_m<4>(p, grid, st); break;

@@ -62,11 +62,31 @@ __device__ __forceinline__ void fir_stage(const RenderParams &p, const float *in
   float *xs = fir;                   // [half][buf][kFirXs]
   float *hp = fir + 2 * 2 * kFirXs;  // [half][buf][ear][kFirHp]
 
+  // where this thread's 10 slice samples come from does not depend on the channel: >= 0 = offset in
+  // the channel's plane of the call's input, -1 = past the end of the call (zero), <= -2 = history
+  int off[10];
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const int n = c0 - kFirHist + th + 128 * r;
+    if (n < 0) {
+      off[r] = -2 - (kFirHist + n);
+    } else if (n >= p.total) {
+      off[r] = -1;
+    } else {
+      const int f = n / p.frame_size;
+      off[r] = (int)(f * p.in_frame_stride) + (n - f * p.frame_size);
+    }
+  }
   float xr[10], hr[5];
   auto fetch = [&](int ci) {  // global -> registers for channel ci of this half
     const int ch = ch0 + (ci < my_n ? ci : 0);
+    const float *plane = in_s + (int64_t)ch * p.frame_size;
+    const float *hch = hist + ch * kFirHist;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) xr[r] = fir_input(p, in_s, hist, ch, c0 - kFirHist + th + 128 * r);
+    for (int r = 0; r < 10; ++r) {
+      const int o = off[r];
+      xr[r] = o >= 0 ? plane[o] : (o == -1 ? 0.f : hch[-2 - o]);
+    }
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
       const int j = th + 128 * r;  // 0..639 >= 2 * kFirHp = [ear][kFirHp]
