@@ -183,7 +183,7 @@ void launch_fir_m(const RenderParams &p, dim3 grid, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     opted = true;
   }
-  hipLaunchKernelGGL((render_fast_kernel<M, 2, true>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((render_fast_kernel<M, 2, true>), grid, dim3(512), lds, st, p);  // 8 waves: see render_fir.hpp
 }
 
 template <int M>

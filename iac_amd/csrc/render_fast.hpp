@@ -168,8 +168,10 @@ __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
   return i >= kFRing ? i - kFRing : i;
 }
 
+// The HRTF variant runs 512 threads: all eight waves work in fir_stage (ear x quarter of the
+// channels), waves 0..3 alone (`act`) run the stages around it.
 template <int M, int OC, bool FIR = false>
-__global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) {
+__global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kernel(const RenderParams p) {
   extern __shared__ float lds[];
   constexpr int R = kFRing;
   constexpr int NB = R / 16;
@@ -189,7 +191,8 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
   float *fir = misc + 16;               // [kFirLdsFloats]  HRTF staging (FIR variant only)
 
   const int s = blockIdx.x;
-  const int t = threadIdx.x;
+  const bool act = !FIR || threadIdx.x < 256;
+  const int t = FIR ? (int)(threadIdx.x & 255) : (int)threadIdx.x;  // helper waves keep indices in range
   const int wave = t >> 6;
   const int lane = t & 63;
   const int q = t & 3;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
   int base = (int)(p.pos0 % R);  // ring position of the chunk's first sample; multiple of 16
 
   // ---- stream state and constants -> LDS (persisted format is the generic kernel's) ----
-  {
+  if (act) {
     const float *sy = p.ring_y + (int64_t)s * OC * kSave;
     const float *spm = p.ring_pm + (int64_t)s * kSave;
     const int rp = ring_wrap(base - kSave + t);  // saved entry t is sample pos0 - 256 + t
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
   for (int c0 = 0; c0 < p.total; c0 += kFChunk) {
     const int cnt = p.total - c0 < kFChunk ? p.total - c0 : kFChunk;  // multiple of 64
     const int k = c0 + 4 * t;
-    const bool valid = 4 * t < cnt;
+    const bool valid = act && 4 * t < cnt;
     const int64_t gk = p.pos0 + k;
     const int rp = ring_wrap(base + 4 * t);
 
@@ -272,16 +275,19 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     float4 y[OC];
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (FIR) fir_stage<M>(p, in_s, fir_hist, c0, fir, fir);  // both ears of the chunk -> LDS partials
+    if (act)
 #pragma unroll
     for (int c = 0; c < OC; ++c) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (FIR) {
-        const float *p0 = fir + c * (kFChunk + 32), *p1 = fir + (c + 2) * (kFChunk + 32);
+        // ear c: the partial sums of the four channel quarters (waves c, c+2, c+4, c+6), in that order
+        const float *p0 = fir + c * (kFChunk + 32);
         const int u = 4 * t + ((4 * t) >> 5);  // padded index; 4 consecutive samples stay in one 32-block
-        v.x = p0[u + 0] + p1[u + 0];
-        v.y = p0[u + 1] + p1[u + 1];
-        v.z = p0[u + 2] + p1[u + 2];
-        v.w = p0[u + 3] + p1[u + 3];
+        constexpr int PS = 2 * (kFChunk + 32);
+        v.x = ((p0[u + 0] + p0[PS + u + 0]) + p0[2 * PS + u + 0]) + p0[3 * PS + u + 0];
+        v.y = ((p0[u + 1] + p0[PS + u + 1]) + p0[2 * PS + u + 1]) + p0[3 * PS + u + 1];
+        v.z = ((p0[u + 2] + p0[PS + u + 2]) + p0[2 * PS + u + 2]) + p0[3 * PS + u + 2];
+        v.w = ((p0[u + 3] + p0[PS + u + 3]) + p0[2 * PS + u + 3]) + p0[3 * PS + u + 3];
       } else if (live[c]) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -323,58 +329,62 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     }
 
     // ---- per-16 prefix / suffix / block maxima: 4 lanes x 4 samples = one aligned block ----
-    const float i0 = pm.x, i1 = fmaxf(i0, pm.y), i2 = fmaxf(i1, pm.z), i3 = fmaxf(i2, pm.w);
-    const float s3 = pm.w, s2 = fmaxf(pm.z, s3), s1 = fmaxf(pm.y, s2), s0 = fmaxf(pm.x, s1);
-    const float qa = dpp_quad_bcast0(i3), qb = dpp_quad_bcast1(i3), qc = dpp_quad_bcast2(i3),
-                qd = dpp_quad_bcast3(i3);
-    const float before = q == 0 ? 0.f : (q == 1 ? qa : (q == 2 ? fmaxf(qa, qb) : fmaxf(fmaxf(qa, qb), qc)));
-    const float after = q == 3 ? 0.f : (q == 2 ? qd : (q == 1 ? fmaxf(qc, qd) : fmaxf(fmaxf(qb, qc), qd)));
-    const float4 pre_ex = make_float4(before, fmaxf(before, i0), fmaxf(before, i1), fmaxf(before, i2));
-    if (valid) {
+    float4 pre_ex = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) {
+      const float i0 = pm.x, i1 = fmaxf(i0, pm.y), i2 = fmaxf(i1, pm.z), i3 = fmaxf(i2, pm.w);
+      const float s3 = pm.w, s2 = fmaxf(pm.z, s3), s1 = fmaxf(pm.y, s2), s0 = fmaxf(pm.x, s1);
+      const float qa = dpp_quad_bcast0(i3), qb = dpp_quad_bcast1(i3), qc = dpp_quad_bcast2(i3),
+                  qd = dpp_quad_bcast3(i3);
+      const float before = q == 0 ? 0.f : (q == 1 ? qa : (q == 2 ? fmaxf(qa, qb) : fmaxf(fmaxf(qa, qb), qc)));
+      const float after = q == 3 ? 0.f : (q == 2 ? qd : (q == 1 ? fmaxf(qc, qd) : fmaxf(fmaxf(qb, qc), qd)));
+      pre_ex = make_float4(before, fmaxf(before, i0), fmaxf(before, i1), fmaxf(before, i2));
+      if (valid) {
 #pragma unroll
-      for (int c = 0; c < OC; ++c) *reinterpret_cast<float4 *>(&ring_y[c * R + rp]) = y[c];
-      *reinterpret_cast<float4 *>(&ring_pm[rp]) = pm;
-      *reinterpret_cast<float4 *>(&ring_suf[rp]) =
-          make_float4(fmaxf(s0, after), fmaxf(s1, after), fmaxf(s2, after), fmaxf(s3, after));
-      if (q == 0) ring_bm[rp >> 4] = fmaxf(fmaxf(qa, qb), fmaxf(qc, qd));
+        for (int c = 0; c < OC; ++c) *reinterpret_cast<float4 *>(&ring_y[c * R + rp]) = y[c];
+        *reinterpret_cast<float4 *>(&ring_pm[rp]) = pm;
+        *reinterpret_cast<float4 *>(&ring_suf[rp]) =
+            make_float4(fmaxf(s0, after), fmaxf(s1, after), fmaxf(s2, after), fmaxf(s3, after));
+        if (q == 0) ring_bm[rp >> 4] = fmaxf(fmaxf(qa, qb), fmaxf(qc, qd));
+      }
     }
     __syncthreads();
 
     // ---- 240-sample window maximum = tail of block b-15, blocks b-14..b-1, head of block b ----
-    const int bpos = rp >> 4;
-    float w14 = 0.f;
-#pragma unroll
-    for (int j = 1; j <= 14; ++j) {
-      int bi = bpos - j;
-      bi = bi < 0 ? bi + NB : bi;
-      w14 = fmaxf(w14, ring_bm[bi]);
-    }
     const int rd = ring_wrap(base + 4 * t - kDelay);  // ring position of sample gk - 240
-    const float4 so = *reinterpret_cast<const float4 *>(&ring_suf[rd]);
-    float4 pk;
-    pk.x = fmaxf(fmaxf(so.x, w14), pre_ex.x);
-    pk.y = fmaxf(fmaxf(so.y, w14), pre_ex.y);
-    pk.z = fmaxf(fmaxf(so.z, w14), pre_ex.z);
-    pk.w = fmaxf(fmaxf(so.w, w14), pre_ex.w);
-    // ---- gains under the hypothesis "no trigger in this chunk" ----
-    float gh[4];
+    float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (act) {
+      const int bpos = rp >> 4;
+      float w14 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int np = n_st + 4 * t + j;
-      np = np < n_end ? np : n_end;
-      const int ci = np + 1 < n_end ? np + 1 : n_end;
-      gh[j] = gain_at(np, gs, ge, ctl[ci], n_atk, n_end);
-    }
-    float4 g = make_float4(gh[0], gh[1], gh[2], gh[3]);
-    int kfirst = kBig;
-    if (valid) {
-      if (pk.w * g.w > thr) kfirst = 4 * t + 3;
-      if (pk.z * g.z > thr) kfirst = 4 * t + 2;
-      if (pk.y * g.y > thr) kfirst = 4 * t + 1;
-      if (pk.x * g.x > thr) kfirst = 4 * t + 0;
-    }
-    *reinterpret_cast<float4 *>(&arr_p[4 * t]) = pk;
-    {
+      for (int j = 1; j <= 14; ++j) {
+        int bi = bpos - j;
+        bi = bi < 0 ? bi + NB : bi;
+        w14 = fmaxf(w14, ring_bm[bi]);
+      }
+      const float4 so = *reinterpret_cast<const float4 *>(&ring_suf[rd]);
+      float4 pk;
+      pk.x = fmaxf(fmaxf(so.x, w14), pre_ex.x);
+      pk.y = fmaxf(fmaxf(so.y, w14), pre_ex.y);
+      pk.z = fmaxf(fmaxf(so.z, w14), pre_ex.z);
+      pk.w = fmaxf(fmaxf(so.w, w14), pre_ex.w);
+      // ---- gains under the hypothesis "no trigger in this chunk" ----
+      float gh[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int np = n_st + 4 * t + j;
+        np = np < n_end ? np : n_end;
+        const int ci = np + 1 < n_end ? np + 1 : n_end;
+        gh[j] = gain_at(np, gs, ge, ctl[ci], n_atk, n_end);
+      }
+      g = make_float4(gh[0], gh[1], gh[2], gh[3]);
+      int kfirst = kBig;
+      if (valid) {
+        if (pk.w * g.w > thr) kfirst = 4 * t + 3;
+        if (pk.z * g.z > thr) kfirst = 4 * t + 2;
+        if (pk.y * g.y > thr) kfirst = 4 * t + 1;
+        if (pk.x * g.x > thr) kfirst = 4 * t + 0;
+      }
+      *reinterpret_cast<float4 *>(&arr_p[4 * t]) = pk;
       const unsigned long long any = __ballot(kfirst != kBig);
       if (lane == 0) misc[wave] = __int_as_float(any ? __builtin_amdgcn_readlane(kfirst, __builtin_ctzll(any)) : kBig);
       if (4 * t + 4 == cnt) misc[8] = g.w;  // gain of the chunk's last sample under the hypothesis
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
       n_st = n_st + cnt < n_end ? n_st + cnt : n_end;
     } else {
       const int b0 = kf >> 6;
-      if (wave == cw) {
+      if (act && wave == cw) {
         int ln = n_st + 64 * b0 < n_end ? n_st + 64 * b0 : n_end;
         float lgs = gs, lge = ge, lgl = g_cur;
         limiter_wave(arr_p, arr_g, [ctl](int ci) { return ctl[ci]; }, b0, cnt >> 6, ln, lgs, lge, lgl,
@@ -480,13 +490,13 @@ __global__ __launch_bounds__(256) void render_fast_kernel(const RenderParams p) 
     __syncthreads();  // ring / arr slots are rewritten by the next chunk
   }
 
-  if constexpr (FIR) {
+  if (FIR && act) {
     // input history for the next call: the last 256 samples of [old history | this call's input]
     float *hn = p.fir_hist_next + (int64_t)s * M * kFirHist;
     for (int ch = 0; ch < M; ++ch) hn[ch * kFirHist + t] = fir_input(p, in_s, fir_hist, ch, p.total - kFirHist + t);
   }
   // ---- persist stream state (same format as the generic kernel) ----
-  {
+  if (act) {
     float *sy = p.ring_y + (int64_t)s * OC * kSave;
     float *spm = p.ring_pm + (int64_t)s * kSave;
     const int rp = ring_wrap(base - kSave + t);  // base = ring position of sample pos0 + total

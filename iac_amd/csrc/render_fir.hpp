@@ -14,21 +14,27 @@
 // and B a stride-16 view of the input (B operand of lane (T, kk) at step s is x[16T + 15 - 4s - kk]).
 // A 16x16 tile covers 256 samples; a wave carries the chunk's FOUR column tiles as four independent
 // accumulators, so one A read feeds four MFMAs and back-to-back MFMAs never depend on each other;
-// 94 % of the issued MACs are useful (L / (L + 15)).  Wave w owns ear (w & 1) and half of the
-// channels (w >> 1); the two halves are added at the end.  Per channel the input slice (1280
-// samples incl. 256 of history) and both ears' filters are staged in LDS (register double-buffered
-// global loads, one barrier per channel).  The slice is padded by one float per 16, which makes the
-// stride-16 B reads bank-conflict free AND keeps every operand address of a step equal to a
-// per-lane base plus a wave-uniform offset, so a step is five ds_read_b32 and four MFMAs.
-// (Tried and dropped: wave-private staging without the per-channel barrier — every wave then loads
-// the slice itself and the extra address arithmetic costs more issue slots than the barriers did.)
+// 94 % of the issued MACs are useful (L / (L + 15)).  The stage runs with EIGHT waves: wave w owns
+// ear (w & 1) and a quarter of the channels (w >> 1); the caller adds the four quarters.  With two
+// workgroups per CU that puts four waves on every SIMD, so the matrix pipe finds a wave with MFMAs
+// ready while others stage, wait at a barrier or run the limiter stages.  Per channel the input
+// slice (1280 samples incl. 256 of history) and both ears' filters are staged in LDS by the two
+// waves of the quarter (global loads into registers one channel ahead; single LDS buffer, two
+// barriers per channel).  The slice is padded by one float per 16, which makes the stride-16 B reads
+// (nearly) bank-conflict free AND keeps every operand address of a step equal to a per-lane base
+// plus a wave-uniform offset, so a step is five ds_read_b32 and four MFMAs.
+// Tried and dropped: wave-private staging without barriers (every wave then loads the slice itself
+// and the extra address arithmetic costs more issue slots than the barriers did); operand
+// double-buffering in registers; a lane stride of 20 floats (no measurable change).
 #pragma once
 
 constexpr int kFirChunk = 1024;  // = kFChunk of render_fast.hpp
 constexpr int kFirHist = 256;    // history kept per channel = maximum taps
 constexpr int kFirXs = 1360;     // padded slice: 1280 * 17 / 16
 constexpr int kFirHp = 304;      // padded filter: hp[j] = h[j - 15], zeros elsewhere (4 * 68 + 16 + slack)
-constexpr int kFirLdsFloats = 2 * 2 * kFirXs + 2 * 2 * 2 * kFirHp;  // [half][buf] xs + [half][buf][ear] hp
+constexpr int kFirStage = 4 * kFirXs + 4 * 2 * kFirHp;  // [quarter] xs + [quarter][ear] hp
+constexpr int kFirPart = 8 * (kFirChunk + 32);         // the eight waves' partial sums (alias the staging area)
+constexpr int kFirLdsFloats = kFirPart > kFirStage ? kFirPart : kFirStage;
 
 // sample n (relative to the start of this call) of channel ch of stream s; history for n < 0
 __device__ __forceinline__ float fir_input(const RenderParams &p, const float *in_s, const float *hist, int ch,
@@ -40,27 +46,28 @@ __device__ __forceinline__ float fir_input(const RenderParams &p, const float *i
   return in_s[(int64_t)f * p.in_frame_stride + (int64_t)ch * p.frame_size + i];
 }
 
-// Computes y[e][c0 .. c0+1024) for both ears into `part` ([4][1024 + 32], padded by one per 32):
-// the caller adds part[e] + part[e + 2].  All 256 threads must call it.  fir = LDS scratch of
-// kFirLdsFloats floats; part aliases it (it is dead once the last channel has been multiplied).
+// Computes y[e][c0 .. c0+1024) for both ears into `part` ([8][1024 + 32], padded by one per 32):
+// wave w writes part[w]; ear e = part[e] + part[e+2] + part[e+4] + part[e+6].  All 512 threads must
+// call it.  fir = LDS scratch of kFirLdsFloats floats; part aliases it (the staging area is dead
+// once the last channel has been multiplied).
 template <int M>
 __device__ __forceinline__ void fir_stage(const RenderParams &p, const float *in_s, const float *hist, int c0,
                                           float *fir, float *part) {
   using f32x4 = __attribute__((ext_vector_type(4))) float;
-  constexpr int MH = (M + 1) / 2;  // channel iterations (half 0 takes the extra one when M is odd)
+  constexpr int MQ = (M + 3) / 4;  // channel iterations (the first M % 4 quarters take one more)
   constexpr int U = 4;             // steps per unrolled block (16 MFMAs)
-  const int t = threadIdx.x;
+  const int t = threadIdx.x;       // 0..511
   const int w = t >> 6, lane = t & 63;
-  const int ear = w & 1, half = w >> 1;
-  const int th = t & 127;  // thread index inside the half
+  const int ear = w & 1, quarter = w >> 1;
+  const int th = t & 127;  // thread index inside the quarter
   const int L = p.fir_taps;
   const int KS = (L + 15 + 3) >> 2;         // steps of 4 taps over m' = m + 15 in [0, L + 14]
   const int KSP = (KS + U - 1) & ~(U - 1);  // the padded steps multiply zeros of hp; <= 68
   const int col = lane & 15, kk = lane >> 4;
-  const int my_n = half == 0 ? MH : M / 2;  // channels this half multiplies
-  const int ch0 = half == 0 ? 0 : MH;
-  float *xs = fir;                   // [half][buf][kFirXs]
-  float *hp = fir + 2 * 2 * kFirXs;  // [half][buf][ear][kFirHp]
+  const int my_n = M / 4 + (quarter < M % 4 ? 1 : 0);  // channels this quarter multiplies
+  const int ch0 = quarter * (M / 4) + (quarter < M % 4 ? quarter : M % 4);
+  float *xb = fir + quarter * kFirXs;                   // [kFirXs]
+  float *hb = fir + 4 * kFirXs + quarter * 2 * kFirHp;  // [ear][kFirHp]
 
   // where this thread's 10 slice samples come from does not depend on the channel: >= 0 = offset in
   // the channel's plane of the call's input, -1 = past the end of the call (zero), <= -2 = history
@@ -78,7 +85,7 @@ __device__ __forceinline__ void fir_stage(const RenderParams &p, const float *in
     }
   }
   float xr[10], hr[5];
-  auto fetch = [&](int ci) {  // global -> registers for channel ci of this half
+  auto fetch = [&](int ci) {  // global -> registers for channel ci of this quarter
     const int ch = ch0 + (ci < my_n ? ci : 0);
     const float *plane = in_s + (int64_t)ch * p.frame_size;
     const float *hch = hist + ch * kFirHist;
@@ -95,9 +102,7 @@ __device__ __forceinline__ void fir_stage(const RenderParams &p, const float *in
       hr[r] = (j < 2 * kFirHp && tap >= 0 && tap < L) ? p.matrix[((int64_t)e2 * M + ch) * L + tap] : 0.f;
     }
   };
-  auto stash = [&](int buf) {  // registers -> LDS
-    float *xb = xs + (half * 2 + buf) * kFirXs;
-    float *hb = hp + (half * 2 + buf) * 2 * kFirHp;
+  auto stash = [&]() {  // registers -> LDS
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
       const int q = th + 128 * r;  // slice position: sample c0 - 256 + q
@@ -112,17 +117,16 @@ __device__ __forceinline__ void fir_stage(const RenderParams &p, const float *in
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   fetch(0);
-  stash(0);
+  stash();
   __syncthreads();
-  for (int ci = 0; ci < MH; ++ci) {
-    const int buf = ci & 1;
-    if (ci + 1 < MH) fetch(ci + 1);
+  for (int ci = 0; ci < MQ; ++ci) {
+    if (ci + 1 < MQ) fetch(ci + 1);
     if (ci < my_n) {
       // step s: A operand hp[4s + kk + col]; B operand of column tile ct = slice sample
       // 256*ct + 16*col + 271 - kk - 4s, whose padded position is (17*col - kk) + 272*ct + o + (o >> 4)
       // with the wave-uniform o = 271 - 4s (o % 16 is 15, 11, 7 or 3 >= kk, so -kk never crosses a pad)
-      const float *ha = hp + ((half * 2 + buf) * 2 + ear) * kFirHp + (kk + col);
-      const float *xl = xs + (half * 2 + buf) * kFirXs + (17 * col - kk);
+      const float *ha = hb + ear * kFirHp + (kk + col);
+      const float *xl = xb + (17 * col - kk);
       for (int s0 = 0; s0 < KSP; s0 += U) {
         float a[U], b[U][4];
 #pragma unroll
@@ -139,8 +143,11 @@ __device__ __forceinline__ void fir_stage(const RenderParams &p, const float *in
           for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][ct], acc[ct], 0, 0, 0);
       }
     }
-    if (ci + 1 < MH) stash(buf ^ 1);
-    __syncthreads();
+    __syncthreads();  // everybody has read this channel's slice
+    if (ci + 1 < MQ) {
+      stash();
+      __syncthreads();
+    }
   }
   // D[row = phase][col = block]: lane holds block col of tile ct, phases 4*kk + r: four consecutive samples
   float *pw = part + w * (kFirChunk + 32);
