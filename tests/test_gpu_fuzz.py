@@ -1,0 +1,85 @@
+"""-m gpu: seeded random configurations of the batch renderer against the oracle, bit for bit:
+random source / output layouts, frame sizes, call partitions, bit depths, limiter on/off and
+thresholds, sample rates, gains (incl. the values the reference ignores), loudness, stream counts.
+Every case goes through whichever kernel the dispatcher picks (fast / wide4 / wide / generic) and
+usually through several of them across its calls."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+
+pytestmark = pytest.mark.gpu
+
+H2M_OUT = ["A", "B", "C", "D", "E", "F", "G", "H", "I", "J", "L712", "L312", "BINAURAL"]
+M2M_IN = ["MONO", "STEREO", "L51", "L512", "L514", "L71", "L712", "L714", "L312"]
+IN_CH = dict(MONO=1, STEREO=2, L51=6, L512=8, L514=10, L71=8, L712=10, L714=12, L312=6)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available()
+    import iac_amd as A
+    import gpu_util as G
+    return A, G
+
+
+def _partition(rng, total):
+    parts = []
+    while total:
+        n = int(rng.integers(1, min(total, 3) + 1))
+        parts.append(n)
+        total -= n
+    return parts
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration_matches_oracle(hip, seed):
+    A, G = hip
+    rng = np.random.default_rng(9000 + seed)
+    # renderer
+    for _ in range(50):
+        out = H2M_OUT[int(rng.integers(len(H2M_OUT)))]
+        if rng.random() < 0.5:
+            order = int(rng.integers(0, 4))
+            m = (order + 1) ** 2
+            try:
+                mx, omx = A.get_h2m_matrix(order, A.SS[out]), O.get_h2m(order, O.SS[out])
+            except KeyError:
+                continue
+        else:
+            src = M2M_IN[int(rng.integers(len(M2M_IN)))]
+            m = IN_CH[src]
+            try:
+                mx, omx = A.get_m2m_matrix(A.SS[src], A.SS[out]), O.get_m2m(O.SS[src], O.SS[out])
+            except KeyError:
+                continue
+        break
+    else:
+        pytest.skip("no matrix drawn")
+    ch = A.layout_channels(A.SS[out])
+    fs = int(rng.choice([128, 256, 480, 960, 1024, 1024, 2048]))
+    F = int(rng.integers(2, 7))
+    S = int(rng.integers(1, 4))
+    bits = int(rng.choice([16, 16, 24, 32]))
+    fmt = {16: A.FMT_S16, 24: A.FMT_S24, 32: A.FMT_S32}[bits]
+    limiter = bool(rng.random() < 0.8)
+    thr = float(rng.choice([-1.0, -1.0, -3.0, -0.1]))
+    rate = int(rng.choice([48000, 48000, 44100, 32000, 16000]))
+    loud = bool(rng.random() < 0.3)
+    pick = lambda: float(rng.choice([1.0, 1.0, 0.5, 1.7, -1.0, 0.0]))
+    eg, og = [pick() for _ in range(S)], [pick() for _ in range(S)]
+    lg = [float(rng.choice([1.0, 0.6, 1.4])) for _ in range(S)]
+    sigma = float(rng.choice([0.05, 0.2, 0.3]))
+    x = np.stack([synth.hot(seed * 10 + s, m, F * fs, sigma=sigma, burst_phase=int(rng.integers(0, fs)),
+                            burst_period=int(rng.integers(900, 4000))) for s in range(S)])
+    got = G.hip_render(mx, ch, x, frame_size=fs, fmt=fmt, limiter=limiter, flush=limiter,
+                       frames_per_call=_partition(rng, F), gains=dict(element=eg, output=og, loudness=lg),
+                       loudness=loud, threshold_db=thr, sample_rate=rate, projection=A.PROJ_EXACT)
+    for s in range(S):
+        want = O.stream_run(omx, ch, x[s], fs, flush=limiter, element_gain=eg[s], output_gain=og[s],
+                            loudness_on=int(loud), loudness_gain=lg[s], limiter_on=int(limiter), thr_db=thr,
+                            rate=rate, bit_depth=bits)
+        assert got[s].shape == want.shape, (seed, s, got[s].shape, want.shape)
+        assert np.array_equal(got[s], want), (seed, s)
