@@ -1,17 +1,29 @@
 // iamf_render.hip — MI355X (gfx950) kernels + the C ABI of include/iamf_hip.h.
 //
-// One workgroup (4 waves) owns one IAMF stream for the whole call and walks its samples in
-// chunks of 256, lane = sample.  Per chunk, fused in one pass over HBM:
-//   element renderer (gain matrix, reference h2m_rdr.c:1103-1150 / m2m_rdr.c:1826-1837)
+// One workgroup owns one IAMF stream for the whole call and walks its samples in chunks.  Per
+// chunk, fused in one pass over HBM:
+//   [demixer of scalable channel audio, demixer.c] [projection de-mapping, IAMF_core_decoder.c:116-130]
+//   -> element renderer (gain matrix h2m_rdr.c:1103-1150 / m2m_rdr.c:1826-1837, parametric
+//      down-mixer downmix_renderer.c, or the HRTF FIR of render_fir.hpp)
 //   -> element gain -> mix -> output gain -> loudness (IAMF_decoder.c:1392-1397, 2719-2730,
 //   3206-3221) -> look-ahead peak limiter (audio_effect_peak_limiter.c:94-271)
 //   -> float->PCM interleave (IAMF_decoder.c:100-167).
-// Rendered samples live only in an LDS ring (the limiter's 240-sample delay line); HBM sees
-// the planar f32 input once and the packed PCM once.
+// Rendered samples never touch HBM (LDS ring or registers hold the limiter's 240-sample delay
+// line); HBM sees the planar f32 input once and the packed PCM once.
 //
-// Arithmetic is IEEE f32 in the reference's operation order (this TU is compiled with
-// -ffp-contract=off, correctly rounded division), so the VALU path is bit-exact against the
-// CPU reference, not merely within +-1 LSB.
+// Kernel families (launch() picks one per call; all share the persisted per-stream state, so
+// consecutive calls of one stream may take different ones):
+//   render_fast.hpp     1- and 2-channel layouts, 1024-sample chunks, 4 samples per lane (headline);
+//                       with FIR = true the HRTF stage on the f32 MFMA in front (render_fir.hpp)
+//   render_wide4.hpp    even 6..24-channel layouts, s16, rendered samples kept in registers
+//                       (own translation unit: iamf_render_wide4.hip)
+//   render_wide.hpp     any other multi-channel aligned call, 256-sample chunks
+//   render_generic.hpp  everything else: ragged calls, flush, limiter off, second element, gain
+//                       ramps, down-mixer, demixer, projection
+//
+// Arithmetic is IEEE f32 in the reference's operation order (compiled with -ffp-contract=off,
+// correctly rounded division), so the VALU paths are bit-exact against the CPU reference, not
+// merely within +-1 LSB; the MFMA projection variants are the documented exception.
 #include <hip/hip_runtime.h>
 
 #include <math.h>
