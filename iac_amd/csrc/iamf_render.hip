@@ -259,7 +259,10 @@ bool wide_path_ok(const RenderParams &p, int m) {
 // 16-byte aligned planar input, an instantiated (inputs, outputs) pair.
 bool wide4_path_ok(const RenderParams &p, int m) {
   if (getenv("IAMF_HIP_NO_WIDE4")) return false;
-  if (p.out_format != IAMF_HIP_FMT_S16 || (p.total & 1023) || (p.frame_size & 3) || p.n_end < 1088) return false;
+  // whole 1024-sample chunks; the last one may be short if it still holds the 256 samples of stream state
+  if (p.out_format != IAMF_HIP_FMT_S16 || ((p.total & 1023) && (p.total & 1023) < 256) ||
+      (p.frame_size & 3) || p.n_end < 1088)
+    return false;
   if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
   return iamf_hip_wide4_has(m, p.out_ch) != 0;
 }

@@ -1,5 +1,5 @@
 // render_wide4.hpp — multi-channel output layouts (even channel counts 4..24), 16-bit PCM, limiter
-// on, calls of whole 1024-sample chunks.  One workgroup (4 waves) per stream, FOUR consecutive
+// on, calls of whole 1024-sample chunks (the last one may be shorter, down to 256 samples).  One workgroup (4 waves) per stream, FOUR consecutive
 // samples per lane, and — unlike render_wide.hpp — the rendered samples never travel through an
 // LDS ring:
 //   * a lane keeps its 4 samples x C channels in registers and emits THEM itself once their gains
@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int m = 4 * ks + kg;
-          x[4 * ks + cg] = (M % 4 == 0 || m < M) ? ld_stream4(src + (int64_t)m * fs) : make_float4(0.f, 0.f, 0.f, 0.f);
+          x[4 * ks + cg] = ((M % 4 == 0 || m < M) && k < p.total) ? ld_stream4(src + (int64_t)m * fs)
+                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
     } else {
@@ -168,10 +169,10 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       const int i = k - f * fs;
       const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
 #pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
+      for (int m = 0; m < M; ++m) x[m] = k < p.total ? ld_stream4(src + (int64_t)m * fs) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  load_x(0, t);  // total >= 1024
+  load_x(0, t);
   // MFMA A operand: lane (i = lane & 15, kg = lane >> 4) holds W[slot 16*rt + i][input 4*ks + kg]
   float aw[MFMA ? RT * KS : 1];
   if constexpr (MFMA) {
@@ -212,6 +213,9 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
     const int lane = tv & 63, q = tv & 3;
     const bool is_tail = tv >= kW4FirstTail;
     const int tl = is_tail ? tv - kW4FirstTail : 0;
+    const int cnt = p.total - c0 < kFChunk ? p.total - c0 : kFChunk;  // only the call's last chunk may be short:
+                                                                      // a multiple of 64, at least 256
+    const bool valid = 4 * tv < cnt;
     const int rp = ring_wrap(base + 4 * tv);
 
     // ---- element renderer + gains (reference operation order), 4 slots x 4 samples at a time ----
@@ -330,10 +334,12 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
     const float before = q == 0 ? 0.f : (q == 1 ? qa : (q == 2 ? fmaxf(qa, qb) : fmaxf(fmaxf(qa, qb), qc)));
     const float after = q == 3 ? 0.f : (q == 2 ? qd : (q == 1 ? fmaxf(qc, qd) : fmaxf(fmaxf(qb, qc), qd)));
     const float4 pre_ex = make_float4(before, fmaxf(before, i0), fmaxf(before, i1), fmaxf(before, i2));
-    *reinterpret_cast<float4 *>(&ring_pm[rp]) = pm;
-    *reinterpret_cast<float4 *>(&ring_suf[rp]) =
-        make_float4(fmaxf(s0, after), fmaxf(s1, after), fmaxf(s2, after), fmaxf(s3, after));
-    if (q == 0) ring_bm[rp >> 4] = ring_bm[(rp >> 4) + NB] = fmaxf(fmaxf(qa, qb), fmaxf(qc, qd));
+    if (valid) {
+      *reinterpret_cast<float4 *>(&ring_pm[rp]) = pm;
+      *reinterpret_cast<float4 *>(&ring_suf[rp]) =
+          make_float4(fmaxf(s0, after), fmaxf(s1, after), fmaxf(s2, after), fmaxf(s3, after));
+      if (q == 0) ring_bm[rp >> 4] = ring_bm[(rp >> 4) + NB] = fmaxf(fmaxf(qa, qb), fmaxf(qc, qd));
+    }
 #pragma unroll
     for (int r = 0; r < 5; ++r)
       if (tv + 256 * r < kW4Win) win[tv + 256 * r] = wv[r];
@@ -361,16 +367,18 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
     }
     const float4 g = make_float4(gh[0], gh[1], gh[2], gh[3]);
     int kfirst = kBig;
-    if (pk.w * g.w > thr) kfirst = 4 * tv + 3;
-    if (pk.z * g.z > thr) kfirst = 4 * tv + 2;
-    if (pk.y * g.y > thr) kfirst = 4 * tv + 1;
-    if (pk.x * g.x > thr) kfirst = 4 * tv + 0;
+    if (valid) {
+      if (pk.w * g.w > thr) kfirst = 4 * tv + 3;
+      if (pk.z * g.z > thr) kfirst = 4 * tv + 2;
+      if (pk.y * g.y > thr) kfirst = 4 * tv + 1;
+      if (pk.x * g.x > thr) kfirst = 4 * tv + 0;
+    }
     *reinterpret_cast<float4 *>(&arr_p[4 * tv]) = pk;
     *reinterpret_cast<float4 *>(&arr_g[4 * tv]) = g;
     {
       const unsigned long long any = __ballot(kfirst != kBig);
       if (lane == 0) misc[wave] = __int_as_float(any ? __builtin_amdgcn_readlane(kfirst, __builtin_ctzll(any)) : kBig);
-      if (tv == 255) misc[8] = g.w;  // gain of the chunk's last sample under the hypothesis
+      if (4 * tv + 4 == cnt) misc[8] = g.w;  // gain of the chunk's last sample under the hypothesis
     }
     __syncthreads();  // (2) vote, gains and window maxima visible
     int kf = __float_as_int(misc[0]);
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
     kf = min(kf, __float_as_int(misc[3]));
     if (kf == kBig) {
       g_cur = misc[8];
-      n_st = n_st + kFChunk < n_end ? n_st + kFChunk : n_end;
+      n_st = n_st + cnt < n_end ? n_st + cnt : n_end;
     } else {
       const int b0 = kf >> 6;
       if (wave == cw) {
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
           const int d = ci - n_chunk;
           return (d >= 0 && d < kW4Win) ? win[d] : head[ci < kW4Win ? ci : kW4Win - 1];
         };
-        limiter_wave(arr_p, arr_g, look, b0, kFChunk >> 6, ln, lgs, lge, lgl, thr, n_atk, n_end);
+        limiter_wave(arr_p, arr_g, look, b0, cnt >> 6, ln, lgs, lge, lgl, thr, n_atk, n_end);
         if (lane == 0) {
           misc[4] = lgl;
           misc[5] = lgs;
@@ -410,12 +418,12 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
     if (c0 + kFChunk < p.total) fetch_window(n_st, tv);  // for the next chunk, ahead of the stores
     float4 gq = *reinterpret_cast<const float4 *>(&arr_g[is_tail ? 4 * tv - (kFChunk - kDelay) : 4 * tv + kDelay]);
     const float gs4[4] = {gq.x * 32768.f, gq.y * 32768.f, gq.z * 32768.f, gq.w * 32768.f};  // exact scaling
-    if (c0 + kFChunk >= p.total && tv >= 192) {
+    if (c0 + kFChunk >= p.total && valid && 4 * tv >= cnt - kSave) {
       // last chunk of the call: its last 256 rendered samples are the stream state the next call
       // (any kernel) starts from.  Written here so that y is dead once it has been packed below.
       float *sy = p.ring_y + (int64_t)s * C * kSave;
 #pragma unroll
-      for (int c = 0; c < C; ++c) *reinterpret_cast<float4 *>(&sy[c * kSave + 4 * (tv - 192)]) = y[c];
+      for (int c = 0; c < C; ++c) *reinterpret_cast<float4 *>(&sy[c * kSave + 4 * tv - (cnt - kSave)]) = y[c];
     }
     if (is_tail) {  // swap in place: y <- previous tail, slot <- this chunk's samples
 #pragma unroll
@@ -464,8 +472,12 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
             const int l2 = j / H2, k = j - l2 * H2;
             const uint4 v = stg[l2 * S + k];
             const int t2 = wave * 64 + r * LR + l2;
-            const int rel = c0 + 4 * t2 - (t2 >= kW4FirstTail ? kFChunk : 0);  // sample, relative to pos0
-            if (rel + pos_small >= 0)
+            // tail-slot lanes emit the previous chunk's last 240 samples; the others their own, if the
+            // gain 240 samples on exists in this chunk (a short last chunk leaves the rest to the
+            // persisted state)
+            const bool ts = t2 >= kW4FirstTail;
+            const int rel = c0 + 4 * t2 - (ts ? kFChunk : 0);  // sample, relative to pos0
+            if (ts ? rel + pos_small >= 0 : 4 * t2 < cnt - kDelay)
               *reinterpret_cast<uint4 *>(pcm + (uint32_t)((rel + lead) * (C * 2) + k * 16)) = v;
           }
         }
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
         __builtin_amdgcn_wave_barrier();
       }
     }
-    base = base + kFChunk >= R ? base + kFChunk - R : base + kFChunk;
+    base = base + cnt >= R ? base + cnt - R : base + cnt;
     // no barrier here: the next chunk writes ring_* / win before its barrier (1), whose readers
     // all finished before barrier (2)/(3) of this chunk; arr_* / misc are written after (1)
   }

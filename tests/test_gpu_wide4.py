@@ -91,3 +91,23 @@ def test_wide4_quiet_signal_never_triggers(hip):
     got = G.hip_render(A.get_m2m_matrix(A.SS["L714"], oid), 12, x, frame_size=fs, flush=True)[0]
     want = O.stream_run(O.get_m2m(O.SS["L714"], O.SS["J"]), 12, x[0], fs)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("fs,calls", [(960, [1, 1, 2, 1, 3]), (1536, [1, 2, 1]), (320, [4, 1, 7, 2]), (1280, [1, 1, 1])])
+def test_wide4_short_last_chunk(hip, fs, calls):
+    """frame sizes that do not fill 1024-sample chunks (Opus-style 960, ...): every call ends with a
+    short chunk (>= 256 samples) or falls back to another kernel; state carries across either way"""
+    A, G = hip
+    F = sum(calls)
+    for src, m, out in (("L714", 12, "J"), ("TOA", 16, "H"), ("TOA", 16, "B")):
+        x = synth.hot(404 + fs, m, F * fs, sigma=0.25, burst_phase=211, burst_period=1900)[None]
+        oid = A.SS[out]
+        ch = A.layout_channels(oid)
+        if src == "TOA":
+            mx, omx = A.get_h2m_matrix(3, oid), O.get_h2m(3, O.SS[out])
+        else:
+            mx, omx = A.get_m2m_matrix(A.SS[src], oid), O.get_m2m(O.SS[src], O.SS[out])
+        got = G.hip_render(mx, ch, x, frame_size=fs, flush=True, frames_per_call=calls, projection=A.PROJ_EXACT)[0]
+        want = O.stream_run(omx, ch, x[0], fs)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), (fs, src, out)
