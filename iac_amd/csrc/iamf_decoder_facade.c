@@ -1095,7 +1095,9 @@ static float lpcm_sample(const struct IAMF_Decoder *d, const uint8_t *p) { /* pc
     int16_t v = d->little_endian ? (int16_t)(p[0] | (p[1] << 8)) : (int16_t)(p[1] | (p[0] << 8));
     return v / (float)(1 << 15);
   } else if (d->sample_size == 24) {
-    int32_t v = d->little_endian ? (p[0] | (p[1] << 8) | (p[2] << 16)) : (p[2] | (p[1] << 8) | (p[0] << 16));
+    /* big-endian 24-bit: the reference's reads24be (bitstream.c:204-208) assembles the first two bytes
+     * little-endian, i.e. byte 1 is the most significant one; a drop-in has to read it the same way */
+    int32_t v = d->little_endian ? (p[0] | (p[1] << 8) | (p[2] << 16)) : (p[2] | (p[0] << 8) | (p[1] << 16));
     if (v & 0x800000) v |= ~0xffffff;
     return v / (float)(1 << 23);
   } else {

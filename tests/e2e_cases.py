@@ -29,8 +29,8 @@ def _pdef_static(pid, rate=48000):
     return W.param_definition(pid, rate, mode=1)
 
 
-def _descriptor_prefix(frame_size, sample_size=16, rate=48000):
-    return W.sequence_header(1) + W.codec_config_lpcm(0, frame_size, sample_size, rate)
+def _descriptor_prefix(frame_size, sample_size=16, rate=48000, little_endian=True):
+    return W.sequence_header(1) + W.codec_config_lpcm(0, frame_size, sample_size, rate, little_endian)
 
 
 def _ss_layout(name):
@@ -64,6 +64,17 @@ CASES = {
     # projection-mode ambisonics: 10 sub-streams (6 coupled) -> 16 decoded channels -> Q15 de-mapping
     # matrix -> 16 ambisonics channels (IAMF_core_decoder.c:116-130,228-252)
     "toa_projection_B_s16": dict(layout=_ss_layout("B"), bit_depth=16, frames=5, fs=1024, seed=55),
+    # LPCM sample formats of the substreams (pcm/IAMF_pcm_decoder.c:60-83): 24 / 32 bit, big endian.
+    # 24-bit big-endian goes through the reference's reads24be, which swaps the two upper bytes
+    # (bitstream.c:204-208): the stream below decodes to what THAT produces
+    "stereo_in24le": dict(layout=_ss_layout("A"), bit_depth=24, frames=4, fs=1024, seed=61, sample_size=24, lpcm=True),
+    "stereo_in32le": dict(layout=_ss_layout("A"), bit_depth=32, frames=4, fs=1024, seed=62, sample_size=32, lpcm=True),
+    "stereo_in16be": dict(layout=_ss_layout("A"), bit_depth=16, frames=4, fs=1024, seed=63, sample_size=16, lpcm=True,
+                          big_endian=True),
+    "stereo_in32be": dict(layout=_ss_layout("A"), bit_depth=16, frames=4, fs=1024, seed=64, sample_size=32, lpcm=True,
+                          big_endian=True),
+    "stereo_in24be_quirk": dict(layout=_ss_layout("A"), bit_depth=16, frames=4, fs=1024, seed=65, sample_size=24,
+                                lpcm=True, big_endian=True),
     # scalable channel audio (N2): stereo -> 5.1.2 -> 7.1.4 with output gains on the first two layers,
     # recon-gain and demixing parameter blocks; the output layout selects the layer that is decoded
     # (IAMF_decoder.c:1776-1822), the demixer rebuilds the rest (demixer.c)
@@ -111,7 +122,8 @@ def build(name):
     n = fs * F
     ss = c.get("sample_size", 16)
     rate = c.get("rate", 48000)
-    stream = _descriptor_prefix(fs, ss, rate)
+    le = not c.get("big_endian", False)
+    stream = _descriptor_prefix(fs, ss, rate, le)
     info = dict(case=c, elements=[])
     eg = c.get("element_gain_q78", 0)
     og = c.get("output_gain_q78", 0)
@@ -190,6 +202,22 @@ def build(name):
             stream += W.temporal_delimiter()
             subs = [(i, W.lpcm_bytes(xq[i:i + 1, f * fs:(f + 1) * fs], ss)) for i in range(16)]
             stream += W.audio_frames(subs)
+    elif c.get("lpcm"):
+        x = synth.uniform(c["seed"], 2, n, 0.6)
+        xq = W.quantize(x, ss)
+        if ss == 24 and not le:   # what reads24be makes of big-endian bytes b0 b1 b2: (b1 << 16) | (b0 << 8) | b2
+            v = np.round(x.astype(np.float64) * 8388608.0).clip(-2 ** 23, 2 ** 23 - 1).astype(np.int64) & 0xffffff
+            b0, b1, b2 = v >> 16, (v >> 8) & 0xff, v & 0xff
+            u = (b1 << 16) | (b0 << 8) | b2
+            u = np.where(u & 0x800000, u - (1 << 24), u)
+            xq = (u.astype(np.float32) / np.float32(8388608.0)).astype(np.float32)
+        stream += W.audio_element_channel(1, 0, 1, [0])
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100), default_q78=eg)],
+                                     dict(pdef=_pdef_static(101), default_q78=og), layouts_field)
+        info["elements"].append(dict(kind="channel", layout=1, x=xq))
+        for f in range(F):
+            stream += W.temporal_delimiter()
+            stream += W.audio_frames([(0, W.lpcm_bytes(x[:, f * fs:(f + 1) * fs], ss, le))])
     elif c.get("scalable"):
         import demix_cases as D
         layers = SCALABLE_LAYERS

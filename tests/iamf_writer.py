@@ -189,16 +189,17 @@ def demixing_block(pid, mode):
     return obu(OBU_PARAMETER_BLOCK, leb128(pid) + bytes([(mode & 7) << 5]))
 
 
-def lpcm_bytes(x, sample_size=16):
-    """x: [channels_in_substream(1 or 2)][n] float in [-1, 1) -> sample-interleaved LE bytes"""
+def lpcm_bytes(x, sample_size=16, little_endian=True):
+    """x: [channels_in_substream(1 or 2)][n] float in [-1, 1) -> sample-interleaved bytes"""
     inter = np.ascontiguousarray(x.T)
+    e = "<" if little_endian else ">"
     if sample_size == 16:
-        return np.round(inter * 32768.0).clip(-32768, 32767).astype("<i2").tobytes()
+        return np.round(inter * 32768.0).clip(-32768, 32767).astype(e + "i2").tobytes()
     if sample_size == 32:
-        return np.round(inter.astype(np.float64) * 2147483648.0).clip(-2 ** 31, 2 ** 31 - 1).astype("<i4").tobytes()
+        return np.round(inter.astype(np.float64) * 2147483648.0).clip(-2 ** 31, 2 ** 31 - 1).astype(e + "i4").tobytes()
     v = np.round(inter.astype(np.float64) * 8388608.0).clip(-2 ** 23, 2 ** 23 - 1).astype("<i4")
     b = v.reshape(-1, 1).view(np.uint8).reshape(-1, 4)[:, :3]
-    return b.tobytes()
+    return (b if little_endian else b[:, ::-1]).tobytes()
 
 
 def audio_frames(substreams, trim=None):
