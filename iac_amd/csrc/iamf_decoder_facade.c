@@ -819,6 +819,7 @@ static void free_runtime(struct IAMF_Decoder *d) {
 int IAMF_decoder_close(IAMF_DecoderHandle d) {
   if (!d) return IAMF_ERR_BAD_ARG;
   free_runtime(d);
+  for (int i = 0; i < d->nparam; ++i) free(d->param[i].rq);
   free(d);
   return IAMF_OK;
 }
