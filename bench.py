@@ -96,7 +96,7 @@ def cpu_baseline(workload, fs, seconds_target=12.0):
     t1 = time.perf_counter() - t0
     single = n1 / t1 / 1e6
     cores = min(len(os.sched_getaffinity(0)), 16)   # the GPU box gives one GPU a 16-thread CPU share
-    reps = max(1, min(int(seconds_target / max(t1, 1e-3)), 64))
+    reps = max(1, min(int(seconds_target / max(t1, 1e-4)), 4096))   # ~seconds_target of wall time on `cores` threads
     t0 = time.perf_counter()
     with cf.ThreadPoolExecutor(cores) as ex:   # ctypes drops the GIL for the whole C call
         total = sum(ex.map(one_stream, range(cores * reps)))
@@ -105,6 +105,74 @@ def cpu_baseline(workload, fs, seconds_target=12.0):
             "single_core_value": round(single, 3),
             "sample": "%d streams x %d frames x %d samples of %s through oracle/ (scalar C port of "
                       "the reference loops), one stream per thread" % (cores * reps, frames, fs, workload)}
+
+
+def reference_baseline(workload, fs, seconds_target=12.0):
+    """The REAL reference (oracle/_ref/libiamf_ref.so, built from /root/reference's own sources by
+    oracle/Makefile; the built library travels with the repo snapshot) timed on this box's host
+    cores: one IAMF_DecoderHandle per thread decoding a synthetic LPCM .iamf stream of the same
+    workload through IAMF_decoder_decode (OBU parsing + LPCM unpack + the whole rendering path).
+    Returns None when the library is not there (then the oracle port is timed instead)."""
+    import concurrent.futures as cf
+    import ctypes as C
+    path = os.path.join(ROOT, "oracle", "_ref", "libref_driver.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        import iamf_writer as W
+        import synth
+        kind, in_id, out_id, in_ch, _ = WORKLOADS[workload]
+        frames = 48
+        x = W.quantize(np.clip(synth.hot(4242, in_ch, frames * fs), -1, 1 - 2 ** -15).astype(np.float32), 16)
+        pd = lambda pid: W.param_definition(pid, 48000, mode=1)
+        stream = W.sequence_header(1) + W.codec_config_lpcm(0, fs, 16, 48000)
+        if kind == "h2m":
+            stream += W.audio_element_ambisonics_mono(1, 0, in_ch, list(range(in_ch)))
+        else:
+            stream += W.audio_element_channel(1, 0, 7, list(range(W.LAYOUT_SUBSTREAMS[7][0])))
+            perm = [0, 1, 10, 11, 2, 3, 4, 5, 6, 7, 8, 9]   # playback -> audio-layer order of 7.1.4
+            xal = np.empty_like(x)
+            for p_, a in enumerate(perm):
+                xal[a] = x[p_]
+        ss = {0x1020: None, 0x9A3: 7, 0x470: 9}[out_id]
+        layouts = [("binaural",)] if ss is None else [("ss", ss)]
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=pd(100), default_q78=0)], dict(pdef=pd(101), default_q78=0), layouts)
+        desc_len = len(stream)
+        for f in range(frames):
+            stream += W.temporal_delimiter()
+            if kind == "h2m":
+                stream += W.audio_frames([(i, W.lpcm_bytes(x[i:i + 1, f * fs:(f + 1) * fs], 16)) for i in range(in_ch)])
+            else:
+                stream += W.audio_frames(W.channel_element_substreams(7, xal[:, f * fs:(f + 1) * fs], 0, 16))
+        buf = (C.c_char * len(stream)).from_buffer_copy(stream)
+        drv = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_driver.so"))   # oracle/ref_driver.c
+        drv.refdrv_decode.restype = C.c_long
+        drv.refdrv_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_double)]
+
+        def one_stream(_):
+            sec = C.c_double(0.0)
+            n = drv.refdrv_decode(C.addressof(buf), len(stream), -1 if ss is None else ss, 16, -1.0, C.byref(sec))
+            return n, sec.value
+
+        n1, t1 = one_stream(0)
+        if n1 <= 0:
+            return None
+        single = n1 / t1 / 1e6
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        reps = max(1, min(int(seconds_target / max(t1, 1e-4)), 4096))   # ~seconds_target of wall time
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(cores) as ex:   # ctypes drops the GIL for the whole C call
+            res = list(ex.map(one_stream, range(cores * reps)))
+        tm = time.perf_counter() - t0
+        total = sum(r[0] for r in res)
+        return {"value": round(total / tm / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "reference",
+                "single_core_value": round(single, 3),
+                "sample": "%d decoder handles x %d frames x %d samples of %s through IAMF_decoder_decode of the "
+                          "reference itself (oracle/_ref/libiamf_ref.so: LPCM .iamf stream -> PCM), one handle per "
+                          "thread" % (cores * reps, frames, fs, workload)}
+    except Exception as e:   # anything missing on this box: fall back to the port
+        sys.stderr.write("reference baseline unavailable (%s)\n" % e)
+        return None
 
 
 def main():
@@ -257,7 +325,14 @@ def main():
                                     "hbm_gbs": round(achieved, 1)})
             out["config"]["parity"] = "unpinned (HRTF arithmetic is not in the reference tree)"
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload if kind != "fir" else "toa_binaural_limiter_s16", fs)
+            wl = args.workload if kind != "fir" else "toa_binaural_limiter_s16"
+            refb = reference_baseline(wl, fs)
+            port = cpu_baseline(wl, fs, seconds_target=6.0 if refb else 12.0)
+            if refb:   # the reference itself is the baseline; the oracle port is reported beside it
+                refb["oracle_port"] = {k: port[k] for k in ("value", "unit", "cores", "single_core_value")}
+            out["cpu_baseline"] = refb or port
+            if kind == "fir":   # the reference's buildable binaural path is the 16->2 matrix, not an HRTF
+                out["cpu_baseline"]["sample"] += " [the matrix binaural path: the reference has no buildable HRTF]"
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
