@@ -128,6 +128,8 @@ struct iamf_hip_batch {
   iamf_hip_batch_config cfg;
   int m = 0, n_feeds = 0;
   int32_t src_feed[kMaxOut];
+  uint32_t nz_mask[6] = {0, 0, 0, 0, 0, 0};
+  int sparse = 0;
   int32_t *d_src_feed = nullptr;
   float thr = 0.f;
   int n_atk = 0, n_end = 0;
@@ -359,6 +361,8 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
   p.n_end = b->n_end;
   p.thr = b->thr;
   p.src_feed = b->d_src_feed;
+  for (int g = 0; g < 6; ++g) p.nz_mask[g] = b->nz_mask[g];
+  p.sparse = getenv("IAMF_HIP_DENSE") ? 0 : b->sparse;
   if (b->has2 && a.d_in2) {
     p.in2 = a.d_in2;
     p.in2_stream_stride = a.in2_stream_stride;
@@ -521,6 +525,20 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
     fm.assign(mx.mat, mx.mat + (size_t)2 * mx.m * cfg->fir_taps);
   } else {
     build_feed_map(mx, cfg->out_channels, fm, b->src_feed);
+    // sparsity of the matrix as the output slots see it (render_wide4.hpp skips all-zero weight batches)
+    int set = 0, all = 0;
+    for (int g = 0; g < 6 && 4 * g < cfg->out_channels; ++g)
+      for (int k = 0; k < mx.m && k < 32; ++k) {
+        bool nz = false;
+        for (int c = 4 * g; c < 4 * g + 4 && c < cfg->out_channels; ++c)
+          if (b->src_feed[c] >= 0 && fm[(size_t)b->src_feed[c] * mx.m + k] != 0.f) nz = true;
+        ++all;
+        if (nz) {
+          ++set;
+          b->nz_mask[g] |= 1u << k;
+        }
+      }
+    b->sparse = 2 * set < all ? 1 : 0;
   }
 
   // limiter constants and the coefficient table.  currentTC only ever takes the values

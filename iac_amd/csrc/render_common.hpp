@@ -42,6 +42,10 @@ struct RenderParams {
   int32_t n_atk, n_end;     // limiter table split points
   float thr;
   const int32_t *src_feed;  // device [out_ch]: output slot -> feed index, or -1 = silent slot
+  // wide4 VALU projection: bit m of nz_mask[g] = some output slot 4g..4g+3 has a non-zero weight for
+  // input m; sparse = less than half of those bits are set (then all-zero weight batches are skipped)
+  uint32_t nz_mask[6];
+  int32_t sparse;
   // ---- optional extras (generic kernel only) ----
   const float *in2;         // second element (planar f32) or nullptr
   int64_t in2_stream_stride, in2_frame_stride;

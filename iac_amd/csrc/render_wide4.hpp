@@ -268,41 +268,18 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
         pm.w = fmaxf(pm.w, fabsf(v.w));
       }
     } else {
-      // weights of MB inputs x 4 slots per LDS batch, the next batch fetched while this one is
-      // multiplied (explicit double buffer: left alone the scheduler hoists a whole group's
-      // weight reads and runs out of registers)
       constexpr int MB = (C >= 24 || (M & 1)) ? 1 : 2, NB_M = M / MB, G = C4 / 4;
       static_assert(M % MB == 0, "inputs per batch");
-      float4 wc[MB], wn[MB];
-#pragma unroll
-      for (int j = 0; j < MB; ++j) wc[j] = *reinterpret_cast<const float4 *>(&mat[j * C4]);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        constexpr float4 z4 = {0.f, 0.f, 0.f, 0.f};
-        float4 a0 = z4, a1 = z4, a2 = z4, a3 = z4;
-#pragma unroll
-        for (int b = 0; b < NB_M; ++b) {
-          const int nb = b + 1 < NB_M ? b + 1 : 0, ng = b + 1 < NB_M ? g : g + 1;
-          if (ng < G) {
-#pragma unroll
-            for (int j = 0; j < MB; ++j) wn[j] = *reinterpret_cast<const float4 *>(&mat[(nb * MB + j) * C4 + 4 * ng]);
-          }
-#pragma unroll
-          for (int j = 0; j < MB; ++j) {
-            const float4 w = wc[j];
-            const float4 xv = x[b * MB + j];
-            a0.x = a0.x + w.x * xv.x; a0.y = a0.y + w.x * xv.y; a0.z = a0.z + w.x * xv.z; a0.w = a0.w + w.x * xv.w;
-            a1.x = a1.x + w.y * xv.x; a1.y = a1.y + w.y * xv.y; a1.z = a1.z + w.y * xv.z; a1.w = a1.w + w.y * xv.w;
-            if (4 * g + 2 < C) {
-              a2.x = a2.x + w.z * xv.x; a2.y = a2.y + w.z * xv.y; a2.z = a2.z + w.z * xv.z; a2.w = a2.w + w.z * xv.w;
-              a3.x = a3.x + w.w * xv.x; a3.y = a3.y + w.w * xv.y; a3.z = a3.z + w.w * xv.z; a3.w = a3.w + w.w * xv.w;
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < MB; ++j) wc[j] = wn[j];
-          __builtin_amdgcn_sched_barrier(0);
+      constexpr float4 z4 = {0.f, 0.f, 0.f, 0.f};
+      auto mac = [&](const float4 w, const float4 xv, int g, float4 &a0, float4 &a1, float4 &a2, float4 &a3) {
+        a0.x = a0.x + w.x * xv.x; a0.y = a0.y + w.x * xv.y; a0.z = a0.z + w.x * xv.z; a0.w = a0.w + w.x * xv.w;
+        a1.x = a1.x + w.y * xv.x; a1.y = a1.y + w.y * xv.y; a1.z = a1.z + w.y * xv.z; a1.w = a1.w + w.y * xv.w;
+        if (4 * g + 2 < C) {
+          a2.x = a2.x + w.z * xv.x; a2.y = a2.y + w.z * xv.y; a2.z = a2.z + w.z * xv.z; a2.w = a2.w + w.z * xv.w;
+          a3.x = a3.x + w.w * xv.x; a3.y = a3.y + w.w * xv.y; a3.z = a3.z + w.w * xv.z; a3.w = a3.w + w.w * xv.w;
         }
-        const float4 acc[4] = {a0, a1, a2, a3};
+      };
+      auto finish = [&](int g, const float4 (&acc)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (4 * g + i < C) {
@@ -319,6 +296,54 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
             pm.z = fmaxf(pm.z, fabsf(v.z));
             pm.w = fmaxf(pm.w, fabsf(v.w));
           }
+        }
+      };
+      if (p.sparse) {
+        // Sparse matrices (the 7.1.4 -> J matrix of cfg2 is the identity, down-mix matrices have a
+        // few entries per row): a batch of inputs whose weights are zero for all four slots of the
+        // group adds 0 * x = +-0 to every accumulator, which leaves them unchanged for every FINITE
+        // input, so it is skipped (wave-uniform branch on the host-computed mask).  Non-finite
+        // inputs — which an LPCM decoder cannot produce — would give NaN in the reference.
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          float4 a0 = z4, a1 = z4, a2 = z4, a3 = z4;
+          const uint32_t nz = p.nz_mask[g];
+#pragma unroll
+          for (int b = 0; b < NB_M; ++b) {
+            if (nz & (((1u << MB) - 1u) << (b * MB))) {
+#pragma unroll
+              for (int j = 0; j < MB; ++j)
+                mac(*reinterpret_cast<const float4 *>(&mat[(b * MB + j) * C4 + 4 * g]), x[b * MB + j], g, a0, a1, a2, a3);
+            }
+          }
+          const float4 acc[4] = {a0, a1, a2, a3};
+          finish(g, acc);
+        }
+      } else {
+        // weights of MB inputs x 4 slots per LDS batch, the next batch fetched while this one is
+        // multiplied (explicit double buffer: left alone the scheduler hoists a whole group's
+        // weight reads and runs out of registers)
+        float4 wc[MB], wn[MB];
+#pragma unroll
+        for (int j = 0; j < MB; ++j) wc[j] = *reinterpret_cast<const float4 *>(&mat[j * C4]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          float4 a0 = z4, a1 = z4, a2 = z4, a3 = z4;
+#pragma unroll
+          for (int b = 0; b < NB_M; ++b) {
+            const int nb = b + 1 < NB_M ? b + 1 : 0, ng = b + 1 < NB_M ? g : g + 1;
+            if (ng < G) {
+#pragma unroll
+              for (int j = 0; j < MB; ++j) wn[j] = *reinterpret_cast<const float4 *>(&mat[(nb * MB + j) * C4 + 4 * ng]);
+            }
+#pragma unroll
+            for (int j = 0; j < MB; ++j) mac(wc[j], x[b * MB + j], g, a0, a1, a2, a3);
+#pragma unroll
+            for (int j = 0; j < MB; ++j) wc[j] = wn[j];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const float4 acc[4] = {a0, a1, a2, a3};
+          finish(g, acc);
         }
       }
     }
