@@ -348,7 +348,12 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       }
     }
 
-    // ---- prefetch the next chunk's input ----
+    // ---- table window -> LDS, THEN the prefetch of the next chunk's input.  Vector-memory operations
+    //      retire in order: waiting for the window values (fetched before the previous chunk's stores)
+    //      after the prefetch had been issued would drain the prefetch on the spot ----
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+      if (tv + 256 * r < kW4Win) win[tv + 256 * r] = wv[r];
     if (c0 + kFChunk < p.total) load_x(c0 + kFChunk, tv);
 
     // ---- per-16 prefix / suffix / block maxima: 4 lanes x 4 samples = one aligned block ----
@@ -365,9 +370,6 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
           make_float4(fmaxf(s0, after), fmaxf(s1, after), fmaxf(s2, after), fmaxf(s3, after));
       if (q == 0) ring_bm[rp >> 4] = ring_bm[(rp >> 4) + NB] = fmaxf(fmaxf(qa, qb), fmaxf(qc, qd));
     }
-#pragma unroll
-    for (int r = 0; r < 5; ++r)
-      if (tv + 256 * r < kW4Win) win[tv + 256 * r] = wv[r];
     __syncthreads();  // (1) maxima and table window visible
 
     // ---- 240-sample window maximum = tail of block b-15, blocks b-14..b-1, head of block b ----
