@@ -505,7 +505,11 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
             const bool ts = t2 >= kW4FirstTail;
             const int rel = c0 + 4 * t2 - (ts ? kFChunk : 0);  // sample, relative to pos0
             if (ts ? rel + pos_small >= 0 : 4 * t2 < cnt - kDelay)
-              *reinterpret_cast<uint4 *>(pcm + (uint32_t)((rel + lead) * (C * 2) + k * 16)) = v;
+            {  // written once, never read back by this GPU: streaming store
+              using u4 = __attribute__((ext_vector_type(4))) unsigned;
+              __builtin_nontemporal_store(u4{v.x, v.y, v.z, v.w},
+                                          reinterpret_cast<u4 *>(pcm + (uint32_t)((rel + lead) * (C * 2) + k * 16)));
+            }
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next round overwrites the staging area
