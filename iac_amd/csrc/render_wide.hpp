@@ -248,7 +248,10 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
       }
     }
 
-    // ---- prefetch the next chunk's input ----
+    // ---- table window -> LDS first (waiting for it after the prefetch had been issued would drain the
+    //      prefetch: vector-memory operations retire in order), then the next chunk's input ----
+    win[t] = wv0;
+    if (t < kWWin - 256) win[t + 256] = wv1;
     if (c0 + kWChunk < p.total) load_chunk(c0 + kWChunk);
 
     // ---- per-16 suffix / exclusive prefix / block maxima by DPP row scans ----
@@ -267,8 +270,6 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
       ring_suf[rp] = sfx;
       if ((t & 15) == 0) ring_bm[rp >> 4] = sfx;
     }
-    win[t] = wv0;
-    if (t < kWWin - 256) win[t + 256] = wv1;
     __syncthreads();
 
     // ---- 240-sample window maximum = tail of block b-15, blocks b-14..b-1, head of block b ----
