@@ -36,6 +36,10 @@ WORKLOADS = {
     # binaural by HRTF FIR (256-tap synthetic HRIRs; the reference's own binauraliser is not in its
     # tree -> "parity unpinned"): compute-bound on the f32 MFMA, 2*16*2*256 flop per sample-frame
     "toa_hrtf256_limiter_s16": ("fir", 3, 0x1020, 16, 16 * 4 + 2 * 2),
+    # scalable channel audio, layers stereo -> 5.1.2 -> 7.1.4 (12 decoded channels in
+    # bitstream order) through the demixer (output gains, S1to2..S5to7 / T2toT4 with a demixing mode
+    # per frame, recon-gain smoothing), then 7.1.4 -> J, limiter, s16: the general kernel
+    "scalable_714_ssJ_limiter_s16": ("demix", 0x714, 0x470, 12, 12 * 4 + 12 * 2),
 }
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA, dense (155 TF measured)
 FIR_TAPS = 256
@@ -211,7 +215,7 @@ def main():
         hr = (rng.standard_normal((2, in_ch, FIR_TAPS)) * np.exp(-np.arange(FIR_TAPS) / 40.0) * 0.08).astype(np.float32)
         mx = A.fir_matrix(hr)
     else:
-        mx = A.get_h2m_matrix(in_id, out_id) if kind == "h2m" else A.get_m2m_matrix(in_id, out_id)
+        mx = A.get_h2m_matrix(in_id, out_id) if kind == "h2m" else A.get_m2m_matrix(in_id, out_id)   # m2m, demix
     out_ch = A.layout_channels(out_id)
     S, F, fs = args.streams, args.frames, args.frame_size
 
@@ -220,6 +224,26 @@ def main():
         x = (torch.randn_like(x) * 0.05).contiguous()
     batch = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True,
                     fir_taps=FIR_TAPS if kind == "fir" else 0)
+    demix_args = None
+    if kind == "demix":
+        import ctypes as C
+        import demix_cases as D
+        layers = [1, 3, 7]
+        order, _ = D.channels_order(layers)
+        rec = D.recon_order(7, D.recon_flags(1, 7))
+        batch.set_demixer(7, order, D.output_gain_list(layers, {0: (0b110000, 0.7079458), 1: (0b001111, 1.4125376)}))
+        frames_rec = (A.DemixFrame * (S * F))()
+        rc = (C.c_int32 * 12)(*rec)
+        st = A.DemixState()
+        for s_ in range(S):   # host control plane: a demixing mode and recon gains per frame and stream
+            A.lib().iamf_hip_demix_state_init(C.byref(st))
+            A.lib().iamf_hip_demix_set_info(C.byref(st), 1, 3)
+            for f_ in range(F):
+                A.lib().iamf_hip_demix_set_info(C.byref(st), (0, 1, 2, 4, 5, 6)[(s_ + f_) % 6], -1)
+                gains_ = (C.c_float * 12)(*[0.5 + 0.5 * ((s_ * 7 + f_ * 3 + i) % 16) / 15.0 for i in range(len(rec))])
+                A.lib().iamf_hip_demix_frame_fill(C.byref(st), len(rec), rc, gains_, C.byref(frames_rec[s_ * F + f_]))
+        d_frames = torch.from_numpy(np.frombuffer(bytes(frames_rec), dtype=np.uint8).copy()).to(dev)
+        demix_args = d_frames
     stride_bytes = F * fs * out_ch * 2
     pcm = [torch.zeros((S, stride_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
     gather_on = world > 1 and args.gather != "none"
@@ -235,7 +259,14 @@ def main():
         # events bracket only the render kernel: the gather runs on RCCL's own stream
         if ev_pair:
             ev_pair[0].record()
-        n = batch.render(x.data_ptr(), stream_stride, frame_stride, F, buf.data_ptr(), stride_bytes, stream)
+        if demix_args is not None:
+            a = A.RenderArgs()
+            a.d_in, a.in_stream_stride, a.in_frame_stride = x.data_ptr(), stream_stride, frame_stride
+            a.n_frames, a.d_pcm, a.pcm_stream_stride_bytes, a.stream = F, buf.data_ptr(), stride_bytes, stream
+            a.d_demix_frames = demix_args.data_ptr()
+            n = batch.render_ex(a)
+        else:
+            n = batch.render(x.data_ptr(), stream_stride, frame_stride, F, buf.data_ptr(), stride_bytes, stream)
         if ev_pair:
             ev_pair[1].record()
         return n
@@ -285,7 +316,9 @@ def main():
         total_sf = sf_per_step * args.steps * world
         value = total_sf / elapsed / 1e6
         achieved = bytes_per_sf * sf_per_step / (kernel_ms * 1e-3) / 1e9
-        if kind == "fir":
+        if kind == "demix":
+            ktag = "render_kernel<%d>" % in_ch
+        elif kind == "fir":
             ktag = "render_fast_kernel<%d, 2, true>" % in_ch
         elif out_ch <= 2:
             ktag = "render_fast_kernel<%d, %d, false>" % (in_ch, out_ch)
@@ -325,7 +358,7 @@ def main():
                                     "hbm_gbs": round(achieved, 1)})
             out["config"]["parity"] = "unpinned (HRTF arithmetic is not in the reference tree)"
         if not args.no_cpu_baseline:
-            wl = args.workload if kind != "fir" else "toa_binaural_limiter_s16"
+            wl = {"fir": "toa_binaural_limiter_s16", "demix": "714_ssJ_limiter_s16"}.get(kind, args.workload)
             refb = reference_baseline(wl, fs)
             port = cpu_baseline(wl, fs, seconds_target=6.0 if refb else 12.0)
             if refb:   # the reference itself is the baseline; the oracle port is reported beside it
@@ -333,6 +366,8 @@ def main():
             out["cpu_baseline"] = refb or port
             if kind == "fir":   # the reference's buildable binaural path is the 16->2 matrix, not an HRTF
                 out["cpu_baseline"]["sample"] += " [the matrix binaural path: the reference has no buildable HRTF]"
+            if kind == "demix":
+                out["cpu_baseline"]["sample"] += " [the single-layer 7.1.4 stream: without the demixer stage]"
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

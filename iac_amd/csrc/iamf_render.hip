@@ -37,6 +37,7 @@
 
 #include "../../include/iamf_hip.h"
 
+extern "C" int iamf_hip_wide4_has_demixer(int m, int c);                              // iamf_render_wide4.hip
 extern "C" int iamf_hip_wide4_has(int m, int c);                                      // iamf_render_wide4.hip
 extern "C" int iamf_hip_wide4_launch(const void *params, int m, hipStream_t st);      // iamf_render_wide4.hip
 
@@ -149,7 +150,7 @@ struct iamf_hip_batch {
   float *d_pre = nullptr;
   int pre_l = 0;
   bool demix = false;
-  int demix_steps = 0, demix_skip = 0;
+  int demix_steps = 0, demix_skip = 0, demix_layout = 0, demix_gmask = 0, demix_w4 = 0;
   int32_t *d_demix_tab = nullptr;
   float *d_demix_ftab = nullptr;
   bool fir = false;
@@ -248,10 +249,11 @@ bool fast_path_ok(const RenderParams &p) {
 }
 
 // The wide kernel: 3..24 output channels, limiter on, aligned calls.
-bool wide_path_ok(const RenderParams &p, int m) {
+bool wide_path_ok(const RenderParams &p, int m, bool with_demixer = false) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
   if (!p.limiter_on || !p.in || p.out_ch <= 2 || p.out_ch > kMaxOut || p.n_end < kWWin) return false;
-  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix || p.demix_on) return false;
+  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix) return false;
+  if (p.demix_on && !with_demixer) return false;
   if ((p.pos0 & 15) || (p.total & 63)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
   return sizeof(float) * (size_t)wide_lds_floats(p.out_ch, m) <= 80 * 1024;
@@ -266,6 +268,8 @@ bool wide4_path_ok(const RenderParams &p, int m) {
       (p.frame_size & 3) || p.n_end < 1088)
     return false;
   if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
+  if (p.demix_on)  // scalable channel audio: the variant with the demixer in front of the projection
+    return p.demix_w4 && !p.use_mfma && (p.demix_i0 & 3) == 0 && iamf_hip_wide4_has_demixer(m, p.out_ch) != 0;
   return iamf_hip_wide4_has(m, p.out_ch) != 0;
 }
 
@@ -287,7 +291,7 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
   }
   const bool fast = fast_path_ok(p);
   const bool wide = !fast && wide_path_ok(p, m);
-  if (wide && wide4_path_ok(p, m) && iamf_hip_wide4_launch(&p, m, st)) {
+  if ((wide || (p.demix_on && wide_path_ok(p, m, true))) && wide4_path_ok(p, m) && iamf_hip_wide4_launch(&p, m, st)) {
     HIPCHK(hipGetLastError());
     return IAMF_HIP_OK;
   }
@@ -395,6 +399,9 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     p.demix_ftab = b->d_demix_ftab;
     p.demix_frames = a.d_demix_frames;
     p.demix_i0 = a.n_frames == 1 ? a.demix_sample0 : 0;
+    p.demix_layout = b->demix_layout;
+    p.demix_gmask = b->demix_gmask;
+    p.demix_w4 = b->demix_w4;
   }
   if (b->fir) {
     p.fir_taps = b->fir_taps;
@@ -749,11 +756,12 @@ int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *c
   auto h4 = [&]() { if (have[kChHBR]) return; h2(); if (!ok) return;
                     if (!have[kChHFR] || !have[kChHFL]) { ok = false; return; }
                     steps |= 32; have[kChHBL] = have[kChHBR] = true; };
-  int32_t tab[40];
+  int32_t tab[64];
   memset(tab, 0, sizeof(tab));
   for (int i = 0; i < c->n_in; ++i) {
     const int ch = kLayoutCh[c->layout][i];
     tab[i] = c->chs_in[i];
+    tab[40 + c->chs_in[i]] = i;  // IAChannel -> decoded position (render_wide4.hpp)
     tab[12 + i] = ch;
     if (have[ch]) continue;
     switch (ch) {
@@ -768,17 +776,24 @@ int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *c
     if (!ok || !have[ch]) return IAMF_HIP_ERR_BAD_ARG;
   }
   const int fs = b->cfg.frame_size;
-  std::vector<float> ft(12 + 2 * (size_t)fs, 0.f);
-  int ng = 0;
+  std::vector<float> ft(12 + 2 * (size_t)fs + 12, 0.f);
+  float *gin = ft.data() + 12 + 2 * (size_t)fs;  // the same gains by decoded channel, for render_wide4.hpp
+  for (int k = 0; k < 12; ++k) gin[k] = 1.f;
+  int ng = 0, gmask = 0;
+  bool gain_twice = false;
   for (int i = 0; i < c->n_gain; ++i) {  // dmx_gainup touches only channels that were decoded
     const int ch = c->gain_ch[i];
-    bool decoded = false;
-    for (int k = 0; k < c->n_in; ++k) decoded = decoded || c->chs_in[k] == ch;
+    int at = -1;
+    for (int k = 0; k < c->n_in; ++k)
+      if (c->chs_in[k] == ch) at = k;
     if (ch <= 0 || ch >= kChCount) return IAMF_HIP_ERR_BAD_ARG;
-    if (!decoded) continue;
+    if (at < 0) continue;
     tab[25 + ng] = ch;
     ft[ng] = c->gain[i];
     ++ng;
+    gain_twice = gain_twice || ((gmask >> at) & 1);
+    gmask |= 1 << at;
+    gin[at] = c->gain[i];
   }
   tab[24] = ng;
   // demixer_open + demixer_set_frame_offset (demixer.c:476-567): Hann cross-fade of fs/16 samples
@@ -812,6 +827,10 @@ int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *c
   b->demix = true;
   b->demix_steps = steps;
   b->demix_skip = pre;
+  b->demix_layout = c->layout;
+  b->demix_gmask = gmask;
+  // the in-register demixer keeps the first 192 entries of the cross-fade windows and reads them 4 at a time
+  b->demix_w4 = (!gain_twice && fs >= 256 && pre + ov <= 192 && (pre & 3) == 0) ? 1 : 0;
   return IAMF_HIP_OK;
 }
 

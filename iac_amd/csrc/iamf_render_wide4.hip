@@ -17,23 +17,50 @@ namespace {
 
 template <int M, int C>
 void launch_mc(const RenderParams &p, hipStream_t st) {
-  const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M);
+  const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M, false);
   static bool opted = false;
   if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, true, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     opted = true;
   }
   if (p.use_mfma)
-    hipLaunchKernelGGL((render_wide4_kernel<M, C, true>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((render_wide4_kernel<M, C, true, false>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
   else
-    hipLaunchKernelGGL((render_wide4_kernel<M, C, false>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((render_wide4_kernel<M, C, false, false>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
+}
+
+// scalable channel audio: M decoded channels -> demixer -> the M channels of the target layout -> C
+template <int M, int C>
+void launch_mc_demixer(const RenderParams &p, hipStream_t st) {
+  static_assert(wide4_lds_floats(C, M, true) <= 20480, "two workgroups per CU");
+  const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M, true);
+  static bool opted = false;
+  if (!opted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    opted = true;
+  }
+  hipLaunchKernelGGL((render_wide4_kernel<M, C, false, true>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
 }
 
 template <int M>
 bool launch_m(const RenderParams &p, hipStream_t st) {
+  if (p.demix_on) {
+    if constexpr (M == 6 || M == 8 || M == 10 || M == 12) {
+      switch (p.out_ch) {
+        case 6: launch_mc_demixer<M, 6>(p, st); return true;
+        case 8: launch_mc_demixer<M, 8>(p, st); return true;
+        case 10: launch_mc_demixer<M, 10>(p, st); return true;
+        case 12: launch_mc_demixer<M, 12>(p, st); return true;
+        case 24: launch_mc_demixer<M, 24>(p, st); return true;
+        default: return false;
+      }
+    }
+    return false;
+  }
   switch (p.out_ch) {
     case 6: launch_mc<M, 6>(p, st); return true;
     case 8: launch_mc<M, 8>(p, st); return true;
@@ -50,6 +77,11 @@ bool launch_m(const RenderParams &p, hipStream_t st) {
 extern "C" __attribute__((visibility("hidden"))) int iamf_hip_wide4_has(int m, int c) {
   return (m == 4 || m == 6 || m == 8 || m == 9 || m == 10 || m == 12 || m == 16) &&
          (c == 6 || c == 8 || c == 10 || c == 12 || c == 24);
+}
+
+// 1 if the demixer variant exists: m = channels of the scalable element's target layout (5.1 .. 7.1.4)
+extern "C" __attribute__((visibility("hidden"))) int iamf_hip_wide4_has_demixer(int m, int c) {
+  return (m == 6 || m == 8 || m == 10 || m == 12) && (c == 6 || c == 8 || c == 10 || c == 12 || c == 24);
 }
 
 // params: the caller's RenderParams (same definition, render_common.hpp); returns 1 if launched

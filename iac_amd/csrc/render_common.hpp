@@ -67,9 +67,14 @@ struct RenderParams {
   int32_t demix_steps;      // bit 0 S1to2, 1 S2to3, 2 S3to5, 3 S5to7, 4 TF2toT2, 5 T2toT4
   int32_t demix_skip;       // samples at the start of every frame that use the previous mode
   int32_t demix_i0;         // frame position of the call's first sample (trimmed single-frame calls)
-  const int32_t *demix_tab; // device: [0..12) chs_in, [12..24) chs_out, [24] n_gain, [25..37) gain_ch
-  const float *demix_ftab;  // device: [0..12) gains, then start_window[frame_size], stop_window[frame_size]
+  const int32_t *demix_tab; // device: [0..12) chs_in, [12..24) chs_out, [24] n_gain, [25..37) gain_ch,
+                            //         [40..64) decoded position of an IAChannel (0 if it is not decoded)
+  const float *demix_ftab;  // device: [0..12) gains, start_window[frame_size], stop_window[frame_size],
+                            //         then [0..12) the gain of every decoded channel (1 where none)
   const iamf_hip_demix_frame *demix_frames;  // device [n_streams][frames of this call]
+  int32_t demix_layout;     // IAChannelLayoutType of the target layout (render_wide4_kernel<.., DMX>)
+  int32_t demix_gmask;      // bit m: decoded channel m takes the output gain demix_ftab[12 + 2*frame_size + m]
+  int32_t demix_w4;         // 1 if the in-register demixer of render_wide4.hpp covers this configuration
   // ---- HRTF FIR renderer (render_fast_kernel<M, 2, true>): matrix = h[2][M][fir_taps] ----
   int32_t fir_taps;
   const float *fir_hist;    // device [n_streams][M][256] input history before this call

@@ -25,17 +25,43 @@ constexpr int kW4Win = 1088;        // staged table window / head length (> chun
 constexpr int kW4TailLanes = 60;    // lanes holding the chunk's last 240 samples
 constexpr int kW4FirstTail = 256 - kW4TailLanes;
 
-__host__ __device__ constexpr int wide4_base_floats(int c, int m) {
-  return 4 * kW4TailLanes * c + 2 * kFRing + 2 * (kFRing / 16) + 2 * kFChunk + 2 * kW4Win + ((c + 3) & ~3) * m + 16;
+// demixer variant: [2][5] frame records of 36 floats, the first 192 entries of the two cross-fade
+// windows, playback position of every IAChannel
+constexpr int kW4DmxRecs = 5, kW4DmxRec = 36, kW4DmxWin = 192;
+constexpr int kW4DmxFloats = 2 * kW4DmxRecs * kW4DmxRec + 2 * kW4DmxWin + 24;  // records double-buffered
+
+__host__ __device__ constexpr int wide4_base_floats(int c, int m, bool dmx) {
+  return 4 * kW4TailLanes * c + 2 * kFRing + 2 * (kFRing / 16) + 2 * kFChunk + 2 * kW4Win + ((c + 3) & ~3) * m + 16 +
+         (dmx ? kW4DmxFloats : 0);
 }
 // PCM staging (per wave): a lane's 8*C output bytes = C/2 16-byte pieces, lane stride padded to an
 // odd number of pieces (conflict-free).  All 64 lanes at once if that fits 80 KB, else 32 per round.
 __host__ __device__ constexpr int wide4_stage_stride(int c) { return ((c / 2) & 1) ? c / 2 : c / 2 + 1; }
-__host__ __device__ constexpr int wide4_stage_lanes(int c, int m) {
-  return wide4_base_floats(c, m) + 4 * 64 * wide4_stage_stride(c) * 4 <= 20480 ? 64 : 32;
+__host__ __device__ constexpr int wide4_stage_lanes(int c, int m, bool dmx) {
+  return wide4_base_floats(c, m, dmx) + 4 * 64 * wide4_stage_stride(c) * 4 <= 20480 ? 64 : 32;
 }
-__host__ __device__ constexpr int wide4_lds_floats(int c, int m) {
-  return wide4_base_floats(c, m) + 4 * wide4_stage_lanes(c, m) * wide4_stage_stride(c) * 4;
+__host__ __device__ constexpr int wide4_lds_floats(int c, int m, bool dmx) {
+  return wide4_base_floats(c, m, dmx) + 4 * wide4_stage_lanes(c, m, dmx) * wide4_stage_stride(c) * 4;
+}
+
+// playback order of the scalable layouts (IAChannelLayoutType; reference IAMF_utils.c:117-133)
+__host__ __device__ constexpr int w4_layout_count(int layout) {
+  constexpr int n[9] = {1, 2, 6, 8, 10, 8, 10, 12, 6};
+  return n[layout];
+}
+__host__ __device__ constexpr int w4_layout_ch(int layout, int i) {
+  constexpr int ch[9][12] = {
+      {kChMono},
+      {kChL2, kChR2},
+      {kChL7, kChR7, kChC, kChLFE, kChSL5, kChSR5},
+      {kChL7, kChR7, kChC, kChLFE, kChSL5, kChSR5, kChHL, kChHR},
+      {kChL7, kChR7, kChC, kChLFE, kChSL5, kChSR5, kChHFL, kChHFR, kChHBL, kChHBR},
+      {kChL7, kChR7, kChC, kChLFE, kChSL7, kChSR7, kChBL7, kChBR7},
+      {kChL7, kChR7, kChC, kChLFE, kChSL7, kChSR7, kChBL7, kChBR7, kChHL, kChHR},
+      {kChL7, kChR7, kChC, kChLFE, kChSL7, kChSR7, kChBL7, kChBR7, kChHFL, kChHFR, kChHBL, kChHBR},
+      {kChL3, kChR3, kChC, kChLFE, kChTL, kChTR},
+  };
+  return ch[layout][i];
 }
 
 using w4_f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -62,9 +88,122 @@ __device__ __forceinline__ void w4_transpose_rows(float &r0, float &r1, float &r
   r3 = __uint_as_float(d[1]);
 }
 
-template <int M, int C, bool MFMA>
+// Demixer of scalable channel audio (reference demixer.c:636-664) on a lane's 4 consecutive samples:
+// x[] arrives as the M decoded channels (bitstream order) and leaves as the target layout's channels
+// in playback order.  The channel file, indexed by IAChannel, is a register array; scr = 64 * M floats
+// of LDS private to the wave.
+// Same operations in the same order as the generic kernel's demixer (render_generic.hpp).
+template <int M>
+__device__ __forceinline__ void w4_demix(const RenderParams &p, float4 (&x)[M], 
+                                         const float (&gin)[M], const int (&row)[kChCount], const float *dmx_rec,
+                                         const float *dmx_ws,
+                                         float *scr, int c0, int k4, int fs, int any_mask) {
+  const int k = c0 + k4;
+  const int f = k / fs;
+  const int icur = k - f * fs;
+  int j = f - c0 / fs;
+  j = j < kW4DmxRecs - 1 ? j : kW4DmxRecs - 1;  // only lanes past the end of the call get clamped
+  const float *rec = dmx_rec + kW4DmxRec * j;
+  const int iw = icur + p.demix_i0;  // multiple of 4, like demix_skip: one mode for the lane's 4 samples
+  const float *cf = rec + (iw < p.demix_skip ? 0 : 5);
+  const float alpha = cf[0], beta = cf[1], gamma = cf[2], delta = cf[3], w = cf[4];
+  float4 ws = make_float4(1.f, 1.f, 1.f, 1.f), wp = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (iw < kW4DmxWin) {  // behind the cross-fade the windows are 1 and 0
+    ws = *reinterpret_cast<const float4 *>(&dmx_ws[iw]);
+    wp = *reinterpret_cast<const float4 *>(&dmx_ws[kW4DmxWin + iw]);
+  }
+  // Scatter: decoded channel m -> slot in_ch[m] of the channel file.  A register array cannot be
+  // indexed by a run-time value, an LDS address can: every lane parks its M values in its own column
+  // of the wave's scratch rows (row m = decoded channel m) and reads slot c back from row
+  // demix_tab[40 + c] (row 0 for a slot no decoded channel lands in: such a slot holds a value no
+  // planned step reads, iamf_hip_batch_set_demixer).  One sample position per pass; the data never
+  // crosses lanes, so program order is all the synchronisation there is.
+  float4 ch[kChCount];
+  {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if ((p.demix_gmask >> m) & 1) {  // dmx_gainup (:426-435)
+        const float g = gin[m];
+        x[m].x = x[m].x * g; x[m].y = x[m].y * g; x[m].z = x[m].z * g; x[m].w = x[m].w * g;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) scr[64 * m + lane] = w4_comp(x[m], i);
+#pragma unroll
+      for (int c = 1; c < kChCount; ++c) w4_set(ch[c], i, scr[row[c]]);
+    }
+  }
+  const int steps = p.demix_steps;
+  if (steps & 1) {  // S1to2 (:126-147)
+    const float4 a = ch[kChMono], b = ch[kChL2];
+    ch[kChR2] = make_float4(2 * a.x - b.x, 2 * a.y - b.y, 2 * a.z - b.z, 2 * a.w - b.w);
+  }
+  if (steps & 2) {  // S2to3 (:152-181): the reference's 0.707 literal makes this double arithmetic
+    const float4 cc = ch[kChC], l = ch[kChL2], r = ch[kChR2];
+    const double cx = 0.707 * (double)cc.x, cy = 0.707 * (double)cc.y, cz = 0.707 * (double)cc.z, cw = 0.707 * (double)cc.w;
+    ch[kChL3] = make_float4((float)((double)l.x - cx), (float)((double)l.y - cy), (float)((double)l.z - cz), (float)((double)l.w - cw));
+    ch[kChR3] = make_float4((float)((double)r.x - cx), (float)((double)r.y - cy), (float)((double)r.z - cz), (float)((double)r.w - cw));
+  }
+  if (steps & 4) {  // S3to5 (:186-230)
+    const float4 a = ch[kChL3], b = ch[kChL7], c = ch[kChR3], d = ch[kChR7];
+    ch[kChSL5] = make_float4((a.x - b.x) / delta, (a.y - b.y) / delta, (a.z - b.z) / delta, (a.w - b.w) / delta);
+    ch[kChSR5] = make_float4((c.x - d.x) / delta, (c.y - d.y) / delta, (c.z - d.z) / delta, (c.w - d.w) / delta);
+  }
+  if (steps & 8) {  // S5to7 (:236-284)
+    const float4 a = ch[kChSL5], b = ch[kChSL7], c = ch[kChSR5], d = ch[kChSR7];
+    ch[kChBL7] = make_float4((a.x - b.x * alpha) / beta, (a.y - b.y * alpha) / beta, (a.z - b.z * alpha) / beta, (a.w - b.w * alpha) / beta);
+    ch[kChBR7] = make_float4((c.x - d.x * alpha) / beta, (c.y - d.y * alpha) / beta, (c.z - d.z * alpha) / beta, (c.w - d.w * alpha) / beta);
+  }
+  if (steps & 16) {  // TF2toT2 (:290-335)
+    const float4 a = ch[kChTL], b = ch[kChSL5], c = ch[kChTR], d = ch[kChSR5];
+    const float dw = delta * w;
+    ch[kChHL] = make_float4(a.x - dw * b.x, a.y - dw * b.y, a.z - dw * b.z, a.w - dw * b.w);
+    ch[kChHR] = make_float4(c.x - dw * d.x, c.y - dw * d.y, c.z - dw * d.z, c.w - dw * d.w);
+  }
+  if (steps & 32) {  // T2toT4 (:340-377)
+    const float4 a = ch[kChHL], b = ch[kChHFL], c = ch[kChHR], d = ch[kChHFR];
+    ch[kChHBL] = make_float4((a.x - b.x) / gamma, (a.y - b.y) / gamma, (a.z - b.z) / gamma, (a.w - b.w) / gamma);
+    ch[kChHBR] = make_float4((c.x - d.x) / gamma, (c.y - d.y) / gamma, (c.z - d.z) / gamma, (c.w - d.w) / gamma);
+  }
+  // the target layout's channels in playback order; the layouts of M channels are the only candidates
+  const int layout = p.demix_layout;
+  if constexpr (M == 12) {  // 7.1.4 is the only one
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = ch[w4_layout_ch(7, m)];
+  } else {
+#pragma unroll
+    for (int lt = 2; lt < 9; ++lt) {
+      if (w4_layout_count(lt) == M && layout == lt) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) x[m] = ch[w4_layout_ch(lt, m)];
+      }
+    }
+  }
+  // recon gain with its cross-fade from the last frame's smoothed value (dmx_rms, :447-478);
+  // any_mask = the channels with a recon gain in any frame of this chunk (wave-uniform)
+  const int mask = __float_as_int(rec[10]);
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    if (!((any_mask >> m) & 1)) continue;
+    const float2 g = *reinterpret_cast<const float2 *>(&rec[12 + 2 * m]);
+    if ((mask >> m) & 1) {
+      float4 v = x[m];
+      v.x = v.x * (g.x * wp.x + g.y * ws.x);
+      v.y = v.y * (g.x * wp.y + g.y * ws.y);
+      v.z = v.z * (g.x * wp.z + g.y * ws.z);
+      v.w = v.w * (g.x * wp.w + g.y * ws.w);
+      x[m] = v;
+    }
+  }
+}
+
+template <int M, int C, bool MFMA, bool DMX>
 __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams p) {
   static_assert((C & 1) == 0 && C >= 4 && C <= 24, "even channel counts");
+  static_assert(!(DMX && MFMA), "the demixer variant projects on the VALU");
   extern __shared__ float lds[];
   constexpr int R = kFRing;
   constexpr int NB = R / 16;
@@ -80,7 +219,10 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
   float *head = win + kW4Win;                       // [kW4Win] ctab[i]
   float *mat = head + kW4Win;                       // [M][C4] weights, input-major
   float *misc = mat + C4 * M;                       // [16]
-  uint4 *stage = reinterpret_cast<uint4 *>(misc + 16);  // [4 waves][LR][S] packed PCM on its way out
+  float *dmx_rec = misc + 16;                            // DMX: [2][5][36] frame records of this / the next chunk
+  float *dmx_ws = dmx_rec + 2 * kW4DmxRecs * kW4DmxRec;  // DMX: [192] start window, [192] stop window
+  int *dmx_pos = reinterpret_cast<int *>(dmx_ws + 2 * kW4DmxWin);  // DMX: [24] playback position of an IAChannel
+  uint4 *stage = reinterpret_cast<uint4 *>(misc + 16 + (DMX ? kW4DmxFloats : 0));  // [4 waves][LR][S] packed PCM
 
   const int s = blockIdx.x;
   const int t = threadIdx.x;
@@ -119,6 +261,87 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       mat[i] = f >= 0 ? p.matrix[f * M + m] : 0.f;
     }
     chain_wave_publish(misc + 12);
+    if constexpr (DMX) {
+      for (int i = t; i < kW4DmxWin; i += 256) {
+        dmx_ws[i] = p.demix_ftab[12 + i];
+        dmx_ws[kW4DmxWin + i] = p.demix_ftab[12 + fs + i];
+      }
+      if (t < 24) {
+        int pos = -1;
+        for (int m = 0; m < M; ++m)
+          if (p.demix_tab[12 + m] == t) pos = m;
+        dmx_pos[t] = pos;
+      }
+    }
+  }
+  // Demixer, control side.  A chunk touches at most 5 frames (frame_size >= 256).  Their records
+  // (iamf_hip_demix_frame: 47 dwords, recon gains keyed by IAChannel) are re-keyed by playback
+  // position into LDS: [0..5) factors of the previous mode, [5..10) of the current one, [10] bit m =
+  // output channel m has a recon gain, [12 + 2m] its smoothed gain of the last frame, [13 + 2m] of
+  // this frame.  16 threads per record fetch 5 dwords each next to the table window (ahead of the
+  // PCM stores and of the input prefetch in the in-order vector-memory queue) and write them with the
+  // window, into the buffer the current chunk does not read.
+  const int dmx_nfr = DMX ? (p.total + fs - 1) / fs : 0;
+  float dv[DMX ? 5 : 1];
+  auto fetch_rec = [&](int cbase, int tt) {
+    if constexpr (DMX) {
+      // every thread loads (those past the 80 that write repeat record 4): straight-line code, so
+      // that nothing has to wait for these loads before put_rec does
+      const int j = (tt >> 4) < kW4DmxRecs ? (tt >> 4) : kW4DmxRecs - 1, r = tt & 15;
+      int fi = cbase / fs + j;
+      fi = fi < dmx_nfr ? fi : dmx_nfr - 1;
+      const float *d = reinterpret_cast<const float *>(p.demix_frames + (int64_t)s * dmx_nfr + fi);
+      // r < 12: n_recon, recon_ch[r], recon_prev[r], recon_cur[r];  r = 12: prev[0..5);  r > 12: cur[0..5)
+      const int o0 = r < 12 ? 10 : (r == 12 ? 0 : 5), st = r < 12 ? 12 : 1, o1 = r < 12 ? 11 + r : o0 + 1;
+      dv[0] = d[o0];
+      dv[1] = d[o1];
+      dv[2] = d[o1 + st];
+      dv[3] = d[o1 + 2 * st];
+      dv[4] = d[r < 12 ? 10 : o0 + 4];
+    }
+  };
+  auto put_rec = [&](int tt, int buf) {
+    if constexpr (DMX) {
+      if (tt < 16 * kW4DmxRecs) {
+        const int j = tt >> 4, r = tt & 15;
+        float *rec = dmx_rec + kW4DmxRec * (kW4DmxRecs * buf + j);
+        int bit = 0;
+        if (r < 12) {
+          const int n = __float_as_int(dv[0]), ch = __float_as_int(dv[1]);
+          if (r < n && ch > 0 && ch < 24) {
+            const int m = dmx_pos[ch];
+            if (m >= 0) {
+              rec[12 + 2 * m] = dv[2];
+              rec[13 + 2 * m] = dv[3];
+              bit = 1 << m;
+            }
+          }
+        }
+        bit |= __shfl_xor(bit, 1, 16);
+        bit |= __shfl_xor(bit, 2, 16);
+        bit |= __shfl_xor(bit, 4, 16);
+        bit |= __shfl_xor(bit, 8, 16);
+        if (r == 12) rec[10] = __int_as_float(bit);
+        if (r == 12 || r == 13) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) rec[(r == 12 ? 0 : 5) + i] = dv[i];
+        }
+      }
+    }
+  };
+  float dmx_gin[DMX ? M : 1];  // output gain of every decoded channel (wave-uniform)
+  int dmx_row[DMX ? kChCount : 1];  // where the lane finds IAChannel c in the wave's scatter rows (w4_demix)
+  if constexpr (DMX) {
+#pragma unroll
+    for (int c = 1; c < kChCount; ++c) dmx_row[c] = 64 * p.demix_tab[40 + c] + lane;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      dmx_gin[m] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__float_as_int(p.demix_ftab[12 + 2 * fs + m])));
+    }
+    fetch_rec(0, t);
+    __syncthreads();  // dmx_pos visible
+    put_rec(t, 0);
+    fetch_rec(kFChunk, t);  // written to LDS in the first chunk
   }
   LimState ls = p.lim[s];
   float g_cur = ls.g, gs = ls.gs, ge = ls.ge;
@@ -163,6 +386,16 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
                                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
+    } else if constexpr (DMX) {
+      // lanes past the end of a short last chunk load the call's last quad instead of zeros: nothing
+      // they compute is ever stored, and unconditional loads keep the prefetch free of branches
+      int k = cbase + 4 * tt;
+      k = k < p.total ? k : p.total - 4;
+      const int f = k / fs;
+      const int i = k - f * fs;
+      const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
     } else {
       const int k = cbase + 4 * tt;
       const int f = k / fs;
@@ -217,6 +450,25 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
                                                                       // a multiple of 64, at least 256
     const bool valid = 4 * tv < cnt;
     const int rp = ring_wrap(base + 4 * tv);
+
+    float4 xw[NX];
+    float4(&X)[NX] = DMX ? xw : x;  // what the projection reads
+    if constexpr (DMX) {
+      // the prefetched 16-byte tuples stay what the loop carries; the demixer works on copies, so that
+      // no later use of a component can pull a copy (and with it a wait) up to where the load is issued
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        xw[m] = x[m];
+        asm volatile("" : "+v"(xw[m].x), "+v"(xw[m].y), "+v"(xw[m].z), "+v"(xw[m].w));
+      }
+      const float *recs = dmx_rec + kW4DmxRec * kW4DmxRecs * ((c0 >> 10) & 1);
+      int any_mask = 0;
+#pragma unroll
+      for (int j = 0; j < kW4DmxRecs; ++j) any_mask |= __float_as_int(recs[kW4DmxRec * j + 10]);
+      static_assert(wide4_stage_lanes(C, M, true) * wide4_stage_stride(C) * 4 >= 64 * M, "scatter rows fit the wave's staging area");
+      float *scr = reinterpret_cast<float *>(stage + (tv >> 6) * (wide4_stage_lanes(C, M, true) * wide4_stage_stride(C)));
+      w4_demix<M>(p, xw, dmx_gin, dmx_row, recs, dmx_ws, scr, c0, 4 * tv, fs, __builtin_amdgcn_readfirstlane(any_mask));
+    }
 
     // ---- element renderer + gains (reference operation order), 4 slots x 4 samples at a time ----
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -313,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
             if (nz & (((1u << MB) - 1u) << (b * MB))) {
 #pragma unroll
               for (int j = 0; j < MB; ++j)
-                mac(*reinterpret_cast<const float4 *>(&mat[(b * MB + j) * C4 + 4 * g]), x[b * MB + j], g, a0, a1, a2, a3);
+                mac(*reinterpret_cast<const float4 *>(&mat[(b * MB + j) * C4 + 4 * g]), X[b * MB + j], g, a0, a1, a2, a3);
             }
           }
           const float4 acc[4] = {a0, a1, a2, a3};
@@ -337,7 +589,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
               for (int j = 0; j < MB; ++j) wn[j] = *reinterpret_cast<const float4 *>(&mat[(nb * MB + j) * C4 + 4 * ng]);
             }
 #pragma unroll
-            for (int j = 0; j < MB; ++j) mac(wc[j], x[b * MB + j], g, a0, a1, a2, a3);
+            for (int j = 0; j < MB; ++j) mac(wc[j], X[b * MB + j], g, a0, a1, a2, a3);
 #pragma unroll
             for (int j = 0; j < MB; ++j) wc[j] = wn[j];
             __builtin_amdgcn_sched_barrier(0);
@@ -354,7 +606,10 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
 #pragma unroll
     for (int r = 0; r < 5; ++r)
       if (tv + 256 * r < kW4Win) win[tv + 256 * r] = wv[r];
-    if (c0 + kFChunk < p.total) load_x(c0 + kFChunk, tv);
+    if (c0 + kFChunk < p.total) {
+      put_rec(tv, ((c0 >> 10) + 1) & 1);  // the next chunk's frame records
+      load_x(c0 + kFChunk, tv);
+    }
 
     // ---- per-16 prefix / suffix / block maxima: 4 lanes x 4 samples = one aligned block ----
     const float i0 = pm.x, i1 = fmaxf(i0, pm.y), i2 = fmaxf(i1, pm.z), i3 = fmaxf(i2, pm.w);
@@ -443,6 +698,8 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
     // ---- emit 4 sample-frames per lane: lanes < 196 their own (gains at +240 in this chunk),
     //      tail lanes the previous chunk's (gains at 4t - 784), leaving their own in the slot ----
     if (c0 + kFChunk < p.total) fetch_window(n_st, tv);  // for the next chunk, ahead of the stores
+    if (c0 + 2 * kFChunk < p.total) fetch_rec(c0 + 2 * kFChunk, tv);  // written to LDS in the next chunk
+    if constexpr (DMX) __builtin_amdgcn_sched_barrier(0);  // keep both fetches ahead of the stores
     float4 gq = *reinterpret_cast<const float4 *>(&arr_g[is_tail ? 4 * tv - (kFChunk - kDelay) : 4 * tv + kDelay]);
     const float gs4[4] = {gq.x * 32768.f, gq.y * 32768.f, gq.z * 32768.f, gq.w * 32768.f};  // exact scaling
     if (c0 + kFChunk >= p.total && valid && 4 * tv >= cnt - kSave) {
@@ -465,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       // Pack to s16 (rint then saturate == the reference's clamp then lrintf: the bounds are
       // integers).  Piece k of a lane = dwords 4k..4k+3 of its 8*C bytes; dword d = sample
       // d / (C/2), channels 2*(d % (C/2)) and +1.
-      constexpr int H2 = C / 2, S = wide4_stage_stride(C), LR = wide4_stage_lanes(C, M);
+      constexpr int H2 = C / 2, S = wide4_stage_stride(C), LR = wide4_stage_lanes(C, M, DMX);
       uint32_t od[4 * H2];  // filled channel pair by channel pair so that y dies as od is born
 #pragma unroll
       for (int c = 0; c < C; c += 2) {

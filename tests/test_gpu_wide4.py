@@ -111,3 +111,113 @@ def test_wide4_short_last_chunk(hip, fs, calls):
         want = O.stream_run(omx, ch, x[0], fs)
         assert got.shape == want.shape
         assert np.array_equal(got, want), (fs, src, out)
+
+
+# ---- scalable channel audio: the demixer in front of the projection (render_wide4_kernel<.., DMX>) ----
+def _demix_frames(A, c, S):
+    import ctypes as C
+    F = len(c["schedule"])
+    frames = (A.DemixFrame * (S * F))()
+    st = A.DemixState()
+    rec = (C.c_int32 * 12)(*c["recon"])
+    for s in range(S):
+        A.lib().iamf_hip_demix_state_init(C.byref(st))
+        A.lib().iamf_hip_demix_set_info(C.byref(st), c["default"][0], c["default"][1])
+        cur = [1.0] * len(c["recon"])
+        for f, (mode, rg) in enumerate(c["schedule"]):
+            if rg is not None:
+                cur = rg
+            if mode > -1:
+                A.lib().iamf_hip_demix_set_info(C.byref(st), mode, -1)
+            A.lib().iamf_hip_demix_frame_fill(C.byref(st), len(cur), rec, (C.c_float * 12)(*cur),
+                                              C.byref(frames[s * F + f]))
+    return frames
+
+
+def _demix_render(A, c, mx, out_ch, x, calls):
+    """x [S][F][ch][fs] decoded channels -> demixer -> mx -> limiter -> s16; one render_ex per entry of
+    `calls` (frames), then the flush.  Returns [S][n][out_ch]."""
+    import torch
+    S, F, ch, fs = x.shape
+    b = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True)
+    b.set_demixer(c["layout"], c["order"], c["gains"], c["offset"])
+    frames = _demix_frames(A, c, S)
+    xin = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    outs = [[] for _ in range(S)]
+    f0 = 0
+    for nf in calls + [0]:
+        cap = max(nf * fs, 240) * out_ch * 2
+        pcm = torch.zeros((S, cap), dtype=torch.uint8, device="cuda")
+        if nf:
+            # the records of this call's frames, [S][nf]
+            raw = np.frombuffer(bytes(frames), dtype=np.uint8).reshape(S, F, -1)[:, f0:f0 + nf].copy()
+            d_fr = torch.from_numpy(raw).cuda()
+            a = A.RenderArgs()
+            a.d_in, a.in_stream_stride, a.in_frame_stride = xin.data_ptr() + 4 * f0 * ch * fs, F * ch * fs, ch * fs
+            a.n_frames, a.d_pcm, a.pcm_stream_stride_bytes, a.stream = nf, pcm.data_ptr(), cap, st
+            a.d_demix_frames = d_fr.data_ptr()
+            n = b.render_ex(a)
+        else:
+            n = b.flush(pcm.data_ptr(), cap, st)
+        torch.cuda.synchronize()
+        h = pcm.cpu().numpy()
+        for s in range(S):
+            outs[s].append(h[s][:n * out_ch * 2].view(np.int16).reshape(n, out_ch).copy())
+        f0 += nf
+    b.close()
+    return [np.concatenate(o, axis=0) for o in outs]
+
+
+def _demix_cases():
+    import demix_cases as D
+    cases = dict(D.STAGE_CASES)  # 256-sample frames: four frame records per 1024-sample chunk
+    cases["714_fs1024_pre40"] = D.make_case([1, 3, 7], {0: (0b110000, 0.7079458), 1: (0b001111, 1.4125376)},
+                                            offset=40, fs=1024, seed=770)
+    cases["514_fs512"] = D.make_case([1, 2, 4], {1: (0b001100, 1.2)}, default=(5, 9), fs=512, seed=780)
+    cases["712_fs960"] = D.make_case([8, 3, 6], {0: (0b110011, 1.1885022)}, default=(6, 2), offset=8, fs=960, seed=790)
+    cases["510_fs320"] = D.make_case([0, 1, 2], default=(2, 4), fs=320, seed=800)
+    return cases
+
+
+_LAYOUT_SS = {2: "L51", 3: "L512", 4: "L514", 5: "L71", 6: "L712", 7: "L714", 8: "L312"}
+
+
+@pytest.mark.parametrize("name", sorted(_demix_cases()))
+def test_wide4_demixer_exact(hip, name, monkeypatch):
+    """decoded layers -> demixer -> layout matrix -> limiter -> s16 on the wide4 kernel: bit-exact
+    against (oracle demixer, pinned to the reference's demixer.c) -> (oracle renderer chain), and
+    identical to the generic kernel's demixer"""
+    import demix_cases as D
+    A, G = hip
+    c = _demix_cases()[name]
+    S, fs, F = 2, c["fs"], len(c["schedule"])
+    ch = len(c["order"])
+    x = np.stack([np.stack([synth.uniform(c["seed"] + 100 * s + f, ch, fs, 0.9) for f in range(F)]) for s in range(S)])
+    dem = [D.drive_demixer(O.lib(), "orc_demixer_", c, x[s]) for s in range(S)]   # [F][ch][fs]
+    src = _LAYOUT_SS[c["layout"]]
+    outs = ["J", "H"] if ch == 12 else ["J"]
+    calls = [4, F - 4] if (4 * fs) % 1024 == 0 else [F]
+    for out in outs + ["id"]:
+        if out == "id":
+            mx, omx, och = G.identity_matrix(ch), None, ch
+        else:
+            try:
+                mx, omx = A.get_m2m_matrix(A.SS[src], A.SS[out]), O.get_m2m(O.SS[src], O.SS[out])
+            except KeyError:
+                continue
+            och = A.layout_channels(A.SS[out])
+        got = _demix_render(A, c, mx, och, x, calls)
+        monkeypatch.setenv("IAMF_HIP_NO_WIDE4", "1")
+        ref = _demix_render(A, c, mx, och, x, calls)
+        monkeypatch.delenv("IAMF_HIP_NO_WIDE4")
+        for s in range(S):
+            xd = np.ascontiguousarray(dem[s].transpose(1, 0, 2).reshape(ch, F * fs))
+            if omx is None:
+                z, _ = O.limiter_run(xd, [fs] * F)
+                want = O.pack(z, 16)
+            else:
+                want = O.stream_run(omx, och, xd, fs)
+            assert got[s].shape == want.shape, (name, out, s)
+            assert np.array_equal(ref[s], want), (name, out, s, "generic kernel")
+            assert np.array_equal(got[s], want), (name, out, s)
