@@ -32,6 +32,7 @@ WORKLOADS = {
     # name: (kind, in_id, out_id, in_ch, algorithmic bytes per sample-frame)
     "toa_binaural_limiter_s16": ("h2m", 3, 0x1020, 16, 16 * 4 + 2 * 2),
     "toa_ssH_limiter_s16": ("h2m", 3, 0x9A3, 16, 16 * 4 + 24 * 2),
+    "toa_ssB_limiter_s16": ("h2m", 3, 0x050, 16, 16 * 4 + 6 * 2),
     "714_ssJ_limiter_s16": ("m2m", 0x714, 0x470, 12, 12 * 4 + 12 * 2),
     # binaural by HRTF FIR (256-tap synthetic HRIRs; the reference's own binauraliser is not in its
     # tree -> "parity unpinned"): compute-bound on the f32 MFMA, 2*16*2*256 flop per sample-frame
@@ -40,6 +41,11 @@ WORKLOADS = {
     # bitstream order) through the demixer (output gains, S1to2..S5to7 / T2toT4 with a demixing mode
     # per frame, recon-gain smoothing), then 7.1.4 -> J, limiter, s16: the general kernel
     "scalable_714_ssJ_limiter_s16": ("demix", 0x714, 0x470, 12, 12 * 4 + 12 * 2),
+    # projection-mode 3rd-order ambisonics: 16 decoded channels -> de-mapping matrix ->
+    # 16 ambisonics channels -> binaural / 5.1.  Tolerance mode (AUTO): one composed matrix on the
+    # fast / wide4-MFMA kernel; IAMF_HIP_PROJECTION=exact in the environment gives the two exact stages
+    "toa_projection_binaural_limiter_s16": ("h2m_proj", 3, 0x1020, 16, 16 * 4 + 2 * 2),
+    "toa_projection_ssB_limiter_s16": ("h2m_proj", 3, 0x050, 16, 16 * 4 + 6 * 2),
 }
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA, dense (155 TF measured)
 FIR_TAPS = 256
@@ -130,7 +136,7 @@ def reference_baseline(workload, fs, seconds_target=12.0):
         x = W.quantize(np.clip(synth.hot(4242, in_ch, frames * fs), -1, 1 - 2 ** -15).astype(np.float32), 16)
         pd = lambda pid: W.param_definition(pid, 48000, mode=1)
         stream = W.sequence_header(1) + W.codec_config_lpcm(0, fs, 16, 48000)
-        if kind == "h2m":
+        if kind in ("h2m", "h2m_proj"):
             stream += W.audio_element_ambisonics_mono(1, 0, in_ch, list(range(in_ch)))
         else:
             stream += W.audio_element_channel(1, 0, 7, list(range(W.LAYOUT_SUBSTREAMS[7][0])))
@@ -138,13 +144,13 @@ def reference_baseline(workload, fs, seconds_target=12.0):
             xal = np.empty_like(x)
             for p_, a in enumerate(perm):
                 xal[a] = x[p_]
-        ss = {0x1020: None, 0x9A3: 7, 0x470: 9}[out_id]
+        ss = {0x1020: None, 0x9A3: 7, 0x470: 9, 0x050: 1}[out_id]
         layouts = [("binaural",)] if ss is None else [("ss", ss)]
         stream += W.mix_presentation(1, [dict(eid=1, pdef=pd(100), default_q78=0)], dict(pdef=pd(101), default_q78=0), layouts)
         desc_len = len(stream)
         for f in range(frames):
             stream += W.temporal_delimiter()
-            if kind == "h2m":
+            if kind in ("h2m", "h2m_proj"):
                 stream += W.audio_frames([(i, W.lpcm_bytes(x[i:i + 1, f * fs:(f + 1) * fs], 16)) for i in range(in_ch)])
             else:
                 stream += W.audio_frames(W.channel_element_substreams(7, xal[:, f * fs:(f + 1) * fs], 0, 16))
@@ -215,7 +221,7 @@ def main():
         hr = (rng.standard_normal((2, in_ch, FIR_TAPS)) * np.exp(-np.arange(FIR_TAPS) / 40.0) * 0.08).astype(np.float32)
         mx = A.fir_matrix(hr)
     else:
-        mx = A.get_h2m_matrix(in_id, out_id) if kind == "h2m" else A.get_m2m_matrix(in_id, out_id)   # m2m, demix
+        mx = A.get_h2m_matrix(in_id, out_id) if kind in ("h2m", "h2m_proj") else A.get_m2m_matrix(in_id, out_id)
     out_ch = A.layout_channels(out_id)
     S, F, fs = args.streams, args.frames, args.frame_size
 
@@ -225,6 +231,11 @@ def main():
     batch = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True,
                     fir_taps=FIR_TAPS if kind == "fir" else 0)
     demix_args = None
+    if kind == "h2m_proj":   # a well-conditioned Q15 de-mapping matrix (identity/2 + noise)
+        rngp = np.random.default_rng(5)
+        Pm = rngp.integers(-6000, 6000, size=(in_ch, in_ch)).astype(np.float32) * np.float32(2.0 ** -15)
+        Pm[np.arange(in_ch), np.arange(in_ch)] += np.float32(0.5)
+        batch.set_projection(Pm.astype(np.float32))
     if kind == "demix":
         import ctypes as C
         import demix_cases as D
@@ -240,10 +251,23 @@ def main():
             A.lib().iamf_hip_demix_set_info(C.byref(st), 1, 3)
             for f_ in range(F):
                 A.lib().iamf_hip_demix_set_info(C.byref(st), (0, 1, 2, 4, 5, 6)[(s_ + f_) % 6], -1)
-                gains_ = (C.c_float * 12)(*[0.5 + 0.5 * ((s_ * 7 + f_ * 3 + i) % 16) / 15.0 for i in range(len(rec))])
+                gains_ = (C.c_float * 12)(*[0.75 + 0.25 * ((s_ * 7 + f_ * 3 + i) % 16) / 15.0 for i in range(len(rec))])
                 A.lib().iamf_hip_demix_frame_fill(C.byref(st), len(rec), rc, gains_, C.byref(frames_rec[s_ * F + f_]))
         d_frames = torch.from_numpy(np.frombuffer(bytes(frames_rec), dtype=np.uint8).copy()).to(dev)
         demix_args = d_frames
+        # The decoded layers are the DOWN-MIX of the programme x (7.1.4 playback order), made with the
+        # same per-frame factors the demixer will use (the encoder side of the codec: IAMF spec 7.2),
+        # so that what leaves the demixer is the programme every other workload renders.
+        raw = np.frombuffer(bytes(frames_rec), dtype=np.float32).reshape(S, F, -1)
+        cf = torch.from_numpy(raw[:, :, 5:10].copy()).to(dev).view(S, F, 5, 1)   # cur: alpha beta gamma delta w
+        al, be, ga, de = cf[:, :, 0], cf[:, :, 1], cf[:, :, 2], cf[:, :, 3]
+        L7, R7, Cc, LFE, SL7, SR7, BL7, BR7, HFL, HFR, HBL, HBR = [x[:, :, i] for i in range(12)]
+        SL5, SR5 = al * SL7 + be * BL7, al * SR7 + be * BR7
+        L2, R2 = L7 + de * SL5 + 0.707 * Cc, R7 + de * SR5 + 0.707 * Cc
+        HL, HR = HFL + ga * HBL, HFR + ga * HBR
+        x = torch.stack([L2 / 0.7079458, R2 / 0.7079458, L7, R7, HL / 1.4125376, HR / 1.4125376, Cc, LFE,
+                         SL7, SR7, HFL, HFR], dim=2).contiguous()
+        del L7, R7, Cc, LFE, SL7, SR7, BL7, BR7, HFL, HFR, HBL, HBR, SL5, SR5, L2, R2, HL, HR
     stride_bytes = F * fs * out_ch * 2
     pcm = [torch.zeros((S, stride_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
     gather_on = world > 1 and args.gather != "none"
@@ -317,7 +341,7 @@ def main():
         value = total_sf / elapsed / 1e6
         achieved = bytes_per_sf * sf_per_step / (kernel_ms * 1e-3) / 1e9
         if kind == "demix":
-            ktag = "render_kernel<%d>" % in_ch
+            ktag = "render_wide4_kernel<%d, %d, false, true>" % (in_ch, out_ch)
         elif kind == "fir":
             ktag = "render_fast_kernel<%d, 2, true>" % in_ch
         elif out_ch <= 2:
@@ -359,6 +383,7 @@ def main():
             out["config"]["parity"] = "unpinned (HRTF arithmetic is not in the reference tree)"
         if not args.no_cpu_baseline:
             wl = {"fir": "toa_binaural_limiter_s16", "demix": "714_ssJ_limiter_s16"}.get(kind, args.workload)
+            wl = wl.replace("toa_projection_", "toa_")
             refb = reference_baseline(wl, fs)
             port = cpu_baseline(wl, fs, seconds_target=6.0 if refb else 12.0)
             if refb:   # the reference itself is the baseline; the oracle port is reported beside it
@@ -368,6 +393,8 @@ def main():
                 out["cpu_baseline"]["sample"] += " [the matrix binaural path: the reference has no buildable HRTF]"
             if kind == "demix":
                 out["cpu_baseline"]["sample"] += " [the single-layer 7.1.4 stream: without the demixer stage]"
+            if kind == "h2m_proj":
+                out["cpu_baseline"]["sample"] += " [the mono-mode stream: without the de-mapping stage]"
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

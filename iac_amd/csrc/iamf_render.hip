@@ -149,6 +149,10 @@ struct iamf_hip_batch {
   int dmx_n_in = 0, dmx_n_out = 0;
   float *d_pre = nullptr;
   int pre_l = 0;
+  std::vector<float> h_fm;          // host copy of d_matrix ([n_feeds][m])
+  float *d_matrix_pre = nullptr;    // [n_feeds][pre_l]: renderer matrix x de-mapping matrix (tolerance mode)
+  uint32_t nz_mask_pre[6] = {0, 0, 0, 0, 0, 0};
+  int sparse_pre = 0;
   bool demix = false;
   int demix_steps = 0, demix_skip = 0, demix_layout = 0, demix_gmask = 0, demix_w4 = 0;
   int32_t *d_demix_tab = nullptr;
@@ -353,6 +357,7 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
   p.out_format = b->cfg.out_format;
   p.limiter_on = b->cfg.limiter_enable ? 1 : 0;
   p.loudness_on = b->cfg.loudness_enable ? 1 : 0;
+  bool tolerance = false;
   {
     const int proj = b->cfg.projection;
     const char *env = getenv("IAMF_HIP_PROJECTION");  // "exact" / "mfma" override for experiments
@@ -360,6 +365,7 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     if (env && !strcmp(env, "exact")) mf = false;
     if (env && !strcmp(env, "mfma")) mf = true;
     p.use_mfma = (mf && b->n_feeds <= 32) ? 1 : 0;
+    tolerance = mf;
   }
   p.n_atk = b->n_atk;
   p.n_end = b->n_end;
@@ -387,9 +393,20 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     p.dmx_n_out = b->dmx_n_out;
     p.dmx_tab = b->d_dmx_tab;
   }
+  int m_eff = b->m;
   if (b->d_pre && a.d_in) {
-    p.pre_matrix = b->d_pre;
-    p.pre_l = b->pre_l;
+    const int l = b->pre_l;
+    const bool inst = l == 1 || l == 2 || l == 4 || l == 6 || l == 8 || l == 9 || l == 10 || l == 12 || l == 14 ||
+                      l == 16 || l == 24;
+    if (tolerance && b->d_matrix_pre && inst && !p.in2) {  // one composed matrix, see iamf_hip_batch_set_projection
+      p.matrix = b->d_matrix_pre;
+      for (int g = 0; g < 6; ++g) p.nz_mask[g] = b->nz_mask_pre[g];
+      p.sparse = getenv("IAMF_HIP_DENSE") ? 0 : b->sparse_pre;
+      m_eff = l;
+    } else {
+      p.pre_matrix = b->d_pre;
+      p.pre_l = b->pre_l;
+    }
   }
   if (b->demix && a.d_in) {
     p.demix_on = 1;
@@ -410,7 +427,7 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
   }
   const size_t lds = sizeof(float) * ((size_t)(p.out_ch + 2) * kRing + 3 * kChunk + kHead + 4 +
                                       ((b->dmx || b->demix) ? (size_t)kChCount * kChunk : 0));
-  const int r = launch(p, b->m, lds, static_cast<hipStream_t>(a.stream));
+  const int r = launch(p, m_eff, lds, static_cast<hipStream_t>(a.stream));
   if (r != IAMF_HIP_OK) return r;
   if (b->fir && p.in) b->fir_cur ^= 1;
   const int64_t before = p.limiter_on ? (b->pos > kDelay ? b->pos - kDelay : 0) : b->pos;
@@ -546,6 +563,7 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
         }
       }
     b->sparse = 2 * set < all ? 1 : 0;
+    b->h_fm = fm;
   }
 
   // limiter constants and the coefficient table.  currentTC only ever takes the values
@@ -605,6 +623,7 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
 
 void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   if (!b) return;
+  (void)hipFree(b->d_matrix_pre);
   (void)hipFree(b->d_matrix);
   (void)hipFree(b->d_gains);
   (void)hipFree(b->d_ctab);
@@ -721,6 +740,38 @@ int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *matrix, int l_
   HIPCHK(hipMalloc(&b->d_pre, sizeof(float) * (size_t)l_in * b->m));
   HIPCHK(hipMemcpy(b->d_pre, matrix, sizeof(float) * (size_t)l_in * b->m, hipMemcpyHostToDevice));
   b->pre_l = l_in;
+  // Tolerance mode (IAMF_HIP_PROJ_MFMA, or AUTO with an H2M matrix: results within +-1 LSB of the
+  // reference): de-mapping and rendering are both linear, so one matrix W' = W * P^T (products and
+  // sums in double, rounded once) takes the decoded channels straight to the output slots and the
+  // call runs on the same kernels as a mono-mode element with l_in channels.  IAMF_HIP_PROJ_EXACT
+  // keeps the reference's two stages and their f32 roundings (generic kernel).
+  (void)hipFree(b->d_matrix_pre);
+  b->d_matrix_pre = nullptr;
+  if (!b->h_fm.empty()) {
+    std::vector<float> w((size_t)b->n_feeds * l_in);
+    for (int f = 0; f < b->n_feeds; ++f)
+      for (int l = 0; l < l_in; ++l) {
+        double acc = 0;
+        for (int r = 0; r < b->m; ++r) acc += (double)b->h_fm[(size_t)f * b->m + r] * (double)matrix[(size_t)l * b->m + r];
+        w[(size_t)f * l_in + l] = (float)acc;
+      }
+    int set = 0, all = 0;
+    for (int g = 0; g < 6; ++g) b->nz_mask_pre[g] = 0;
+    for (int g = 0; g < 6 && 4 * g < b->cfg.out_channels; ++g)
+      for (int k = 0; k < l_in && k < 32; ++k) {
+        bool nz = false;
+        for (int c = 4 * g; c < 4 * g + 4 && c < b->cfg.out_channels; ++c)
+          if (b->src_feed[c] >= 0 && w[(size_t)b->src_feed[c] * l_in + k] != 0.f) nz = true;
+        ++all;
+        if (nz) {
+          ++set;
+          b->nz_mask_pre[g] |= 1u << k;
+        }
+      }
+    b->sparse_pre = 2 * set < all ? 1 : 0;
+    HIPCHK(hipMalloc(&b->d_matrix_pre, sizeof(float) * w.size()));
+    HIPCHK(hipMemcpy(b->d_matrix_pre, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
+  }
   return IAMF_HIP_OK;
 }
 

@@ -164,7 +164,7 @@ def test_projection_demapping_vs_oracle(hip):
     P = (rng.integers(-12000, 12000, size=(L_in, 9)).astype(np.float32) * np.float32(2.0 ** -15)).astype(np.float32)
     xd = np.stack([synth.hot(80 + s, L_in, n, sigma=0.15, burst_phase=200 + 300 * s, burst_period=1900) for s in range(S)])
     oid = A.SS["J"]
-    b = A.Batch(S, A.get_h2m_matrix(2, oid), 12, frame_size=fs)
+    b = A.Batch(S, A.get_h2m_matrix(2, oid), 12, frame_size=fs, projection=A.PROJ_EXACT)
     b.set_projection(P)
     got = _run_ex(A, G, torch, b, S, L_in, xd, fs, 12, A.FMT_S16, calls=[1, 2])
     b.close()
@@ -175,6 +175,38 @@ def test_projection_demapping_vs_oracle(hip):
         y = O.render(O.get_h2m(2, O.SS["J"]), xa, 12)
         z, _ = O.limiter_run(y, [fs] * F)
         assert np.array_equal(got[s], O.pack(z, 16)), s
+
+
+@pytest.mark.parametrize("order,l_in,out", [(3, 16, "BINAURAL"), (3, 16, "B"), (3, 16, "J"), (2, 9, "H"), (1, 4, "A"),
+                                             (2, 12, "J")])
+def test_projection_tolerance_mode_within_1lsb(hip, order, l_in, out):
+    """IAMF_HIP_PROJ_AUTO / _MFMA: de-mapping and H2M matrix composed into one (W * P^T in double),
+    so the call runs on the fast / wide4 kernels.  Tolerance: +-1 LSB of the 16-bit PCM against the
+    reference's two f32 stages, and most samples identical."""
+    A, G, torch = hip
+    fs, F, S = 1024, 4, 2
+    n = fs * F
+    m = (order + 1) ** 2
+    rng = np.random.default_rng(1000 * order + l_in)
+    P = (rng.integers(-9000, 9000, size=(l_in, m)).astype(np.float32) * np.float32(2.0 ** -15)).astype(np.float32)
+    P[np.arange(min(l_in, m)), np.arange(min(l_in, m))] += np.float32(0.5)
+    xd = np.stack([synth.hot(90 + s, l_in, n, sigma=0.15, burst_phase=200 + 300 * s, burst_period=1900) for s in range(S)])
+    oid = A.SS[out]
+    ch = A.layout_channels(oid)
+    b = A.Batch(S, A.get_h2m_matrix(order, oid), ch, frame_size=fs)   # projection=AUTO
+    b.set_projection(P)
+    got = _run_ex(A, G, torch, b, S, l_in, xd, fs, ch, A.FMT_S16, calls=[1, 3])
+    b.close()
+    for s in range(S):
+        xa = np.zeros((m, n), np.float32)
+        for l in range(l_in):
+            xa = (xa + (xd[s][l][None, :] * P[l][:, None]).astype(np.float32)).astype(np.float32)
+        y = O.render(O.get_h2m(order, O.SS[out]), xa, ch)
+        z, _ = O.limiter_run(y, [fs] * F)
+        want = O.pack(z, 16)
+        d = np.abs(got[s].astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1, (s, int(d.max()))
+        assert (d != 0).mean() < 0.2, (s, float((d != 0).mean()))
 
 
 def test_mix_gain_ramps_vs_oracle(hip):
