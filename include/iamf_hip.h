@@ -179,7 +179,10 @@ int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *
  * elements): x[r] = sum over the l_in decoded channels l, ascending, of in[l] * matrix[l*m + r]
  * (iamf_core_decoder_convert_projection, src/iamf_dec/IAMF_core_decoder.c:116-130).  `matrix` is a
  * host array of l_in * m floats (the Q15 demixing matrix of the bitstream as floats); afterwards
- * element 0's input carries l_in channels per frame instead of m.  Call before the first render. */
+ * element 0's input carries l_in channels per frame instead of m.  Call before the first render.
+ * With IAMF_HIP_PROJ_EXACT the two stages run as the reference runs them (bit-exact); in tolerance
+ * mode (IAMF_HIP_PROJ_MFMA, or _AUTO with an H2M matrix: +-1 LSB of the PCM) they are composed into
+ * one matrix on the host and the call costs what a mono-mode element of l_in channels costs. */
 int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *matrix, int l_in);
 
 /* ------------------------------------------------------------------------------------------
@@ -216,7 +219,7 @@ typedef struct iamf_hip_demix_frame {
   float prev[5], cur[5];            /* alpha, beta, gamma, delta, w of the previous / current mode:
                                        the first frame_offset % frame_size samples use prev */
   int32_t n_recon;                  /* channels of demixer_set_recon_gain valid for this frame: decoded or */
-  int32_t recon_ch[12];             /* reconstructed channels of the target layout */
+  int32_t recon_ch[12];             /* reconstructed channels of the target layout; distinct IAChannel ids */
   float recon_prev[12], recon_cur[12]; /* per recon channel: smoothed gain of the last frame / of this one */
 } iamf_hip_demix_frame;
 
