@@ -44,9 +44,9 @@ extern "C" int iamf_hip_wide4_launch(const void *params, int m, hipStream_t st);
 namespace {
 
 #include "render_common.hpp"
-#include "render_generic.hpp"
 #include "render_fir.hpp"
 #include "render_fast.hpp"
+#include "render_generic.hpp"
 #include "render_wide.hpp"
 
 // ------------------------------------------------------------------------------------------

@@ -288,14 +288,20 @@ __global__ __launch_bounds__(kChunk) void render_kernel(const RenderParams p) {
           n_st = n_end;
         }
       } else {
-        // at least one trigger: run the recurrence serially over the chunk
+        // at least one trigger: wave 0 runs the recurrence over the chunk
         arr_p[t] = pk;
         arr_e[t] = e;
         __syncthreads();
-        if (t == 0) {
+        if (t < 64) {
+          // whole 64-sample blocks: the wave-level recurrence of the fast kernels (render_fast.hpp);
+          // what is left of a ragged chunk: sample by sample
           float lgc = g_cur, lgs = gs, lge = ge;
           int ln = n_st;
-          for (int i = 0; i < cnt; ++i) {
+          const int nfull = cnt >> 6;
+          if (nfull > 0)
+            limiter_wave(arr_p, arr_g, [head, &p](int ci) { return ci < kHead ? head[ci] : p.ctab[ci]; }, 0, nfull,
+                         ln, lgs, lge, lgc, thr, n_atk, n_end);
+          for (int i = 64 * nfull; t == 0 && i < cnt; ++i) {
             if (ln < n_end) {
               const int cl = ln + 1;
               const float c = cl < kHead ? head[cl] : p.ctab[cl];
@@ -312,10 +318,12 @@ __global__ __launch_bounds__(kChunk) void render_kernel(const RenderParams p) {
             }
             arr_g[i] = lgc;
           }
-          st[0] = lgc;
-          st[1] = lgs;
-          st[2] = lge;
-          st[3] = __int_as_float(ln);
+          if (t == 0) {
+            st[0] = lgc;
+            st[1] = lgs;
+            st[2] = lge;
+            st[3] = __int_as_float(ln);
+          }
         }
         __syncthreads();
         g = arr_g[t];
