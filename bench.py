@@ -41,6 +41,11 @@ WORKLOADS = {
     # bitstream order) through the demixer (output gains, S1to2..S5to7 / T2toT4 with a demixing mode
     # per frame, recon-gain smoothing), then 7.1.4 -> J, limiter, s16: the general kernel
     "scalable_714_ssJ_limiter_s16": ("demix", 0x714, 0x470, 12, 12 * 4 + 12 * 2),
+    # §8 A5: a 7.1.4 element that carries a demixing parameter, rendered to a smaller IAMF layout by the
+    # parametric down-mixer (downmix_renderer.c) with a mode per frame, instead of a gain matrix
+    # (the reference takes the down-mixer unless the input has height channels and the output none)
+    "714_downmix_512_limiter_s16": ("dmx", 7, 3, 12, 12 * 4 + 8 * 2),
+    "710_downmix_stereo_limiter_s16": ("dmx", 5, 1, 8, 8 * 4 + 2 * 2),
     # projection-mode 3rd-order ambisonics: 16 decoded channels -> de-mapping matrix ->
     # 16 ambisonics channels -> binaural / 5.1.  Tolerance mode (AUTO): one composed matrix on the
     # fast / wide4-MFMA kernel; IAMF_HIP_PROJECTION=exact in the environment gives the two exact stages
@@ -220,9 +225,11 @@ def main():
         rng = np.random.default_rng(5)
         hr = (rng.standard_normal((2, in_ch, FIR_TAPS)) * np.exp(-np.arange(FIR_TAPS) / 40.0) * 0.08).astype(np.float32)
         mx = A.fir_matrix(hr)
+    elif kind == "dmx":
+        mx = A.dmx_matrix(in_id, out_id)
     else:
         mx = A.get_h2m_matrix(in_id, out_id) if kind in ("h2m", "h2m_proj") else A.get_m2m_matrix(in_id, out_id)
-    out_ch = A.layout_channels(out_id)
+    out_ch = mx.channels if kind == "dmx" else A.layout_channels(out_id)
     S, F, fs = args.streams, args.frames, args.frame_size
 
     x = synth_hot_device(S, in_ch, F, fs, 1000 + rank, dev)
@@ -231,6 +238,19 @@ def main():
     batch = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True,
                     fir_taps=FIR_TAPS if kind == "fir" else 0)
     demix_args = None
+    if kind == "dmx":   # host control plane: a down-mix mode per frame and stream (DMRenderer_set_mode_weight)
+        import ctypes as C
+        fr_ = (A.DmxFrame * (S * F))()
+        st_ = A.DmxState()
+        for s_ in range(S):
+            A.lib().iamf_hip_dmx_state_init(C.byref(st_))
+            A.lib().iamf_hip_dmx_set_mode_weight(C.byref(st_), 1, 3)
+            for f_ in range(F):
+                fr_[s_ * F + f_].offset = 0
+                A.lib().iamf_hip_dmx_coefficients(C.byref(st_), fr_[s_ * F + f_].prev)
+                A.lib().iamf_hip_dmx_set_mode_weight(C.byref(st_), (0, 1, 2, 4, 5, 6)[(s_ + f_) % 6], -1)
+                A.lib().iamf_hip_dmx_coefficients(C.byref(st_), fr_[s_ * F + f_].cur)
+        demix_args = torch.from_numpy(np.frombuffer(bytes(fr_), dtype=np.uint8).copy()).to(dev)
     if kind == "h2m_proj":   # a well-conditioned Q15 de-mapping matrix (identity/2 + noise)
         rngp = np.random.default_rng(5)
         Pm = rngp.integers(-6000, 6000, size=(in_ch, in_ch)).astype(np.float32) * np.float32(2.0 ** -15)
@@ -287,7 +307,10 @@ def main():
             a = A.RenderArgs()
             a.d_in, a.in_stream_stride, a.in_frame_stride = x.data_ptr(), stream_stride, frame_stride
             a.n_frames, a.d_pcm, a.pcm_stream_stride_bytes, a.stream = F, buf.data_ptr(), stride_bytes, stream
-            a.d_demix_frames = demix_args.data_ptr()
+            if kind == "dmx":
+                a.d_dmx_frames = demix_args.data_ptr()
+            else:
+                a.d_demix_frames = demix_args.data_ptr()
             n = batch.render_ex(a)
         else:
             n = batch.render(x.data_ptr(), stream_stride, frame_stride, F, buf.data_ptr(), stride_bytes, stream)
@@ -340,7 +363,10 @@ def main():
         total_sf = sf_per_step * args.steps * world
         value = total_sf / elapsed / 1e6
         achieved = bytes_per_sf * sf_per_step / (kernel_ms * 1e-3) / 1e9
-        if kind == "demix":
+        if kind == "dmx":
+            ktag = ("render_fast_kernel<%d, %d, false, true>" if out_ch <= 2 else
+                    "render_wide4_kernel<%d, %d, false, false, true>") % (in_ch, out_ch)
+        elif kind == "demix":
             ktag = "render_wide4_kernel<%d, %d, false, true>" % (in_ch, out_ch)
         elif kind == "fir":
             ktag = "render_fast_kernel<%d, 2, true>" % in_ch
@@ -384,6 +410,8 @@ def main():
         if not args.no_cpu_baseline:
             wl = {"fir": "toa_binaural_limiter_s16", "demix": "714_ssJ_limiter_s16"}.get(kind, args.workload)
             wl = wl.replace("toa_projection_", "toa_")
+            if kind == "dmx":
+                wl = "714_ssJ_limiter_s16"
             refb = reference_baseline(wl, fs)
             port = cpu_baseline(wl, fs, seconds_target=6.0 if refb else 12.0)
             if refb:   # the reference itself is the baseline; the oracle port is reported beside it
@@ -393,6 +421,8 @@ def main():
                 out["cpu_baseline"]["sample"] += " [the matrix binaural path: the reference has no buildable HRTF]"
             if kind == "demix":
                 out["cpu_baseline"]["sample"] += " [the single-layer 7.1.4 stream: without the demixer stage]"
+            if kind == "dmx":
+                out["cpu_baseline"]["sample"] += " [the 7.1.4 -> J matrix stream: the reference's down-mixer needs a demixing-parameter stream]"
             if kind == "h2m_proj":
                 out["cpu_baseline"]["sample"] += " [the mono-mode stream: without the de-mapping stage]"
         print(json.dumps(out))

@@ -37,6 +37,7 @@
 
 #include "../../include/iamf_hip.h"
 
+extern "C" int iamf_hip_wide4_has_downmixer(int m, int c);                            // iamf_render_wide4.hip
 extern "C" int iamf_hip_wide4_has_demixer(int m, int c);                              // iamf_render_wide4.hip
 extern "C" int iamf_hip_wide4_has(int m, int c);                                      // iamf_render_wide4.hip
 extern "C" int iamf_hip_wide4_launch(const void *params, int m, hipStream_t st);      // iamf_render_wide4.hip
@@ -44,6 +45,7 @@ extern "C" int iamf_hip_wide4_launch(const void *params, int m, hipStream_t st);
 namespace {
 
 #include "render_common.hpp"
+#include "render_downmix.hpp"
 #include "render_fir.hpp"
 #include "render_fast.hpp"
 #include "render_generic.hpp"
@@ -223,6 +225,28 @@ void launch_fast_m(const RenderParams &p, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((render_fast_kernel<M, 2>), grid, dim3(256), lds, st, p);
 }
 
+// parametric down-mixer to mono / stereo: 7.1 -> {2, 1}, 5.1 -> {2, 1}, stereo -> mono
+template <int M, int OC>
+void launch_fast_down_mc(const RenderParams &p, dim3 grid, hipStream_t st) {
+  const size_t lds = sizeof(float) * (size_t)fast_lds_floats(OC, M, p.n_end + 1);
+  static bool opted = false;
+  if (!opted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, OC, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    opted = true;
+  }
+  hipLaunchKernelGGL((render_fast_kernel<M, OC, false, true>), grid, dim3(256), lds, st, p);
+}
+bool launch_fast_down(const RenderParams &p, int m, dim3 grid, hipStream_t st) {
+  if (m == 8 && p.out_ch == 2) launch_fast_down_mc<8, 2>(p, grid, st);
+  else if (m == 8 && p.out_ch == 1) launch_fast_down_mc<8, 1>(p, grid, st);
+  else if (m == 6 && p.out_ch == 2) launch_fast_down_mc<6, 2>(p, grid, st);
+  else if (m == 6 && p.out_ch == 1) launch_fast_down_mc<6, 1>(p, grid, st);
+  else if (m == 2 && p.out_ch == 1) launch_fast_down_mc<2, 1>(p, grid, st);
+  else return false;
+  return true;
+}
+
 template <int M>
 void launch_wide_m(const RenderParams &p, dim3 grid, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)wide_lds_floats(p.out_ch, M);
@@ -242,10 +266,11 @@ void launch_wide_m(const RenderParams &p, dim3 grid, hipStream_t st) {
 
 // The fast kernel takes aligned, limiter-on calls into 1- or 2-channel layouts; everything else
 // (odd sizes, flush, limiter off, wide layouts) goes to the generic kernel.  Both are exact.
-bool fast_path_ok(const RenderParams &p) {
+bool fast_path_ok(const RenderParams &p, bool down_mixer = false) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
   if (!p.limiter_on || !p.in || p.out_ch > 2 || p.n_end + 1 > kFTabMax) return false;
-  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix || p.demix_on) return false;
+  if (p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix || p.demix_on) return false;
+  if (p.dmx_on && !(down_mixer && p.dmx_frames)) return false;
   if ((p.pos0 & 15) || (p.total & 63) || (p.frame_size & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
@@ -253,11 +278,12 @@ bool fast_path_ok(const RenderParams &p) {
 }
 
 // The wide kernel: 3..24 output channels, limiter on, aligned calls.
-bool wide_path_ok(const RenderParams &p, int m, bool with_demixer = false) {
+bool wide_path_ok(const RenderParams &p, int m, bool with_stage = false) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
   if (!p.limiter_on || !p.in || p.out_ch <= 2 || p.out_ch > kMaxOut || p.n_end < kWWin) return false;
-  if (p.in2 || p.dmx_on || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix) return false;
-  if (p.demix_on && !with_demixer) return false;
+  if (p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix) return false;
+  if ((p.demix_on || p.dmx_on) && !with_stage) return false;  // demixer / down-mixer: wide4 variants only
+  if (p.dmx_on && !p.dmx_frames) return false;
   if ((p.pos0 & 15) || (p.total & 63)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
   return sizeof(float) * (size_t)wide_lds_floats(p.out_ch, m) <= 80 * 1024;
@@ -272,6 +298,7 @@ bool wide4_path_ok(const RenderParams &p, int m) {
       (p.frame_size & 3) || p.n_end < 1088)
     return false;
   if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
+  if (p.dmx_on) return iamf_hip_wide4_has_downmixer(m, p.out_ch) != 0;
   if (p.demix_on)  // scalable channel audio: the variant with the demixer in front of the projection
     return p.demix_w4 && !p.use_mfma && (p.demix_i0 & 3) == 0 && iamf_hip_wide4_has_demixer(m, p.out_ch) != 0;
   return iamf_hip_wide4_has(m, p.out_ch) != 0;
@@ -293,9 +320,14 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return IAMF_HIP_OK;
   }
+  if (p.dmx_on && fast_path_ok(p, true) && launch_fast_down(p, m, grid, st)) {
+    HIPCHK(hipGetLastError());
+    return IAMF_HIP_OK;
+  }
   const bool fast = fast_path_ok(p);
   const bool wide = !fast && wide_path_ok(p, m);
-  if ((wide || (p.demix_on && wide_path_ok(p, m, true))) && wide4_path_ok(p, m) && iamf_hip_wide4_launch(&p, m, st)) {
+  if ((wide || ((p.demix_on || p.dmx_on) && wide_path_ok(p, m, true))) && wide4_path_ok(p, m) &&
+      iamf_hip_wide4_launch(&p, m, st)) {
     HIPCHK(hipGetLastError());
     return IAMF_HIP_OK;
   }
@@ -392,6 +424,8 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     p.dmx_n_in = b->dmx_n_in;
     p.dmx_n_out = b->dmx_n_out;
     p.dmx_tab = b->d_dmx_tab;
+    p.dmx_in_layout = b->cfg.matrix.in_id;
+    p.dmx_out_layout = b->cfg.matrix.out_id;
   }
   int m_eff = b->m;
   if (b->d_pre && a.d_in) {

@@ -11,6 +11,7 @@
 namespace {
 
 #include "render_common.hpp"
+#include "render_downmix.hpp"
 #include "render_fir.hpp"
 #include "render_fast.hpp"
 #include "render_wide4.hpp"
@@ -46,8 +47,29 @@ void launch_mc_demixer(const RenderParams &p, hipStream_t st) {
   hipLaunchKernelGGL((render_wide4_kernel<M, C, false, true>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
 }
 
+// parametric down-mixer: M channels of the element's layout -> the C channels of a smaller IAMF layout
+template <int M, int C>
+void launch_mc_downmixer(const RenderParams &p, hipStream_t st) {
+  const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M, false);
+  static bool opted = false;
+  if (!opted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    opted = true;
+  }
+  hipLaunchKernelGGL((render_wide4_kernel<M, C, false, false, true>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
+}
+
 template <int M>
 bool launch_m(const RenderParams &p, hipStream_t st) {
+  if (p.dmx_on) {
+    if constexpr (M == 12 || M == 10 || M == 8) {
+      if (p.out_ch == 10 && M == 12) { launch_mc_downmixer<M, (M > 10 ? 10 : 6)>(p, st); return true; }
+      if (p.out_ch == 8 && M >= 10) { launch_mc_downmixer<M, (M > 8 ? 8 : 6)>(p, st); return true; }
+      if (p.out_ch == 6) { launch_mc_downmixer<M, 6>(p, st); return true; }
+    }
+    return false;
+  }
   if (p.demix_on) {
     if constexpr (M == 6 || M == 8 || M == 10 || M == 12) {
       switch (p.out_ch) {
@@ -77,6 +99,11 @@ bool launch_m(const RenderParams &p, hipStream_t st) {
 extern "C" __attribute__((visibility("hidden"))) int iamf_hip_wide4_has(int m, int c) {
   return (m == 4 || m == 6 || m == 8 || m == 9 || m == 10 || m == 12 || m == 16) &&
          (c == 6 || c == 8 || c == 10 || c == 12 || c == 24);
+}
+
+// 1 if the down-mixer variant exists: 7.1.4 -> {10, 8, 6}, 5.1.4 / 7.1.2 -> {8, 6}, 5.1.2 / 7.1 -> 6 channels
+extern "C" __attribute__((visibility("hidden"))) int iamf_hip_wide4_has_downmixer(int m, int c) {
+  return (m == 12 && (c == 10 || c == 8 || c == 6)) || (m == 10 && (c == 8 || c == 6)) || (m == 8 && c == 6);
 }
 
 // 1 if the demixer variant exists: m = channels of the scalable element's target layout (5.1 .. 7.1.4)

@@ -58,6 +58,7 @@ struct RenderParams {
   int64_t ramp_stream_stride;
   const iamf_hip_dmx_frame *dmx_frames;  // device [n_streams][frames of this call]
   int32_t dmx_n_in, dmx_n_out;
+  int32_t dmx_in_layout, dmx_out_layout;  // IAChannelLayoutType ids (render_downmix.hpp)
   const int32_t *dmx_tab;   // device [24]: IAChannel ids of the inputs, then (from [12]) of the outputs
   // ---- ambisonics projection de-mapping in front of element 0 (generic kernel) ----
   const float *pre_matrix;  // device [pre_l][M] or nullptr

@@ -170,8 +170,10 @@ __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
 
 // The HRTF variant runs 512 threads: all eight waves work in fir_stage (ear x quarter of the
 // channels), waves 0..3 alone (`act`) run the stages around it.
-template <int M, int OC, bool FIR = false>
+// DOWN: the element is rendered by the parametric down-mixer (render_downmix.hpp) instead of a matrix.
+template <int M, int OC, bool FIR = false, bool DOWN = false>
 __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kernel(const RenderParams p) {
+  static_assert(!(FIR && DOWN), "one renderer");
   extern __shared__ float lds[];
   constexpr int R = kFRing;
   constexpr int NB = R / 16;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kern
     if ((t & 15) == 0) ring_bm[rp >> 4] = sfx;
     if constexpr (!FIR)
       for (int i = t; i <= n_end; i += 256) ctl_lds[i] = p.ctab[i];
-    if (!FIR && t < OC * M) {
+    if (!FIR && !DOWN && t < OC * M) {
       const int c = t / M, m = t - c * M;
       const int f = p.src_feed[c];
       mat[t] = f >= 0 ? p.matrix[f * M + m] : 0.f;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kern
   const bool any_gain = eg_on || og_on || lg_on;
   bool live[OC];
 #pragma unroll
-  for (int c = 0; c < OC; ++c) live[c] = FIR || p.src_feed[c] >= 0;
+  for (int c = 0; c < OC; ++c) live[c] = FIR || DOWN || p.src_feed[c] >= 0;
   const float *fir_hist = FIR ? p.fir_hist + (int64_t)s * M * kFirHist : nullptr;
 
   const int64_t out_base = p.pos0 > kDelay ? p.pos0 - kDelay : 0;
@@ -248,6 +250,15 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kern
 
   // input of the first chunk
   float4 x[FIR ? 1 : M];
+  float drec[DOWN ? 11 : 1];  // DOWN: the frame record of the lane's samples, fetched with them
+  const int dmx_nfr = DOWN ? (p.total + fs - 1) / fs : 0;
+  auto load_drec = [&](int f) {
+    if constexpr (DOWN) {
+      const float *d = reinterpret_cast<const float *>(p.dmx_frames + (int64_t)s * dmx_nfr + (f < dmx_nfr ? f : dmx_nfr - 1));
+#pragma unroll
+      for (int i = 0; i < 11; ++i) drec[i] = d[i];
+    }
+  };
   if constexpr (!FIR) {
     const int k = 4 * t;
     if (k < p.total) {
@@ -260,6 +271,7 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kern
 #pragma unroll
       for (int m = 0; m < M; ++m) x[m] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    load_drec(k / fs);
   }
   __syncthreads();
   const int cw = chain_wave_pick(misc + 12);
@@ -275,6 +287,12 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kern
     float4 y[OC];
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (FIR) fir_stage<M>(p, in_s, fir_hist, c0, fir, fir);  // both ears of the chunk -> LDS partials
+    float4 yd[DOWN ? OC : 1];
+    if constexpr (DOWN) {
+      float4 cf[5];
+      downmix_factors(drec, k - (k / fs) * fs, cf);
+      downmix4<M, OC>(x, yd, cf, p.dmx_in_layout, p.dmx_out_layout);
+    }
     if (act)
 #pragma unroll
     for (int c = 0; c < OC; ++c) {
@@ -288,6 +306,8 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kern
         v.y = ((p0[u + 1] + p0[PS + u + 1]) + p0[2 * PS + u + 1]) + p0[3 * PS + u + 1];
         v.z = ((p0[u + 2] + p0[PS + u + 2]) + p0[2 * PS + u + 2]) + p0[3 * PS + u + 2];
         v.w = ((p0[u + 3] + p0[PS + u + 3]) + p0[2 * PS + u + 3]) + p0[3 * PS + u + 3];
+      } else if constexpr (DOWN) {
+        v = yd[c];
       } else if (live[c]) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -325,6 +345,7 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kern
         const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
 #pragma unroll
         for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
+        load_drec(f);
       }
     }
 

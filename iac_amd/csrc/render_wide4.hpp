@@ -44,26 +44,6 @@ __host__ __device__ constexpr int wide4_lds_floats(int c, int m, bool dmx) {
   return wide4_base_floats(c, m, dmx) + 4 * wide4_stage_lanes(c, m, dmx) * wide4_stage_stride(c) * 4;
 }
 
-// playback order of the scalable layouts (IAChannelLayoutType; reference IAMF_utils.c:117-133)
-__host__ __device__ constexpr int w4_layout_count(int layout) {
-  constexpr int n[9] = {1, 2, 6, 8, 10, 8, 10, 12, 6};
-  return n[layout];
-}
-__host__ __device__ constexpr int w4_layout_ch(int layout, int i) {
-  constexpr int ch[9][12] = {
-      {kChMono},
-      {kChL2, kChR2},
-      {kChL7, kChR7, kChC, kChLFE, kChSL5, kChSR5},
-      {kChL7, kChR7, kChC, kChLFE, kChSL5, kChSR5, kChHL, kChHR},
-      {kChL7, kChR7, kChC, kChLFE, kChSL5, kChSR5, kChHFL, kChHFR, kChHBL, kChHBR},
-      {kChL7, kChR7, kChC, kChLFE, kChSL7, kChSR7, kChBL7, kChBR7},
-      {kChL7, kChR7, kChC, kChLFE, kChSL7, kChSR7, kChBL7, kChBR7, kChHL, kChHR},
-      {kChL7, kChR7, kChC, kChLFE, kChSL7, kChSR7, kChBL7, kChBR7, kChHFL, kChHFR, kChHBL, kChHBR},
-      {kChL3, kChR3, kChC, kChLFE, kChTL, kChTR},
-  };
-  return ch[layout][i];
-}
-
 using w4_f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ float w4_comp(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
@@ -200,10 +180,12 @@ __device__ __forceinline__ void w4_demix(const RenderParams &p, float4 (&x)[M],
   }
 }
 
-template <int M, int C, bool MFMA, bool DMX>
+// DOWN: the element is rendered by the parametric down-mixer (render_downmix.hpp) instead of a matrix.
+template <int M, int C, bool MFMA, bool DMX, bool DOWN = false>
 __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams p) {
   static_assert((C & 1) == 0 && C >= 4 && C <= 24, "even channel counts");
   static_assert(!(DMX && MFMA), "the demixer variant projects on the VALU");
+  static_assert(!(DOWN && (MFMA || DMX)), "one renderer");
   extern __shared__ float lds[];
   constexpr int R = kFRing;
   constexpr int NB = R / 16;
@@ -370,7 +352,15 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
   constexpr int KS = (M + 3) / 4, RT = (C + 15) / 16;
   constexpr int NX = MFMA ? 4 * KS : M;
   float4 x[NX];
+  float drec[DOWN ? 11 : 1];  // DOWN: the frame record (iamf_hip_dmx_frame) of the lane's samples, fetched with them
+  const int down_nfr = DOWN ? (p.total + fs - 1) / fs : 0;
   auto load_x = [&](int cbase, int tt) {
+    if constexpr (DOWN) {
+      const int f = (cbase + 4 * tt) / fs;
+      const float *d = reinterpret_cast<const float *>(p.dmx_frames + (int64_t)s * down_nfr + (f < down_nfr ? f : down_nfr - 1));
+#pragma unroll
+      for (int i = 0; i < 11; ++i) drec[i] = d[i];
+    }
     if constexpr (MFMA) {
       const int j = tt & 15, kg = (tt >> 4) & 3, wv_ = tt >> 6;
 #pragma unroll
@@ -472,7 +462,27 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
 
     // ---- element renderer + gains (reference operation order), 4 slots x 4 samples at a time ----
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (MFMA) {
+    if constexpr (DOWN) {
+      float4 cf[5];
+      const int kk = c0 + 4 * tv;
+      downmix_factors(drec, kk - (kk / fs) * fs, cf);
+      downmix4<M, C>(x, y, cf, p.dmx_in_layout, p.dmx_out_layout);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float4 v = y[c];
+        if (any_gain) {
+          v.x = ((v.x * m_eg) * m_og) * m_lg;
+          v.y = ((v.y * m_eg) * m_og) * m_lg;
+          v.z = ((v.z * m_eg) * m_og) * m_lg;
+          v.w = ((v.w * m_eg) * m_og) * m_lg;
+        }
+        y[c] = v;
+        pm.x = fmaxf(pm.x, fabsf(v.x));
+        pm.y = fmaxf(pm.y, fabsf(v.y));
+        pm.z = fmaxf(pm.z, fabsf(v.z));
+        pm.w = fmaxf(pm.w, fabsf(v.w));
+      }
+    } else if constexpr (MFMA) {
       // One sample position i of every lane's quad at a time: 4 column groups x RT row tiles.  Lane
       // (j, g) receives channels 16*rt + 4*g + r of the sample owned by lane 16*cg + j; the row
       // transpose hands every lane all channels of its own sample.  Exact f32 products in a

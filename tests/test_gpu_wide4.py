@@ -221,3 +221,76 @@ def test_wide4_demixer_exact(hip, name, monkeypatch):
             assert got[s].shape == want.shape, (name, out, s)
             assert np.array_equal(ref[s], want), (name, out, s, "generic kernel")
             assert np.array_equal(got[s], want), (name, out, s)
+
+
+# ---- parametric down-mixer on the 4-samples-per-lane kernels (render_downmix.hpp) ----
+_DOWN_PAIRS = [(7, 6), (7, 4), (7, 3), (7, 8), (6, 3), (6, 8), (4, 3), (4, 8), (3, 8), (5, 2), (5, 1), (5, 0),
+               (2, 1), (2, 0), (1, 0)]
+
+
+@pytest.mark.parametrize("il,ol", _DOWN_PAIRS)
+@pytest.mark.parametrize("fs", [1024, 256])
+def test_downmixer_fast_paths_exact(hip, il, ol, fs, monkeypatch):
+    """element -> parametric down-mixer (mode per frame, previous mode for the first `offset` samples,
+    offsets not multiples of 4 included) -> limiter -> s16 on render_fast_kernel<.., DOWN> (mono /
+    stereo) and render_wide4_kernel<.., DOWN>: bit-exact against the oracle down-mixer (pinned to
+    the reference's DMRenderer_*) + limiter + pack, and identical to the generic kernel"""
+    import ctypes as C
+    import torch
+    A, G = hip
+    L = A.lib()
+    assert L.iamf_hip_dmx_valid(il, ol) == 1
+    S, F = 2, 8 * 1024 // fs
+    m, oc = O.LAYOUT_CH[il], O.LAYOUT_CH[ol]
+    sched = [((-1, 1, 2, 4, 5, 6, 0, 2)[f % 8], (0, 0, 37, 128, 0, fs - 3, 4, 0)[f % 8]) for f in range(F)]
+    x = np.stack([np.stack([synth.hot(500 + 31 * s + f, m, fs, sigma=0.3, burst_phase=100 + 50 * f, burst_period=700)
+                            for f in range(F)]) for s in range(S)])               # [S][F][m][fs]
+    frames = (A.DmxFrame * (S * F))()
+    st = A.DmxState()
+    for s in range(S):
+        L.iamf_hip_dmx_state_init(C.byref(st))
+        L.iamf_hip_dmx_set_mode_weight(C.byref(st), 1, 3)
+        for f, (mode, off) in enumerate(sched):
+            fr = frames[s * F + f]
+            fr.offset = off
+            L.iamf_hip_dmx_coefficients(C.byref(st), fr.prev)
+            if mode > -1:
+                L.iamf_hip_dmx_set_mode_weight(C.byref(st), mode, -1)
+            L.iamf_hip_dmx_coefficients(C.byref(st), fr.cur)
+    d_fr = torch.from_numpy(np.frombuffer(bytes(frames), dtype=np.uint8).copy()).cuda()
+    xin = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+    def run():
+        b = A.Batch(S, A.dmx_matrix(il, ol), oc, frame_size=fs, out_format=A.FMT_S16, limiter=True)
+        outs = [[] for _ in range(S)]
+        stt = torch.cuda.current_stream().cuda_stream
+        for last in (False, True):
+            cap = max(F * fs, 240) * oc * 2
+            pcm = torch.zeros((S, cap), dtype=torch.uint8, device="cuda")
+            if not last:
+                a = A.RenderArgs()
+                a.d_in, a.in_stream_stride, a.in_frame_stride = xin.data_ptr(), F * m * fs, m * fs
+                a.n_frames, a.d_pcm, a.pcm_stream_stride_bytes, a.stream = F, pcm.data_ptr(), cap, stt
+                a.d_dmx_frames = d_fr.data_ptr()
+                n = b.render_ex(a)
+            else:
+                n = b.flush(pcm.data_ptr(), cap, stt)
+            torch.cuda.synchronize()
+            h = pcm.cpu().numpy()
+            for s in range(S):
+                outs[s].append(h[s][:n * oc * 2].view(np.int16).reshape(n, oc).copy())
+        b.close()
+        return [np.concatenate(o, axis=0) for o in outs]
+
+    got = run()
+    monkeypatch.setenv("IAMF_HIP_FORCE_GENERIC", "1")
+    ref = run()
+    monkeypatch.delenv("IAMF_HIP_FORCE_GENERIC")
+    for s in range(S):
+        y = O.downmix_run(il, ol, x[s], sched, 1, 3)                     # [F][oc][fs]
+        yd = np.ascontiguousarray(y.transpose(1, 0, 2).reshape(oc, F * fs))
+        z, _ = O.limiter_run(yd, [fs] * F)
+        want = O.pack(z, 16)
+        assert got[s].shape == want.shape
+        assert np.array_equal(ref[s], want), (il, ol, s, "generic kernel")
+        assert np.array_equal(got[s], want), (il, ol, s)
