@@ -197,7 +197,7 @@ void launch_m(const RenderParams &p, dim3 grid, size_t lds_bytes, hipStream_t st
 
 template <int M>
 void launch_fir_m(const RenderParams &p, dim3 grid, hipStream_t st) {
-  const size_t lds = sizeof(float) * (size_t)fast_lds_floats(2, M, p.n_end + 1, true);
+  const size_t lds = sizeof(float) * (size_t)fast_lds_floats(2, M, true);
   static bool opted = false;
   if (!opted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, true>),
@@ -209,7 +209,7 @@ void launch_fir_m(const RenderParams &p, dim3 grid, hipStream_t st) {
 
 template <int M>
 void launch_fast_m(const RenderParams &p, dim3 grid, hipStream_t st) {
-  const size_t lds = sizeof(float) * (size_t)fast_lds_floats(p.out_ch, M, p.n_end + 1);
+  const size_t lds = sizeof(float) * (size_t)fast_lds_floats(p.out_ch, M);
   // more than 64 KiB of dynamic LDS has to be opted into per kernel (gfx950 has 160 KiB per CU)
   static bool opted = false;
   if (!opted) {
@@ -228,7 +228,7 @@ void launch_fast_m(const RenderParams &p, dim3 grid, hipStream_t st) {
 // parametric down-mixer to mono / stereo: 7.1 -> {2, 1}, 5.1 -> {2, 1}, stereo -> mono
 template <int M, int OC>
 void launch_fast_down_mc(const RenderParams &p, dim3 grid, hipStream_t st) {
-  const size_t lds = sizeof(float) * (size_t)fast_lds_floats(OC, M, p.n_end + 1);
+  const size_t lds = sizeof(float) * (size_t)fast_lds_floats(OC, M);
   static bool opted = false;
   if (!opted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, OC, false, true>),
@@ -268,7 +268,7 @@ void launch_wide_m(const RenderParams &p, dim3 grid, hipStream_t st) {
 // (odd sizes, flush, limiter off, wide layouts) goes to the generic kernel.  Both are exact.
 bool fast_path_ok(const RenderParams &p, bool down_mixer = false) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
-  if (!p.limiter_on || !p.in || p.out_ch > 2 || p.n_end + 1 > kFTabMax) return false;
+  if (!p.limiter_on || !p.in || p.out_ch > 2 || p.n_end < kFWin) return false;
   if (p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix || p.demix_on) return false;
   if (p.dmx_on && !(down_mixer && p.dmx_frames)) return false;
   if ((p.pos0 & 15) || (p.total & 63) || (p.frame_size & 3)) return false;
@@ -283,7 +283,7 @@ bool wide_path_ok(const RenderParams &p, int m, bool with_stage = false) {
   if (!p.limiter_on || !p.in || p.out_ch <= 2 || p.out_ch > kMaxOut || p.n_end < kWWin) return false;
   if (p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix) return false;
   if ((p.demix_on || p.dmx_on) && !with_stage) return false;  // demixer / down-mixer: wide4 variants only
-  if (p.dmx_on && !p.dmx_frames) return false;
+  if (p.dmx_on && (!p.dmx_frames || p.demix_on)) return false;  // demixer AND down-mixer: generic kernel
   if ((p.pos0 & 15) || (p.total & 63)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
   return sizeof(float) * (size_t)wide_lds_floats(p.out_ch, m) <= 80 * 1024;

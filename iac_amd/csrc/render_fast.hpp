@@ -16,7 +16,7 @@
 
 constexpr int kFChunk = 1024;
 constexpr int kFRing = 1280;   // >= chunk + look-ahead, multiple of 16 (not a power of two)
-constexpr int kFTabMax = 9984; // largest limiter table kept in LDS (48 kHz needs 9650 entries)
+constexpr int kFWin = 1088;    // staged limiter-table window / head length (> chunk + 1), multiple of 64
 constexpr int kBig = 0x7fffffff;
 
 __device__ __forceinline__ float dpp_quad_bcast0(float v) {
@@ -156,11 +156,14 @@ __device__ __forceinline__ int chain_wave_pick(const float *slots4) {
 
 // LDS floats the fast kernel needs for an OC-channel layout, M inputs and a limiter table of
 // `tab` entries (host and device use the same carve-up)
-__host__ __device__ constexpr int fast_lds_floats(int oc, int m, int tab, bool fir = false) {
-  // the HRTF variant keeps the limiter table in global memory (it has no input prefetch that an
-  // in-loop load could drain) so that two workgroups fit a CU and share its matrix cores
-  return oc * kFRing + 2 * kFRing + kFRing / 16 + 3 * kFChunk + (fir ? 0 : ((tab + 15) & ~15)) +
-         ((oc * m + 15) & ~15) + 16 + (fir ? kFirLdsFloats : 0);
+__host__ __device__ constexpr int fast_lds_floats(int oc, int m, bool fir = false) {
+  // The limiter's curve table (9651 entries at 48 kHz) stays in global memory.  The matrix variant
+  // stages, per chunk, the window of it the chunk can reach without a trigger plus the head that
+  // follows a trigger (2 * kFWin floats): 37 KiB of LDS for a stereo layout, four workgroups per CU.
+  // The HRTF variant reads the table from global memory (it has no input prefetch that an in-loop
+  // load could drain).
+  return oc * kFRing + 2 * kFRing + kFRing / 16 + 2 * kFChunk + (fir ? 0 : 2 * kFWin) + ((oc * m + 15) & ~15) + 16 +
+         (fir ? kFirLdsFloats : 0);
 }
 
 __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
@@ -172,23 +175,21 @@ __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
 // channels), waves 0..3 alone (`act`) run the stages around it.
 // DOWN: the element is rendered by the parametric down-mixer (render_downmix.hpp) instead of a matrix.
 template <int M, int OC, bool FIR = false, bool DOWN = false>
-__global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kernel(const RenderParams p) {
+__global__ __launch_bounds__(FIR ? 512 : 256, (FIR || M <= 16) ? 4 : 2) void render_fast_kernel(const RenderParams p) {
   static_assert(!(FIR && DOWN), "one renderer");
   extern __shared__ float lds[];
   constexpr int R = kFRing;
   constexpr int NB = R / 16;
   const int n_atk = p.n_atk, n_end = p.n_end;
-  const int tab = (n_end + 1 + 15) & ~15;
   float *ring_y = lds;                  // [OC][R]   rendered samples (limiter delay line)
   float *ring_pm = ring_y + OC * R;     // [R]       max |y| over channels
   float *ring_suf = ring_pm + R;        // [R]       suffix maxima of pm inside aligned 16-blocks
   float *ring_bm = ring_suf + R;        // [R/16]    maxima of aligned 16-blocks
   float *arr_p = ring_bm + NB;          // [1024]    window maxima of the chunk
-  float *arr_e = arr_p + kFChunk;       // [1024]    thr / window maximum
-  float *arr_g = arr_e + kFChunk;       // [1024]    gains from the limiter wave
-  float *ctl_lds = arr_g + kFChunk;     // [tab]     limiter curve table (not in the HRTF variant)
-  float *mat = ctl_lds + (FIR ? 0 : tab);  // [OC*M]  feed-major matrix rows of the OC slots
-  const float *ctl = FIR ? p.ctab : ctl_lds;
+  float *arr_g = arr_p + kFChunk;       // [1024]    gains from the limiter wave
+  float *win = arr_g + kFChunk;         // [kFWin]   ctab[min(n_st + i, n_end)] (not in the HRTF variant)
+  float *head = win + kFWin;            // [kFWin]   ctab[i]                     (not in the HRTF variant)
+  float *mat = win + (FIR ? 0 : 2 * kFWin);  // [OC*M]  feed-major matrix rows of the OC slots
   float *misc = mat + ((OC * M + 15) & ~15);  // [16]
   float *fir = misc + 16;               // [kFirLdsFloats]  HRTF staging (FIR variant only)
 
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kern
     ring_suf[rp] = sfx;
     if ((t & 15) == 0) ring_bm[rp >> 4] = sfx;
     if constexpr (!FIR)
-      for (int i = t; i <= n_end; i += 256) ctl_lds[i] = p.ctab[i];
+      for (int i = t; i < kFWin; i += 256) head[i] = p.ctab[i < n_end ? i : n_end];
     if (!FIR && !DOWN && t < OC * M) {
       const int c = t / M, m = t - c * M;
       const int f = p.src_feed[c];
@@ -275,6 +276,23 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kern
   }
   __syncthreads();
   const int cw = chain_wave_pick(misc + 12);
+
+  // Table window the next chunk can reach without a trigger: win[i] = ctab[min(n_st + i, n_end)].
+  // Fetched BEFORE the chunk's PCM stores are issued and written to LDS BEFORE the next input
+  // prefetch is issued: vector-memory operations retire in order, so a wait for these values at
+  // any later point would drain the stores / the prefetch as well.
+  float wv[FIR ? 1 : 5];
+  auto fetch_window = [&](int n0) {
+    if constexpr (!FIR) {
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const int i = n0 + t + 256 * r;
+        wv[r] = 1.0f;
+        if (n0 < n_end && t + 256 * r < kFWin) wv[r] = p.ctab[i < n_end ? i : n_end];
+      }
+    }
+  };
+  fetch_window(n_st);
 
   for (int c0 = 0; c0 < p.total; c0 += kFChunk) {
     const int cnt = p.total - c0 < kFChunk ? p.total - c0 : kFChunk;  // multiple of 64
@@ -335,9 +353,12 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kern
     }
     if constexpr (FIR) __syncthreads();  // partials are consumed; the staging area is reused by the next chunk
 
-    // ---- prefetch the next chunk's input: the ONLY vector-memory loads of the loop, so they
-    //      stay in flight under everything below (the in-order vmcnt never has to drain them) ----
+    // ---- table window -> LDS, then the prefetch of the next chunk's input: the last vector-memory
+    //      loads issued before the limiter work, so they stay in flight under everything below ----
     if constexpr (!FIR) {
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+        if (t + 256 * r < kFWin) win[t + 256 * r] = wv[r];
       const int kn = k + kFChunk;
       if (kn < p.total) {
         const int f = kn / fs;
@@ -395,7 +416,7 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kern
         int np = n_st + 4 * t + j;
         np = np < n_end ? np : n_end;
         const int ci = np + 1 < n_end ? np + 1 : n_end;
-        gh[j] = gain_at(np, gs, ge, ctl[ci], n_atk, n_end);
+        gh[j] = gain_at(np, gs, ge, FIR ? p.ctab[ci] : win[4 * t + j + 1], n_atk, n_end);
       }
       g = make_float4(gh[0], gh[1], gh[2], gh[3]);
       int kfirst = kBig;
@@ -425,8 +446,18 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kern
       if (act && wave == cw) {
         int ln = n_st + 64 * b0 < n_end ? n_st + 64 * b0 : n_end;
         float lgs = gs, lge = ge, lgl = g_cur;
-        limiter_wave(arr_p, arr_g, [ctl](int ci) { return ctl[ci]; }, b0, cnt >> 6, ln, lgs, lge, lgl,
-                     thr, n_atk, n_end);
+        if constexpr (FIR) {
+          const float *ctl = p.ctab;
+          limiter_wave(arr_p, arr_g, [ctl](int ci) { return ctl[ci]; }, b0, cnt >> 6, ln, lgs, lge, lgl, thr, n_atk,
+                       n_end);
+        } else {
+          const int n_chunk = n_st;
+          auto look = [win, head, n_chunk](int ci) {  // before a trigger: the window; after one: the head
+            const int d = ci - n_chunk;
+            return (d >= 0 && d < kFWin) ? win[d] : head[ci < kFWin ? ci : kFWin - 1];
+          };
+          limiter_wave(arr_p, arr_g, look, b0, cnt >> 6, ln, lgs, lge, lgl, thr, n_atk, n_end);
+        }
         if (lane == 0) {
           misc[4] = lgl;
           misc[5] = lgs;
@@ -441,6 +472,8 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 1) void render_fast_kern
       ge = misc[6];
       n_st = __float_as_int(misc[7]);
     }
+
+    if (c0 + kFChunk < p.total) fetch_window(n_st);  // for the next chunk, ahead of the stores
 
     // ---- emit 4 delayed samples * gain as interleaved PCM ----
     const int64_t j0 = gk - kDelay;

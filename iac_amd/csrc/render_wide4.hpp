@@ -21,7 +21,7 @@
 //   * two workgroup barriers per chunk on the no-trigger path.
 #pragma once
 
-constexpr int kW4Win = 1088;        // staged table window / head length (> chunk + 1), multiple of 64
+constexpr int kW4Win = kFWin;       // staged table window / head length (render_fast.hpp)
 constexpr int kW4TailLanes = 60;    // lanes holding the chunk's last 240 samples
 constexpr int kW4FirstTail = 256 - kW4TailLanes;
 

@@ -90,8 +90,8 @@ def test_widest_layouts_24_in_24_out(hip):
 
 @pytest.mark.parametrize("thr_db,rate", [(-3.0, 48000), (0.0, 48000), (-1.0, 44100), (-6.0, 96000), (-1.0, 16000)])
 def test_limiter_settings_and_rates(hip, thr_db, rate):
-    """threshold and sample rate change the limiter's constants and its table (96 kHz: the table no
-    longer fits LDS, the call goes to the generic kernel)"""
+    """threshold and sample rate change the limiter's constants and its table (96 kHz: 19 298 entries;
+    the kernels stage the window of it a chunk can reach, so the size does not matter)"""
     A, G, torch = hip
     fs, F = 1024, 6
     x = synth.hot(1234, 16, F * fs, sigma=0.25, burst_phase=600, burst_period=2500)[None]
