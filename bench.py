@@ -41,6 +41,8 @@ WORKLOADS = {
     # bitstream order) through the demixer (output gains, S1to2..S5to7 / T2toT4 with a demixing mode
     # per frame, recon-gain smoothing), then 7.1.4 -> J, limiter, s16: the general kernel
     "scalable_714_ssJ_limiter_s16": ("demix", 0x714, 0x470, 12, 12 * 4 + 12 * 2),
+    # §8 A8: a mix presentation of two elements: 3rd-order HOA bed + stereo dialogue -> binaural
+    "toa_plus_stereo_binaural_limiter_s16": ("h2m_in2", 3, 0x1020, 16, 16 * 4 + 2 * 4 + 2 * 2),
     # §8 A5: a 7.1.4 element that carries a demixing parameter, rendered to a smaller IAMF layout by the
     # parametric down-mixer (downmix_renderer.c) with a mode per frame, instead of a gain matrix
     # (the reference takes the down-mixer unless the input has height channels and the output none)
@@ -141,7 +143,7 @@ def reference_baseline(workload, fs, seconds_target=12.0):
         x = W.quantize(np.clip(synth.hot(4242, in_ch, frames * fs), -1, 1 - 2 ** -15).astype(np.float32), 16)
         pd = lambda pid: W.param_definition(pid, 48000, mode=1)
         stream = W.sequence_header(1) + W.codec_config_lpcm(0, fs, 16, 48000)
-        if kind in ("h2m", "h2m_proj"):
+        if kind in ("h2m", "h2m_proj", "h2m_in2"):
             stream += W.audio_element_ambisonics_mono(1, 0, in_ch, list(range(in_ch)))
         else:
             stream += W.audio_element_channel(1, 0, 7, list(range(W.LAYOUT_SUBSTREAMS[7][0])))
@@ -155,7 +157,7 @@ def reference_baseline(workload, fs, seconds_target=12.0):
         desc_len = len(stream)
         for f in range(frames):
             stream += W.temporal_delimiter()
-            if kind in ("h2m", "h2m_proj"):
+            if kind in ("h2m", "h2m_proj", "h2m_in2"):
                 stream += W.audio_frames([(i, W.lpcm_bytes(x[i:i + 1, f * fs:(f + 1) * fs], 16)) for i in range(in_ch)])
             else:
                 stream += W.audio_frames(W.channel_element_substreams(7, xal[:, f * fs:(f + 1) * fs], 0, 16))
@@ -228,7 +230,7 @@ def main():
     elif kind == "dmx":
         mx = A.dmx_matrix(in_id, out_id)
     else:
-        mx = A.get_h2m_matrix(in_id, out_id) if kind in ("h2m", "h2m_proj") else A.get_m2m_matrix(in_id, out_id)
+        mx = A.get_h2m_matrix(in_id, out_id) if kind in ("h2m", "h2m_proj", "h2m_in2") else A.get_m2m_matrix(in_id, out_id)
     out_ch = mx.channels if kind == "dmx" else A.layout_channels(out_id)
     S, F, fs = args.streams, args.frames, args.frame_size
 
@@ -238,6 +240,11 @@ def main():
     batch = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True,
                     fir_taps=FIR_TAPS if kind == "fir" else 0)
     demix_args = None
+    x2 = None
+    if kind == "h2m_in2":
+        batch.set_second_element(A.get_m2m_matrix(A.SS["STEREO"], out_id), [0.7] * S)
+        x2 = synth_hot_device(S, 2, F, fs, 2000 + rank, dev) * 0.5
+        demix_args = x2   # any non-None value: the call goes through render_ex
     if kind == "dmx":   # host control plane: a down-mix mode per frame and stream (DMRenderer_set_mode_weight)
         import ctypes as C
         fr_ = (A.DmxFrame * (S * F))()
@@ -307,7 +314,9 @@ def main():
             a = A.RenderArgs()
             a.d_in, a.in_stream_stride, a.in_frame_stride = x.data_ptr(), stream_stride, frame_stride
             a.n_frames, a.d_pcm, a.pcm_stream_stride_bytes, a.stream = F, buf.data_ptr(), stride_bytes, stream
-            if kind == "dmx":
+            if kind == "h2m_in2":
+                a.d_in2, a.in2_stream_stride, a.in2_frame_stride = x2.data_ptr(), F * 2 * fs, 2 * fs
+            elif kind == "dmx":
                 a.d_dmx_frames = demix_args.data_ptr()
             else:
                 a.d_demix_frames = demix_args.data_ptr()
@@ -363,7 +372,9 @@ def main():
         total_sf = sf_per_step * args.steps * world
         value = total_sf / elapsed / 1e6
         achieved = bytes_per_sf * sf_per_step / (kernel_ms * 1e-3) / 1e9
-        if kind == "dmx":
+        if kind == "h2m_in2":
+            ktag = "render_fast_kernel<%d, %d, false, false, true>" % (in_ch, out_ch)
+        elif kind == "dmx":
             ktag = ("render_fast_kernel<%d, %d, false, true>" if out_ch <= 2 else
                     "render_wide4_kernel<%d, %d, false, false, true>") % (in_ch, out_ch)
         elif kind == "demix":
@@ -412,6 +423,8 @@ def main():
             wl = wl.replace("toa_projection_", "toa_")
             if kind == "dmx":
                 wl = "714_ssJ_limiter_s16"
+            if kind == "h2m_in2":
+                wl = "toa_binaural_limiter_s16"
             refb = reference_baseline(wl, fs)
             port = cpu_baseline(wl, fs, seconds_target=6.0 if refb else 12.0)
             if refb:   # the reference itself is the baseline; the oracle port is reported beside it
@@ -423,6 +436,8 @@ def main():
                 out["cpu_baseline"]["sample"] += " [the single-layer 7.1.4 stream: without the demixer stage]"
             if kind == "dmx":
                 out["cpu_baseline"]["sample"] += " [the 7.1.4 -> J matrix stream: the reference's down-mixer needs a demixing-parameter stream]"
+            if kind == "h2m_in2":
+                out["cpu_baseline"]["sample"] += " [the one-element stream: without the stereo element]"
             if kind == "h2m_proj":
                 out["cpu_baseline"]["sample"] += " [the mono-mode stream: without the de-mapping stage]"
         print(json.dumps(out))

@@ -219,6 +219,21 @@ void launch_fast_m(const RenderParams &p, dim3 grid, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     opted = true;
   }
+  if (p.in2) {
+    static bool opted2 = false;
+    if (!opted2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 1, false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      opted2 = true;
+    }
+    if (p.out_ch == 1)
+      hipLaunchKernelGGL((render_fast_kernel<M, 1, false, false, true>), grid, dim3(256), lds, st, p);
+    else
+      hipLaunchKernelGGL((render_fast_kernel<M, 2, false, false, true>), grid, dim3(256), lds, st, p);
+    return;
+  }
   if (p.out_ch == 1)
     hipLaunchKernelGGL((render_fast_kernel<M, 1>), grid, dim3(256), lds, st, p);
   else
@@ -269,8 +284,11 @@ void launch_wide_m(const RenderParams &p, dim3 grid, hipStream_t st) {
 bool fast_path_ok(const RenderParams &p, bool down_mixer = false) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
   if (!p.limiter_on || !p.in || p.out_ch > 2 || p.n_end < kFWin) return false;
-  if (p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix || p.demix_on) return false;
+  if (p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix || p.demix_on) return false;
   if (p.dmx_on && !(down_mixer && p.dmx_frames)) return false;
+  if (p.in2 && (p.dmx_on || p.fir_taps > 0 || p.m2 > kFIn2 || (reinterpret_cast<uintptr_t>(p.in2) & 15) ||
+                (p.in2_stream_stride & 3) || (p.in2_frame_stride & 3)))
+    return false;  // a second element of up to 4 channels rides along (render_fast_kernel<.., IN2>)
   if ((p.pos0 & 15) || (p.total & 63) || (p.frame_size & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;

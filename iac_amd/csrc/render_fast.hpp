@@ -163,7 +163,7 @@ __host__ __device__ constexpr int fast_lds_floats(int oc, int m, bool fir = fals
   // The HRTF variant reads the table from global memory (it has no input prefetch that an in-loop
   // load could drain).
   return oc * kFRing + 2 * kFRing + kFRing / 16 + 2 * kFChunk + (fir ? 0 : 2 * kFWin) + ((oc * m + 15) & ~15) + 16 +
-         (fir ? kFirLdsFloats : 0);
+         (fir ? kFirLdsFloats : 16 /* second element's matrix rows */);
 }
 
 __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
@@ -174,9 +174,14 @@ __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
 // The HRTF variant runs 512 threads: all eight waves work in fir_stage (ear x quarter of the
 // channels), waves 0..3 alone (`act`) run the stages around it.
 // DOWN: the element is rendered by the parametric down-mixer (render_downmix.hpp) instead of a matrix.
-template <int M, int OC, bool FIR = false, bool DOWN = false>
-__global__ __launch_bounds__(FIR ? 512 : 256, (FIR || M <= 16) ? 4 : 2) void render_fast_kernel(const RenderParams p) {
+// IN2: a second element of at most kFIn2 channels (mono, stereo, first-order ambisonics: a dialogue or
+//      commentary track next to the bed) is rendered by its own matrix and mixed in
+//      (iamf_mixer_mix, IAMF_decoder.c:2702-2733).
+constexpr int kFIn2 = 4;
+template <int M, int OC, bool FIR = false, bool DOWN = false, bool IN2 = false>
+__global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2) void render_fast_kernel(const RenderParams p) {
   static_assert(!(FIR && DOWN), "one renderer");
+  static_assert(!(IN2 && (FIR || DOWN)), "the second element joins a matrix-rendered first one");
   extern __shared__ float lds[];
   constexpr int R = kFRing;
   constexpr int NB = R / 16;
@@ -191,6 +196,7 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || M <= 16) ? 4 : 2) void ren
   float *head = win + kFWin;            // [kFWin]   ctab[i]                     (not in the HRTF variant)
   float *mat = win + (FIR ? 0 : 2 * kFWin);  // [OC*M]  feed-major matrix rows of the OC slots
   float *misc = mat + ((OC * M + 15) & ~15);  // [16]
+  float *mat2 = misc + 16;              // [OC][kFIn2]  second element's matrix rows (IN2 only; aliases fir)
   float *fir = misc + 16;               // [kFirLdsFloats]  HRTF staging (FIR variant only)
 
   const int s = blockIdx.x;
@@ -228,6 +234,11 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || M <= 16) ? 4 : 2) void ren
       const int f = p.src_feed[c];
       mat[t] = f >= 0 ? p.matrix[f * M + m] : 0.f;
     }
+    if (IN2 && t < OC * kFIn2) {
+      const int c = t / kFIn2, m = t - c * kFIn2;
+      const int f = p.src_feed2[c];
+      mat2[t] = (f >= 0 && m < p.m2) ? p.matrix2[f * p.m2 + m] : 0.f;
+    }
     chain_wave_publish(misc + 12);
   }
   LimState ls = p.lim[s];
@@ -243,6 +254,22 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || M <= 16) ? 4 : 2) void ren
 #pragma unroll
   for (int c = 0; c < OC; ++c) live[c] = FIR || DOWN || p.src_feed[c] >= 0;
   const float *fir_hist = FIR ? p.fir_hist + (int64_t)s * M * kFirHist : nullptr;
+  // second element: constant gain (skipped by the reference when it is 1 or not positive)
+  const float eg2 = IN2 ? p.gains2[s] : 1.f;
+  const float m_eg2 = (eg2 != 1.f && eg2 > 0.f) ? eg2 : 1.f;
+  bool live2[OC];
+#pragma unroll
+  for (int c = 0; c < OC; ++c) live2[c] = IN2 && p.src_feed2[c] >= 0;
+  const float *in2_s = IN2 ? p.in2 + (int64_t)s * p.in2_stream_stride : nullptr;
+  float4 x2[IN2 ? kFIn2 : 1];
+  auto load_x2 = [&](int f, int i) {  // the lane's 4 samples of the second element's channels (frame f, position i)
+    if constexpr (IN2) {
+      const float *src = in2_s + (int64_t)f * p.in2_frame_stride + i;
+#pragma unroll
+      for (int m = 0; m < kFIn2; ++m)
+        x2[m] = m < p.m2 ? ld_stream4(src + (int64_t)m * fs) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
 
   const int64_t out_base = p.pos0 > kDelay ? p.pos0 - kDelay : 0;
   const int bytes = p.out_format == IAMF_HIP_FMT_S16 ? 2 : (p.out_format == IAMF_HIP_FMT_S24 ? 3 : 4);
@@ -268,9 +295,12 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || M <= 16) ? 4 : 2) void ren
       const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
 #pragma unroll
       for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
+      load_x2(f, i);
     } else {
 #pragma unroll
       for (int m = 0; m < M; ++m) x[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int m = 0; m < (IN2 ? kFIn2 : 0); ++m) x2[m] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     load_drec(k / fs);
   }
@@ -338,8 +368,28 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || M <= 16) ? 4 : 2) void ren
         }
         v = acc;
       }
-      if (any_gain) {  // a skipped gain is a multiplication by exactly 1; the mixer's 0 + y only
-                       // turns -0 into +0, which no output format can tell apart
+      if constexpr (IN2) {
+        // element gain, mixer (0 + y, then + y2), output and loudness gains in the reference's order;
+        // a gain the reference skips is a multiplication by exactly 1
+        float4 v2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live2[c]) {
+#pragma unroll
+          for (int m = 0; m < kFIn2; ++m) {
+            if (m < p.m2) {
+              const float w = mat2[c * kFIn2 + m];
+              v2.x = v2.x + w * x2[m].x;
+              v2.y = v2.y + w * x2[m].y;
+              v2.z = v2.z + w * x2[m].z;
+              v2.w = v2.w + w * x2[m].w;
+            }
+          }
+        }
+        v.x = (((0.f + v.x * m_eg) + v2.x * m_eg2) * m_og) * m_lg;
+        v.y = (((0.f + v.y * m_eg) + v2.y * m_eg2) * m_og) * m_lg;
+        v.z = (((0.f + v.z * m_eg) + v2.z * m_eg2) * m_og) * m_lg;
+        v.w = (((0.f + v.w * m_eg) + v2.w * m_eg2) * m_og) * m_lg;
+      } else if (any_gain) {  // a skipped gain is a multiplication by exactly 1; the mixer's 0 + y only
+                              // turns -0 into +0, which no output format can tell apart
         v.x = ((v.x * m_eg) * m_og) * m_lg;
         v.y = ((v.y * m_eg) * m_og) * m_lg;
         v.z = ((v.z * m_eg) * m_og) * m_lg;
@@ -367,6 +417,7 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || M <= 16) ? 4 : 2) void ren
 #pragma unroll
         for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
         load_drec(f);
+        load_x2(f, i);
       }
     }
 

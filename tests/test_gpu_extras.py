@@ -154,6 +154,40 @@ def test_two_elements_with_limiter_vs_oracle(hip):
     assert np.array_equal(got, O.pack(z, 16))
 
 
+@pytest.mark.parametrize("second,m2", [("STEREO", 2), ("MONO", 1), ("FOA", 4)])
+@pytest.mark.parametrize("out", ["BINAURAL", "A"])
+def test_two_elements_fast_kernel_vs_oracle(hip, second, m2, out):
+    """3rd-order HOA bed + a mono / stereo / first-order second element into binaural / stereo on
+    render_fast_kernel<16, 2, .., IN2>: element gains, mixer, output gain in the reference's order"""
+    A, G, torch = hip
+    fs, F, S = 1024, 4, 2
+    oid = A.SS[out]
+    x0 = np.stack([synth.hot(161 + s, 16, F * fs, sigma=0.2, burst_phase=400 + 100 * s, burst_period=2600) for s in range(S)])
+    x1 = np.stack([synth.hot(171 + s, m2, F * fs, sigma=0.3, burst_phase=1400, burst_period=2100) for s in range(S)])
+    if second == "FOA":
+        mx2, omx2 = A.get_h2m_matrix(1, oid), O.get_h2m(1, O.SS[out])
+    else:
+        mx2, omx2 = A.get_m2m_matrix(A.SS[second], oid), O.get_m2m(O.SS[second], O.SS[out])
+    eg, eg2, og = [0.8, 1.0], [0.6, 1.0], [1.1, 1.0]
+    b = A.Batch(S, A.get_h2m_matrix(3, oid), 2, frame_size=fs)
+    b.set_gains(element=eg, output=og)
+    b.set_second_element(mx2, eg2)
+    got = _run_ex(A, G, torch, b, S, 16, x0, fs, 2, A.FMT_S16, x2=x1, m2=m2, calls=[1, 3])
+    b.close()
+    for s in range(S):
+        y0 = O.render(O.get_h2m(3, O.SS[out]), x0[s], 2)
+        y1 = O.render(omx2, x1[s], 2)
+        if eg[s] != 1.0:
+            O.lib().orc_frame_gain_const(O.fp(y0), 2, F * fs, eg[s])
+        if eg2[s] != 1.0:
+            O.lib().orc_frame_gain_const(O.fp(y1), 2, F * fs, eg2[s])
+        z = ((np.zeros_like(y0) + y0) + y1).astype(np.float32)
+        if og[s] != 1.0:
+            O.lib().orc_frame_gain_const(O.fp(z), 2, F * fs, og[s])
+        z, _ = O.limiter_run(z, [fs] * F)
+        assert np.array_equal(got[s], O.pack(z, 16)), s
+
+
 def test_projection_demapping_vs_oracle(hip):
     """projection-mode ambisonics: 12 decoded channels -> 9 ambisonics channels (f32, decoded-channel
     ascending, IAMF_core_decoder.c:116-130) -> H2M to 7.1.4 -> limiter, two streams"""
