@@ -219,7 +219,7 @@ void launch_fast_m(const RenderParams &p, dim3 grid, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     opted = true;
   }
-  if (p.in2) {
+  if (p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp) {  // the mixing variant
     static bool opted2 = false;
     if (!opted2) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 1, false, false, true>),
@@ -284,8 +284,14 @@ void launch_wide_m(const RenderParams &p, dim3 grid, hipStream_t st) {
 bool fast_path_ok(const RenderParams &p, bool down_mixer = false) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
   if (!p.limiter_on || !p.in || p.out_ch > 2 || p.n_end < kFWin) return false;
-  if (p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix || p.demix_on) return false;
+  if (p.pre_matrix || p.demix_on) return false;
   if (p.dmx_on && !(down_mixer && p.dmx_frames)) return false;
+  if (p.elem_ramp || p.elem2_ramp || p.out_ramp) {  // per-sample gains: the mixing variant reads them 4 at a time
+    if (p.dmx_on || p.fir_taps > 0 || (p.ramp_stream_stride & 3) || (p.elem2_ramp && !p.in2)) return false;
+    if ((reinterpret_cast<uintptr_t>(p.elem_ramp) | reinterpret_cast<uintptr_t>(p.elem2_ramp) |
+         reinterpret_cast<uintptr_t>(p.out_ramp)) & 15)
+      return false;
+  }
   if (p.in2 && (p.dmx_on || p.fir_taps > 0 || p.m2 > kFIn2 || (reinterpret_cast<uintptr_t>(p.in2) & 15) ||
                 (p.in2_stream_stride & 3) || (p.in2_frame_stride & 3)))
     return false;  // a second element of up to 4 channels rides along (render_fast_kernel<.., IN2>)

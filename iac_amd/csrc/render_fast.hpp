@@ -174,9 +174,11 @@ __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
 // The HRTF variant runs 512 threads: all eight waves work in fir_stage (ear x quarter of the
 // channels), waves 0..3 alone (`act`) run the stages around it.
 // DOWN: the element is rendered by the parametric down-mixer (render_downmix.hpp) instead of a matrix.
-// IN2: a second element of at most kFIn2 channels (mono, stereo, first-order ambisonics: a dialogue or
-//      commentary track next to the bed) is rendered by its own matrix and mixed in
-//      (iamf_mixer_mix, IAMF_decoder.c:2702-2733).
+// IN2: the mixing variant.  A second element of at most kFIn2 channels (mono, stereo, first-order
+//      ambisonics: a dialogue or commentary track next to the bed) is rendered by its own matrix and
+//      mixed in (iamf_mixer_mix, IAMF_decoder.c:2702-2733), and / or the element and output gains are
+//      per-sample ramps (animated mix-gain parameters, iamf_frame_gain with a gains[] array,
+//      IAMF_decoder.c:1383-1408) instead of constants.
 constexpr int kFIn2 = 4;
 template <int M, int OC, bool FIR = false, bool DOWN = false, bool IN2 = false>
 __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2) void render_fast_kernel(const RenderParams p) {
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
       const int f = p.src_feed[c];
       mat[t] = f >= 0 ? p.matrix[f * M + m] : 0.f;
     }
-    if (IN2 && t < OC * kFIn2) {
+    if (IN2 && p.in2 && t < OC * kFIn2) {
       const int c = t / kFIn2, m = t - c * kFIn2;
       const int f = p.src_feed2[c];
       mat2[t] = (f >= 0 && m < p.m2) ? p.matrix2[f * p.m2 + m] : 0.f;
@@ -255,21 +257,36 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
   for (int c = 0; c < OC; ++c) live[c] = FIR || DOWN || p.src_feed[c] >= 0;
   const float *fir_hist = FIR ? p.fir_hist + (int64_t)s * M * kFirHist : nullptr;
   // second element: constant gain (skipped by the reference when it is 1 or not positive)
-  const float eg2 = IN2 ? p.gains2[s] : 1.f;
+  const float eg2 = (IN2 && p.in2) ? p.gains2[s] : 1.f;
   const float m_eg2 = (eg2 != 1.f && eg2 > 0.f) ? eg2 : 1.f;
   bool live2[OC];
 #pragma unroll
-  for (int c = 0; c < OC; ++c) live2[c] = IN2 && p.src_feed2[c] >= 0;
+  for (int c = 0; c < OC; ++c) live2[c] = IN2 && p.in2 && p.src_feed2[c] >= 0;
   const float *in2_s = IN2 ? p.in2 + (int64_t)s * p.in2_stream_stride : nullptr;
   float4 x2[IN2 ? kFIn2 : 1];
+#pragma unroll
+  for (int m = 0; m < (IN2 ? kFIn2 : 1); ++m) x2[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 rmp[IN2 ? 3 : 1];  // per-sample gains of element 0, element 1 and the output, where given
   auto load_x2 = [&](int f, int i) {  // the lane's 4 samples of the second element's channels (frame f, position i)
     if constexpr (IN2) {
-      const float *src = in2_s + (int64_t)f * p.in2_frame_stride + i;
+      if (p.in2) {
+        const float *src = in2_s + (int64_t)f * p.in2_frame_stride + i;
 #pragma unroll
-      for (int m = 0; m < kFIn2; ++m)
-        x2[m] = m < p.m2 ? ld_stream4(src + (int64_t)m * fs) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int m = 0; m < kFIn2; ++m)
+          x2[m] = m < p.m2 ? ld_stream4(src + (int64_t)m * fs) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const int64_t ro = (int64_t)s * p.ramp_stream_stride + (int64_t)f * fs + i;  // sample index inside the call
+      if (p.elem_ramp) rmp[0] = ld_stream4(p.elem_ramp + ro);
+      if (p.elem2_ramp) rmp[1] = ld_stream4(p.elem2_ramp + ro);
+      if (p.out_ramp) rmp[2] = ld_stream4(p.out_ramp + ro);
     }
   };
+  if constexpr (IN2) {
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+    rmp[0] = p.elem_ramp ? one : make_float4(m_eg, m_eg, m_eg, m_eg);
+    rmp[1] = p.elem2_ramp ? one : make_float4(m_eg2, m_eg2, m_eg2, m_eg2);
+    rmp[2] = p.out_ramp ? one : make_float4(m_og, m_og, m_og, m_og);
+  }
 
   const int64_t out_base = p.pos0 > kDelay ? p.pos0 - kDelay : 0;
   const int bytes = p.out_format == IAMF_HIP_FMT_S16 ? 2 : (p.out_format == IAMF_HIP_FMT_S24 ? 3 : 4);
@@ -384,10 +401,18 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
             }
           }
         }
-        v.x = (((0.f + v.x * m_eg) + v2.x * m_eg2) * m_og) * m_lg;
-        v.y = (((0.f + v.y * m_eg) + v2.y * m_eg2) * m_og) * m_lg;
-        v.z = (((0.f + v.z * m_eg) + v2.z * m_eg2) * m_og) * m_lg;
-        v.w = (((0.f + v.w * m_eg) + v2.w * m_eg2) * m_og) * m_lg;
+        // rmp[]: the call's per-sample gains where ramps are given, else the constant gains
+        if (p.in2) {
+          v.x = (((0.f + v.x * rmp[0].x) + v2.x * rmp[1].x) * rmp[2].x) * m_lg;
+          v.y = (((0.f + v.y * rmp[0].y) + v2.y * rmp[1].y) * rmp[2].y) * m_lg;
+          v.z = (((0.f + v.z * rmp[0].z) + v2.z * rmp[1].z) * rmp[2].z) * m_lg;
+          v.w = (((0.f + v.w * rmp[0].w) + v2.w * rmp[1].w) * rmp[2].w) * m_lg;
+        } else {
+          v.x = ((0.f + v.x * rmp[0].x) * rmp[2].x) * m_lg;
+          v.y = ((0.f + v.y * rmp[0].y) * rmp[2].y) * m_lg;
+          v.z = ((0.f + v.z * rmp[0].z) * rmp[2].z) * m_lg;
+          v.w = ((0.f + v.w * rmp[0].w) * rmp[2].w) * m_lg;
+        }
       } else if (any_gain) {  // a skipped gain is a multiplication by exactly 1; the mixer's 0 + y only
                               // turns -0 into +0, which no output format can tell apart
         v.x = ((v.x * m_eg) * m_og) * m_lg;
