@@ -72,13 +72,15 @@ def synth_hot_device(n_streams, in_ch, frames, fs, seed, device):
     return x.contiguous()
 
 
-def measured_traffic(kernel_tag, sf_per_step):
+def measured_traffic(kernel_tag, sf_per_step, workload=None):
     """HBM bytes per launch from the newest committed PMC summary (profiles/*_pmc.json, made by
     tools/prof_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
     same command), scaled to this run's launch size; None if no summary covers the kernel."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    own = [f for f in files if workload and os.path.basename(f).endswith("_%s_pmc.json" % workload)]
+    for f in own or files:   # this workload's own summary if there is one
         try:
             d = json.load(open(f))
         except Exception:
@@ -385,7 +387,7 @@ def main():
             ktag = "render_fast_kernel<%d, %d, false>" % (in_ch, out_ch)
         else:   # whole 1024-sample chunks of s16: the 4-samples-per-lane kernel (else render_wide_kernel)
             ktag = "render_wide4_kernel<%d, %d" % (in_ch, out_ch)
-        traffic = measured_traffic(ktag, sf_per_step)
+        traffic = measured_traffic(ktag, sf_per_step, args.workload)
         out = {
             "metric": "Msamples/s rendered (3rd-order HOA->binaural, 48 kHz)",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
