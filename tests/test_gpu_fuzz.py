@@ -83,3 +83,92 @@ def test_random_configuration_matches_oracle(hip, seed):
                             rate=rate, bit_depth=bits)
         assert got[s].shape == want.shape, (seed, s, got[s].shape, want.shape)
         assert np.array_equal(got[s], want), (seed, s)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_mix_configuration_matches_oracle(hip, seed):
+    """random mix presentations: a bed, optionally a second element (1..16 channels), optionally
+    per-sample element / output gain ramps; mono / stereo / binaural outputs take the mixing variant
+    of the fast kernel when the second element has <= 4 channels, everything else the generic kernel"""
+    import torch
+    from test_gpu_extras import _run_ex
+    A, G = hip
+    rng = np.random.default_rng(7000 + seed)
+    outs = ["A", "BINAURAL", "MONO", "A", "BINAURAL", "B", "J"]
+    for _ in range(50):
+        out = outs[int(rng.integers(len(outs)))]
+        try:
+            if rng.random() < 0.5:
+                order = int(rng.integers(1, 4))
+                m = (order + 1) ** 2
+                mx, omx = A.get_h2m_matrix(order, A.SS[out]), O.get_h2m(order, O.SS[out])
+            else:
+                src = M2M_IN[int(rng.integers(len(M2M_IN)))]
+                m = IN_CH[src]
+                mx, omx = A.get_m2m_matrix(A.SS[src], A.SS[out]), O.get_m2m(O.SS[src], O.SS[out])
+            mx2 = omx2 = None
+            m2 = 0
+            if rng.random() < 0.7:
+                src2 = ["MONO", "STEREO", "FOA", "L51", "TOA"][int(rng.integers(5))]
+                if src2 in ("FOA", "TOA"):
+                    o2 = 1 if src2 == "FOA" else 3
+                    m2 = (o2 + 1) ** 2
+                    mx2, omx2 = A.get_h2m_matrix(o2, A.SS[out]), O.get_h2m(o2, O.SS[out])
+                else:
+                    m2 = IN_CH[src2]
+                    mx2, omx2 = A.get_m2m_matrix(A.SS[src2], A.SS[out]), O.get_m2m(O.SS[src2], O.SS[out])
+        except (KeyError, AssertionError):
+            continue
+        break
+    else:
+        pytest.skip("no matrix drawn")
+    ch = A.layout_channels(A.SS[out])
+    fs = int(rng.choice([256, 960, 1024, 1024, 2048]))
+    F = int(rng.integers(2, 6))
+    S = int(rng.integers(1, 4))
+    bits = int(rng.choice([16, 16, 24, 32]))
+    fmt = {16: A.FMT_S16, 24: A.FMT_S24, 32: A.FMT_S32}[bits]
+    n = F * fs
+    pick = lambda: float(rng.choice([1.0, 0.5, 1.3, -1.0, 0.0]))
+    eg, og, eg2 = [pick() for _ in range(S)], [pick() for _ in range(S)], [pick() for _ in range(S)]
+    ramp = lambda: (0.4 + 0.8 * rng.random((S, n))).astype(np.float32)
+    ramps = {}
+    if rng.random() < 0.4:
+        ramps["element"] = ramp()
+    if m2 and rng.random() < 0.3:
+        ramps["element2"] = ramp()
+    if rng.random() < 0.4:
+        ramps["output"] = ramp()
+    x0 = np.stack([synth.hot(seed * 10 + s, m, n, sigma=0.2, burst_phase=int(rng.integers(0, fs)),
+                             burst_period=int(rng.integers(900, 4000))) for s in range(S)])
+    x1 = np.stack([synth.hot(seed * 10 + 5 + s, max(m2, 1), n, sigma=0.2, burst_phase=int(rng.integers(0, fs)),
+                             burst_period=int(rng.integers(900, 4000))) for s in range(S)]) if m2 else None
+    b = A.Batch(S, mx, ch, frame_size=fs, out_format=fmt, projection=A.PROJ_EXACT)
+    b.set_gains(element=eg, output=og)
+    if m2:
+        b.set_second_element(mx2, eg2)
+    got = _run_ex(A, G, torch, b, S, m, x0, fs, ch, fmt, x2=x1, m2=m2, ramps=ramps or None, calls=_partition(rng, F))
+    b.close()
+    f32 = np.float32
+    for s in range(S):
+        y = O.render(omx, x0[s], ch)[:ch]
+        if "element" in ramps:
+            y = (y * ramps["element"][s][None, :]).astype(f32)
+        elif eg[s] != 1.0 and eg[s] > 0:
+            y = (y * f32(eg[s])).astype(f32)
+        z = (np.zeros_like(y) + y).astype(f32)
+        if m2:
+            y2 = O.render(omx2, x1[s], ch)[:ch]
+            if "element2" in ramps:
+                y2 = (y2 * ramps["element2"][s][None, :]).astype(f32)
+            elif eg2[s] != 1.0 and eg2[s] > 0:
+                y2 = (y2 * f32(eg2[s])).astype(f32)
+            z = (z + y2).astype(f32)
+        if "output" in ramps:
+            z = (z * ramps["output"][s][None, :]).astype(f32)
+        elif og[s] != 1.0 and og[s] > 0:
+            z = (z * f32(og[s])).astype(f32)
+        z, _ = O.limiter_run(np.ascontiguousarray(z), [fs] * F)
+        want = O.pack(z, bits)
+        assert got[s].shape == want.shape, (seed, s, got[s].shape, want.shape)
+        assert np.array_equal(got[s], want), (seed, s)
