@@ -43,6 +43,7 @@ WORKLOADS = {
     "scalable_714_ssJ_limiter_s16": ("demix", 0x714, 0x470, 12, 12 * 4 + 12 * 2),
     # §8 A8: a mix presentation of two elements: 3rd-order HOA bed + stereo dialogue -> binaural
     "toa_plus_stereo_binaural_limiter_s16": ("h2m_in2", 3, 0x1020, 16, 16 * 4 + 2 * 4 + 2 * 2),
+    "714_plus_stereo_ssJ_limiter_s16": ("m2m_in2", 0x714, 0x470, 12, 12 * 4 + 2 * 4 + 12 * 2),
     # §8 A5: a 7.1.4 element that carries a demixing parameter, rendered to a smaller IAMF layout by the
     # parametric down-mixer (downmix_renderer.c) with a mode per frame, instead of a gain matrix
     # (the reference takes the down-mixer unless the input has height channels and the output none)
@@ -243,7 +244,7 @@ def main():
                     fir_taps=FIR_TAPS if kind == "fir" else 0)
     demix_args = None
     x2 = None
-    if kind == "h2m_in2":
+    if kind in ("h2m_in2", "m2m_in2"):
         batch.set_second_element(A.get_m2m_matrix(A.SS["STEREO"], out_id), [0.7] * S)
         x2 = synth_hot_device(S, 2, F, fs, 2000 + rank, dev) * 0.5
         demix_args = x2   # any non-None value: the call goes through render_ex
@@ -316,7 +317,7 @@ def main():
             a = A.RenderArgs()
             a.d_in, a.in_stream_stride, a.in_frame_stride = x.data_ptr(), stream_stride, frame_stride
             a.n_frames, a.d_pcm, a.pcm_stream_stride_bytes, a.stream = F, buf.data_ptr(), stride_bytes, stream
-            if kind == "h2m_in2":
+            if kind in ("h2m_in2", "m2m_in2"):
                 a.d_in2, a.in2_stream_stride, a.in2_frame_stride = x2.data_ptr(), F * 2 * fs, 2 * fs
             elif kind == "dmx":
                 a.d_dmx_frames = demix_args.data_ptr()
@@ -376,6 +377,8 @@ def main():
         achieved = bytes_per_sf * sf_per_step / (kernel_ms * 1e-3) / 1e9
         if kind == "h2m_in2":
             ktag = "render_fast_kernel<%d, %d, false, false, true>" % (in_ch, out_ch)
+        elif kind == "m2m_in2":
+            ktag = "render_wide4_kernel<%d, %d, false, false, false, true>" % (in_ch, out_ch)
         elif kind == "dmx":
             ktag = ("render_fast_kernel<%d, %d, false, true>" if out_ch <= 2 else
                     "render_wide4_kernel<%d, %d, false, false, true>") % (in_ch, out_ch)
@@ -427,6 +430,8 @@ def main():
                 wl = "714_ssJ_limiter_s16"
             if kind == "h2m_in2":
                 wl = "toa_binaural_limiter_s16"
+            if kind == "m2m_in2":
+                wl = "714_ssJ_limiter_s16"
             refb = reference_baseline(wl, fs)
             port = cpu_baseline(wl, fs, seconds_target=6.0 if refb else 12.0)
             if refb:   # the reference itself is the baseline; the oracle port is reported beside it
@@ -438,7 +443,7 @@ def main():
                 out["cpu_baseline"]["sample"] += " [the single-layer 7.1.4 stream: without the demixer stage]"
             if kind == "dmx":
                 out["cpu_baseline"]["sample"] += " [the 7.1.4 -> J matrix stream: the reference's down-mixer needs a demixing-parameter stream]"
-            if kind == "h2m_in2":
+            if kind in ("h2m_in2", "m2m_in2"):
                 out["cpu_baseline"]["sample"] += " [the one-element stream: without the stereo element]"
             if kind == "h2m_proj":
                 out["cpu_baseline"]["sample"] += " [the mono-mode stream: without the de-mapping stage]"

@@ -37,6 +37,8 @@
 
 #include "../../include/iamf_hip.h"
 
+extern "C" int iamf_hip_wide4_has_mix(int m, int c);                                  // iamf_render_wide4_mix.hip
+extern "C" int iamf_hip_wide4_mix_launch(const void *params, int m, hipStream_t st);  // iamf_render_wide4_mix.hip
 extern "C" int iamf_hip_wide4_has_downmixer(int m, int c);                            // iamf_render_wide4.hip
 extern "C" int iamf_hip_wide4_has_demixer(int m, int c);                              // iamf_render_wide4.hip
 extern "C" int iamf_hip_wide4_has(int m, int c);                                      // iamf_render_wide4.hip
@@ -305,8 +307,10 @@ bool fast_path_ok(const RenderParams &p, bool down_mixer = false) {
 bool wide_path_ok(const RenderParams &p, int m, bool with_stage = false) {
   if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
   if (!p.limiter_on || !p.in || p.out_ch <= 2 || p.out_ch > kMaxOut || p.n_end < kWWin) return false;
-  if (p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp || p.pre_matrix) return false;
-  if ((p.demix_on || p.dmx_on) && !with_stage) return false;  // demixer / down-mixer: wide4 variants only
+  if (p.pre_matrix) return false;
+  const bool mixing = p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp;
+  if (mixing && !with_stage) return false;
+  if ((p.demix_on || p.dmx_on) && (!with_stage || mixing)) return false;  // demixer / down-mixer / mixer: wide4 variants only
   if (p.dmx_on && (!p.dmx_frames || p.demix_on)) return false;  // demixer AND down-mixer: generic kernel
   if ((p.pos0 & 15) || (p.total & 63)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
@@ -322,6 +326,16 @@ bool wide4_path_ok(const RenderParams &p, int m) {
       (p.frame_size & 3) || p.n_end < 1088)
     return false;
   if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
+  if (p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp) {  // the mixing variant (render_wide4.hpp, MIX)
+    if (p.in2 && (p.m2 > kFIn2 || (reinterpret_cast<uintptr_t>(p.in2) & 15) || (p.in2_stream_stride & 3) ||
+                  (p.in2_frame_stride & 3)))
+      return false;
+    if ((p.ramp_stream_stride & 3) || (p.elem2_ramp && !p.in2) ||
+        ((reinterpret_cast<uintptr_t>(p.elem_ramp) | reinterpret_cast<uintptr_t>(p.elem2_ramp) |
+          reinterpret_cast<uintptr_t>(p.out_ramp)) & 15))
+      return false;
+    return iamf_hip_wide4_has_mix(m, p.out_ch) != 0;
+  }
   if (p.dmx_on) return iamf_hip_wide4_has_downmixer(m, p.out_ch) != 0;
   if (p.demix_on)  // scalable channel audio: the variant with the demixer in front of the projection
     return p.demix_w4 && !p.use_mfma && (p.demix_i0 & 3) == 0 && iamf_hip_wide4_has_demixer(m, p.out_ch) != 0;
@@ -350,8 +364,9 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
   }
   const bool fast = fast_path_ok(p);
   const bool wide = !fast && wide_path_ok(p, m);
-  if ((wide || ((p.demix_on || p.dmx_on) && wide_path_ok(p, m, true))) && wide4_path_ok(p, m) &&
-      iamf_hip_wide4_launch(&p, m, st)) {
+  const bool mixing = p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp;
+  if ((wide || ((p.demix_on || p.dmx_on || mixing) && wide_path_ok(p, m, true))) && wide4_path_ok(p, m) &&
+      (mixing ? iamf_hip_wide4_mix_launch(&p, m, st) : iamf_hip_wide4_launch(&p, m, st))) {
     HIPCHK(hipGetLastError());
     return IAMF_HIP_OK;
   }

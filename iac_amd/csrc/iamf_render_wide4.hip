@@ -18,7 +18,7 @@ namespace {
 
 template <int M, int C>
 void launch_mc(const RenderParams &p, hipStream_t st) {
-  const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M, false);
+  const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M, 0);
   static bool opted = false;
   if (!opted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, false>),
@@ -36,8 +36,8 @@ void launch_mc(const RenderParams &p, hipStream_t st) {
 // scalable channel audio: M decoded channels -> demixer -> the M channels of the target layout -> C
 template <int M, int C>
 void launch_mc_demixer(const RenderParams &p, hipStream_t st) {
-  static_assert(wide4_lds_floats(C, M, true) <= 20480, "two workgroups per CU");
-  const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M, true);
+  static_assert(wide4_lds_floats(C, M, kW4DmxFloats) <= 20480, "two workgroups per CU");
+  const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M, kW4DmxFloats);
   static bool opted = false;
   if (!opted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, true>),
@@ -50,7 +50,7 @@ void launch_mc_demixer(const RenderParams &p, hipStream_t st) {
 // parametric down-mixer: M channels of the element's layout -> the C channels of a smaller IAMF layout
 template <int M, int C>
 void launch_mc_downmixer(const RenderParams &p, hipStream_t st) {
-  const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M, false);
+  const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M, 0);
   static bool opted = false;
   if (!opted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, false, true>),

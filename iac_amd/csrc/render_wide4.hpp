@@ -30,18 +30,19 @@ constexpr int kW4FirstTail = 256 - kW4TailLanes;
 constexpr int kW4DmxRecs = 5, kW4DmxRec = 36, kW4DmxWin = 192;
 constexpr int kW4DmxFloats = 2 * kW4DmxRecs * kW4DmxRec + 2 * kW4DmxWin + 24;  // records double-buffered
 
-__host__ __device__ constexpr int wide4_base_floats(int c, int m, bool dmx) {
+constexpr int kW4MixFloats = 4 * 24;  // mixing variant: [C][4] matrix rows of the second element
+__host__ __device__ constexpr int wide4_base_floats(int c, int m, int extra) {
   return 4 * kW4TailLanes * c + 2 * kFRing + 2 * (kFRing / 16) + 2 * kFChunk + 2 * kW4Win + ((c + 3) & ~3) * m + 16 +
-         (dmx ? kW4DmxFloats : 0);
+         extra;  // 0, kW4DmxFloats or kW4MixFloats
 }
 // PCM staging (per wave): a lane's 8*C output bytes = C/2 16-byte pieces, lane stride padded to an
 // odd number of pieces (conflict-free).  All 64 lanes at once if that fits 80 KB, else 32 per round.
 __host__ __device__ constexpr int wide4_stage_stride(int c) { return ((c / 2) & 1) ? c / 2 : c / 2 + 1; }
-__host__ __device__ constexpr int wide4_stage_lanes(int c, int m, bool dmx) {
-  return wide4_base_floats(c, m, dmx) + 4 * 64 * wide4_stage_stride(c) * 4 <= 20480 ? 64 : 32;
+__host__ __device__ constexpr int wide4_stage_lanes(int c, int m, int extra) {
+  return wide4_base_floats(c, m, extra) + 4 * 64 * wide4_stage_stride(c) * 4 <= 20480 ? 64 : 32;
 }
-__host__ __device__ constexpr int wide4_lds_floats(int c, int m, bool dmx) {
-  return wide4_base_floats(c, m, dmx) + 4 * wide4_stage_lanes(c, m, dmx) * wide4_stage_stride(c) * 4;
+__host__ __device__ constexpr int wide4_lds_floats(int c, int m, int extra) {
+  return wide4_base_floats(c, m, extra) + 4 * wide4_stage_lanes(c, m, extra) * wide4_stage_stride(c) * 4;
 }
 
 using w4_f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -181,11 +182,15 @@ __device__ __forceinline__ void w4_demix(const RenderParams &p, float4 (&x)[M],
 }
 
 // DOWN: the element is rendered by the parametric down-mixer (render_downmix.hpp) instead of a matrix.
-template <int M, int C, bool MFMA, bool DMX, bool DOWN = false>
+// MIX:  the mixing variant, as in render_fast.hpp: a second element of at most kFIn2 channels rendered
+//       by its own matrix and mixed in, and / or per-sample element / output gain ramps.
+template <int M, int C, bool MFMA, bool DMX, bool DOWN = false, bool MIX = false>
 __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams p) {
   static_assert((C & 1) == 0 && C >= 4 && C <= 24, "even channel counts");
   static_assert(!(DMX && MFMA), "the demixer variant projects on the VALU");
   static_assert(!(DOWN && (MFMA || DMX)), "one renderer");
+  static_assert(!(MIX && (DMX || DOWN)), "the second element joins a matrix-rendered first one");
+  constexpr int kExtra = DMX ? kW4DmxFloats : (MIX ? kW4MixFloats : 0);
   extern __shared__ float lds[];
   constexpr int R = kFRing;
   constexpr int NB = R / 16;
@@ -204,7 +209,8 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
   float *dmx_rec = misc + 16;                            // DMX: [2][5][36] frame records of this / the next chunk
   float *dmx_ws = dmx_rec + 2 * kW4DmxRecs * kW4DmxRec;  // DMX: [192] start window, [192] stop window
   int *dmx_pos = reinterpret_cast<int *>(dmx_ws + 2 * kW4DmxWin);  // DMX: [24] playback position of an IAChannel
-  uint4 *stage = reinterpret_cast<uint4 *>(misc + 16 + (DMX ? kW4DmxFloats : 0));  // [4 waves][LR][S] packed PCM
+  float *mat2 = misc + 16;                           // MIX: [C][4] second element's matrix rows (aliases dmx_rec)
+  uint4 *stage = reinterpret_cast<uint4 *>(misc + 16 + kExtra);  // [4 waves][LR][S] packed PCM
 
   const int s = blockIdx.x;
   const int t = threadIdx.x;
@@ -241,6 +247,14 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       const int m = i / C4, c = i - m * C4;
       const int f = c < C ? p.src_feed[c] : -1;
       mat[i] = f >= 0 ? p.matrix[f * M + m] : 0.f;
+    }
+    if constexpr (MIX) {
+      if (p.in2)
+        for (int i = t; i < 4 * C; i += 256) {
+          const int c = i >> 2, m = i & 3;
+          const int f = p.src_feed2[c];
+          mat2[i] = (f >= 0 && m < p.m2) ? p.matrix2[f * p.m2 + m] : 0.f;
+        }
     }
     chain_wave_publish(misc + 12);
     if constexpr (DMX) {
@@ -336,6 +350,48 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
   // -0 into +0, which no output format can tell apart
   const float m_eg = eg_on ? eg : 1.f, m_og = og_on ? og : 1.f, m_lg = lg_on ? lg : 1.f;
   const bool any_gain = eg_on || og_on || lg_on;
+  // MIX: the second element's channels of the lane's samples; the gains of element 0, element 1 and the
+  // output as the call's per-sample ramps where given, else the constant gains (a gain the reference
+  // skips is a multiplication by exactly 1)
+  float4 x2[MIX ? kFIn2 : 1], rmp[MIX ? 3 : 1];
+  if constexpr (MIX) {
+    const float eg2 = p.in2 ? p.gains2[s] : 1.f;
+    const float m_eg2 = (eg2 != 1.f && eg2 > 0.f) ? eg2 : 1.f;
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+    rmp[0] = p.elem_ramp ? one : make_float4(m_eg, m_eg, m_eg, m_eg);
+    rmp[1] = p.elem2_ramp ? one : make_float4(m_eg2, m_eg2, m_eg2, m_eg2);
+    rmp[2] = p.out_ramp ? one : make_float4(m_og, m_og, m_og, m_og);
+#pragma unroll
+    for (int m = 0; m < kFIn2; ++m) x2[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // gains (and, MIX, the mixer) on the 4 samples of output slot c, in the reference's order
+  auto gains4 = [&](int c, float4 v) -> float4 {
+    if constexpr (MIX) {
+      if (p.in2) {
+        const float4 w = *reinterpret_cast<const float4 *>(&mat2[4 * c]);  // zeros beyond m2 and for a silent slot
+        float4 v2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        v2.x = v2.x + w.x * x2[0].x; v2.y = v2.y + w.x * x2[0].y; v2.z = v2.z + w.x * x2[0].z; v2.w = v2.w + w.x * x2[0].w;
+        v2.x = v2.x + w.y * x2[1].x; v2.y = v2.y + w.y * x2[1].y; v2.z = v2.z + w.y * x2[1].z; v2.w = v2.w + w.y * x2[1].w;
+        v2.x = v2.x + w.z * x2[2].x; v2.y = v2.y + w.z * x2[2].y; v2.z = v2.z + w.z * x2[2].z; v2.w = v2.w + w.z * x2[2].w;
+        v2.x = v2.x + w.w * x2[3].x; v2.y = v2.y + w.w * x2[3].y; v2.z = v2.z + w.w * x2[3].z; v2.w = v2.w + w.w * x2[3].w;
+        v.x = (((0.f + v.x * rmp[0].x) + v2.x * rmp[1].x) * rmp[2].x) * m_lg;
+        v.y = (((0.f + v.y * rmp[0].y) + v2.y * rmp[1].y) * rmp[2].y) * m_lg;
+        v.z = (((0.f + v.z * rmp[0].z) + v2.z * rmp[1].z) * rmp[2].z) * m_lg;
+        v.w = (((0.f + v.w * rmp[0].w) + v2.w * rmp[1].w) * rmp[2].w) * m_lg;
+      } else {
+        v.x = ((0.f + v.x * rmp[0].x) * rmp[2].x) * m_lg;
+        v.y = ((0.f + v.y * rmp[0].y) * rmp[2].y) * m_lg;
+        v.z = ((0.f + v.z * rmp[0].z) * rmp[2].z) * m_lg;
+        v.w = ((0.f + v.w * rmp[0].w) * rmp[2].w) * m_lg;
+      }
+    } else if (any_gain) {
+      v.x = ((v.x * m_eg) * m_og) * m_lg;
+      v.y = ((v.y * m_eg) * m_og) * m_lg;
+      v.z = ((v.z * m_eg) * m_og) * m_lg;
+      v.w = ((v.w * m_eg) * m_og) * m_lg;
+    }
+    return v;
+  };
 
   const int lead = p.pos0 > kDelay ? kDelay : (int)p.pos0;  // pos0 - (first sample of the output buffer)
   const int pos_small = p.pos0 > (1 << 20) ? (1 << 20) : (int)p.pos0;
@@ -355,6 +411,23 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
   float drec[DOWN ? 11 : 1];  // DOWN: the frame record (iamf_hip_dmx_frame) of the lane's samples, fetched with them
   const int down_nfr = DOWN ? (p.total + fs - 1) / fs : 0;
   auto load_x = [&](int cbase, int tt) {
+    if constexpr (MIX) {
+      // the lane's own 4 samples (lanes past the end of a short last chunk re-read the call's last quad)
+      int k = cbase + 4 * tt;
+      k = k < p.total ? k : p.total - 4;
+      const int f = k / fs;
+      const int i = k - f * fs;
+      if (p.in2) {
+        const float *src = p.in2 + (int64_t)s * p.in2_stream_stride + (int64_t)f * p.in2_frame_stride + i;
+#pragma unroll
+        for (int m = 0; m < kFIn2; ++m)
+          x2[m] = m < p.m2 ? ld_stream4(src + (int64_t)m * fs) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const int64_t ro = (int64_t)s * p.ramp_stream_stride + k;
+      if (p.elem_ramp) rmp[0] = ld_stream4(p.elem_ramp + ro);
+      if (p.elem2_ramp) rmp[1] = ld_stream4(p.elem2_ramp + ro);
+      if (p.out_ramp) rmp[2] = ld_stream4(p.out_ramp + ro);
+    }
     if constexpr (DOWN) {
       const int f = (cbase + 4 * tt) / fs;
       const float *d = reinterpret_cast<const float *>(p.dmx_frames + (int64_t)s * down_nfr + (f < down_nfr ? f : down_nfr - 1));
@@ -455,8 +528,8 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       int any_mask = 0;
 #pragma unroll
       for (int j = 0; j < kW4DmxRecs; ++j) any_mask |= __float_as_int(recs[kW4DmxRec * j + 10]);
-      static_assert(wide4_stage_lanes(C, M, true) * wide4_stage_stride(C) * 4 >= 64 * M, "scatter rows fit the wave's staging area");
-      float *scr = reinterpret_cast<float *>(stage + (tv >> 6) * (wide4_stage_lanes(C, M, true) * wide4_stage_stride(C)));
+      static_assert(wide4_stage_lanes(C, M, kW4DmxFloats) * wide4_stage_stride(C) * 4 >= 64 * M, "scatter rows fit the wave's staging area");
+      float *scr = reinterpret_cast<float *>(stage + (tv >> 6) * (wide4_stage_lanes(C, M, kW4DmxFloats) * wide4_stage_stride(C)));
       w4_demix<M>(p, xw, dmx_gin, dmx_row, recs, dmx_ws, scr, c0, 4 * tv, fs, __builtin_amdgcn_readfirstlane(any_mask));
     }
 
@@ -469,13 +542,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       downmix4<M, C>(x, y, cf, p.dmx_in_layout, p.dmx_out_layout);
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        float4 v = y[c];
-        if (any_gain) {
-          v.x = ((v.x * m_eg) * m_og) * m_lg;
-          v.y = ((v.y * m_eg) * m_og) * m_lg;
-          v.z = ((v.z * m_eg) * m_og) * m_lg;
-          v.w = ((v.w * m_eg) * m_og) * m_lg;
-        }
+        const float4 v = gains4(c, y[c]);
         y[c] = v;
         pm.x = fmaxf(pm.x, fabsf(v.x));
         pm.y = fmaxf(pm.y, fabsf(v.y));
@@ -516,13 +583,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       }
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        float4 v = y[c];
-        if (any_gain) {
-          v.x = ((v.x * m_eg) * m_og) * m_lg;
-          v.y = ((v.y * m_eg) * m_og) * m_lg;
-          v.z = ((v.z * m_eg) * m_og) * m_lg;
-          v.w = ((v.w * m_eg) * m_og) * m_lg;
-        }
+        const float4 v = gains4(c, y[c]);
         y[c] = v;
         pm.x = fmaxf(pm.x, fabsf(v.x));
         pm.y = fmaxf(pm.y, fabsf(v.y));
@@ -545,13 +606,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (4 * g + i < C) {
-            float4 v = acc[i];
-            if (any_gain) {
-              v.x = ((v.x * m_eg) * m_og) * m_lg;
-              v.y = ((v.y * m_eg) * m_og) * m_lg;
-              v.z = ((v.z * m_eg) * m_og) * m_lg;
-              v.w = ((v.w * m_eg) * m_og) * m_lg;
-            }
+            const float4 v = gains4(4 * g + i, acc[i]);
             y[4 * g + i] = v;
             pm.x = fmaxf(pm.x, fabsf(v.x));
             pm.y = fmaxf(pm.y, fabsf(v.y));
@@ -732,7 +787,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       // Pack to s16 (rint then saturate == the reference's clamp then lrintf: the bounds are
       // integers).  Piece k of a lane = dwords 4k..4k+3 of its 8*C bytes; dword d = sample
       // d / (C/2), channels 2*(d % (C/2)) and +1.
-      constexpr int H2 = C / 2, S = wide4_stage_stride(C), LR = wide4_stage_lanes(C, M, DMX);
+      constexpr int H2 = C / 2, S = wide4_stage_stride(C), LR = wide4_stage_lanes(C, M, kExtra);
       uint32_t od[4 * H2];  // filled channel pair by channel pair so that y dies as od is born
 #pragma unroll
       for (int c = 0; c < C; c += 2) {

@@ -294,3 +294,61 @@ def test_downmixer_fast_paths_exact(hip, il, ol, fs, monkeypatch):
         assert got[s].shape == want.shape
         assert np.array_equal(ref[s], want), (il, ol, s, "generic kernel")
         assert np.array_equal(got[s], want), (il, ol, s)
+
+
+# ---- mixing variant: second element and per-sample gain ramps (render_wide4_kernel<.., MIX>) ----
+@pytest.mark.parametrize("bed,out,second,m2,proj", [
+    ("L714", "J", "STEREO", 2, "exact"), ("L714", "B", "MONO", 1, "exact"), ("TOA", "J", "FOA", 4, "exact"),
+    ("L51", "C", "STEREO", 2, "exact"), ("TOA", "B", "STEREO", 2, "mfma"), ("L514", "D", None, 0, "exact")])
+def test_wide4_mixing_variant(hip, bed, out, second, m2, proj):
+    """bed + optional second element (<= 4 channels) + element / output gain ramps into 6..12-channel
+    layouts, 1024-sample frames, s16: bit-exact against the oracle chain with the exact projection,
+    within 1 LSB with the MFMA projection"""
+    import torch
+    from test_gpu_extras import _run_ex
+    A, G = hip
+    fs, F, S = 1024, 5, 2
+    n = fs * F
+    oid = A.SS[out]
+    ch = A.layout_channels(oid)
+    if bed == "TOA":
+        m, mx, omx = 16, A.get_h2m_matrix(3, oid), O.get_h2m(3, O.SS[out])
+    else:
+        m, mx, omx = SOURCES[bed], A.get_m2m_matrix(A.SS[bed], oid), O.get_m2m(O.SS[bed], O.SS[out])
+    mx2 = omx2 = None
+    if second == "FOA":
+        mx2, omx2 = A.get_h2m_matrix(1, oid), O.get_h2m(1, O.SS[out])
+    elif second:
+        mx2, omx2 = A.get_m2m_matrix(A.SS[second], oid), O.get_m2m(O.SS[second], O.SS[out])
+    rng = np.random.default_rng(hash((bed, out)) % 1000)
+    x0 = np.stack([synth.hot(261 + s, m, n, sigma=0.2, burst_phase=300 + 100 * s, burst_period=2300) for s in range(S)])
+    x1 = np.stack([synth.hot(271 + s, m2, n, sigma=0.3, burst_phase=900, burst_period=1700) for s in range(S)]) if m2 else None
+    ramps = dict(element=(0.5 + 0.7 * rng.random((S, n))).astype(np.float32),
+                 output=(0.6 + 0.5 * rng.random((S, n))).astype(np.float32))
+    if m2 == 2:
+        ramps["element2"] = (0.3 + 0.9 * rng.random((S, n))).astype(np.float32)
+    eg2 = [0.6, 1.0]
+    b = A.Batch(S, mx, ch, frame_size=fs, projection=A.PROJ_EXACT if proj == "exact" else A.PROJ_MFMA)
+    if m2:
+        b.set_second_element(mx2, eg2)
+    got = _run_ex(A, G, torch, b, S, m, x0, fs, ch, A.FMT_S16, x2=x1, m2=m2, ramps=ramps, calls=[1, 2, 2])
+    b.close()
+    f32 = np.float32
+    for s in range(S):
+        y = (O.render(omx, x0[s], ch)[:ch] * ramps["element"][s][None, :]).astype(f32)
+        z = (np.zeros_like(y) + y).astype(f32)
+        if m2:
+            y2 = O.render(omx2, x1[s], ch)[:ch]
+            if "element2" in ramps:
+                y2 = (y2 * ramps["element2"][s][None, :]).astype(f32)
+            elif eg2[s] != 1.0:
+                y2 = (y2 * f32(eg2[s])).astype(f32)
+            z = (z + y2).astype(f32)
+        z = (z * ramps["output"][s][None, :]).astype(f32)
+        z, _ = O.limiter_run(np.ascontiguousarray(z), [fs] * F)
+        want = O.pack(z, 16)
+        assert got[s].shape == want.shape
+        if proj == "exact":
+            assert np.array_equal(got[s], want), (bed, out, s)
+        else:
+            assert np.abs(got[s].astype(np.int32) - want.astype(np.int32)).max() <= 1, (bed, out, s)
