@@ -14,12 +14,16 @@
 // Kernel families (launch() picks one per call; all share the persisted per-stream state, so
 // consecutive calls of one stream may take different ones):
 //   render_fast.hpp     1- and 2-channel layouts, 1024-sample chunks, 4 samples per lane (headline);
-//                       with FIR = true the HRTF stage on the f32 MFMA in front (render_fir.hpp)
-//   render_wide4.hpp    even 6..24-channel layouts, s16, rendered samples kept in registers
-//                       (own translation unit: iamf_render_wide4.hip)
+//                       variants: FIR (HRTF stage on the f32 MFMA in front, render_fir.hpp), DOWN
+//                       (parametric down-mixer, render_downmix.hpp), IN2 (second element of <= 4
+//                       channels and / or per-sample gain ramps)
+//   render_wide4.hpp    even 6..24-channel layouts, s16, rendered samples kept in registers; VALU or
+//                       MFMA projection; variants: DMX (demixer of scalable channel audio in front),
+//                       DOWN, MIX (as IN2) (own translation units: iamf_render_wide4.hip, _mix.hip)
 //   render_wide.hpp     any other multi-channel aligned call, 256-sample chunks
-//   render_generic.hpp  everything else: ragged calls, flush, limiter off, second element, gain
-//                       ramps, down-mixer, demixer, projection
+//   render_generic.hpp  everything else: ragged calls, flush, limiter off, wide second elements,
+//                       exact two-stage projection, demixer + down-mixer together, other PCM
+//                       formats of the stages above
 //
 // Arithmetic is IEEE f32 in the reference's operation order (compiled with -ffp-contract=off,
 // correctly rounded division), so the VALU paths are bit-exact against the CPU reference, not
