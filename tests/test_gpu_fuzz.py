@@ -3,6 +3,8 @@ random source / output layouts, frame sizes, call partitions, bit depths, limite
 thresholds, sample rates, gains (incl. the values the reference ignores), loudness, stream counts.
 Every case goes through whichever kernel the dispatcher picks (fast / wide4 / wide / generic) and
 usually through several of them across its calls."""
+import os
+
 import numpy as np
 import pytest
 
@@ -34,7 +36,11 @@ def _partition(rng, total):
     return parts
 
 
-@pytest.mark.parametrize("seed", range(40))
+# IAMF_FUZZ_SEEDS=<n> widens both sweeps for a soak run (the defaults keep the suite short)
+_N_SEEDS = int(os.environ.get("IAMF_FUZZ_SEEDS", "0"))
+
+
+@pytest.mark.parametrize("seed", range(_N_SEEDS or 40))
 def test_random_configuration_matches_oracle(hip, seed):
     A, G = hip
     rng = np.random.default_rng(9000 + seed)
@@ -85,7 +91,7 @@ def test_random_configuration_matches_oracle(hip, seed):
         assert np.array_equal(got[s], want), (seed, s)
 
 
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", range(_N_SEEDS or 30))
 def test_random_mix_configuration_matches_oracle(hip, seed):
     """random mix presentations: a bed, optionally a second element (1..16 channels), optionally
     per-sample element / output gain ramps; mono / stereo / binaural outputs take the mixing variant
