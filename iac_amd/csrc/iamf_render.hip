@@ -53,6 +53,7 @@ namespace {
 #include "render_common.hpp"
 #include "render_downmix.hpp"
 #include "render_fir.hpp"
+#include "render_fir16.hpp"
 #include "render_fast.hpp"
 #include "render_generic.hpp"
 #include "render_wide.hpp"
@@ -168,6 +169,8 @@ struct iamf_hip_batch {
   bool fir = false;
   int fir_taps = 0;
   float *d_fir_hist[2] = {nullptr, nullptr};
+  void *d_fir_h16 = nullptr;    // split-f16 filter tables (render_fir16.hpp)
+  float fir_inv_scale = 1.f;
   int fir_cur = 0;
 };
 
@@ -203,14 +206,21 @@ void launch_m(const RenderParams &p, dim3 grid, size_t lds_bytes, hipStream_t st
 
 template <int M>
 void launch_fir_m(const RenderParams &p, dim3 grid, hipStream_t st) {
-  const size_t lds = sizeof(float) * (size_t)fast_lds_floats(2, M, true);
   static bool opted = false;
   if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     opted = true;
   }
-  hipLaunchKernelGGL((render_fast_kernel<M, 2, true>), grid, dim3(512), lds, st, p);  // 8 waves: see render_fir.hpp
+  // 8 waves either way: render_fir.hpp / render_fir16.hpp
+  if (p.fir_h16 && !getenv("IAMF_HIP_FIR_F32")) {
+    static_assert(fast_lds_floats(2, M, 2) * 4 <= 80 * 1024, "two workgroups per CU");
+    hipLaunchKernelGGL((render_fast_kernel<M, 2, 2>), grid, dim3(512), sizeof(float) * (size_t)fast_lds_floats(2, M, 2), st, p);
+  } else {
+    hipLaunchKernelGGL((render_fast_kernel<M, 2, 1>), grid, dim3(512), sizeof(float) * (size_t)fast_lds_floats(2, M, 1), st, p);
+  }
 }
 
 template <int M>
@@ -228,16 +238,16 @@ void launch_fast_m(const RenderParams &p, dim3 grid, hipStream_t st) {
   if (p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp) {  // the mixing variant
     static bool opted2 = false;
     if (!opted2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 1, false, false, true>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 1, 0, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, false, false, true>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 0, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       opted2 = true;
     }
     if (p.out_ch == 1)
-      hipLaunchKernelGGL((render_fast_kernel<M, 1, false, false, true>), grid, dim3(256), lds, st, p);
+      hipLaunchKernelGGL((render_fast_kernel<M, 1, 0, false, true>), grid, dim3(256), lds, st, p);
     else
-      hipLaunchKernelGGL((render_fast_kernel<M, 2, false, false, true>), grid, dim3(256), lds, st, p);
+      hipLaunchKernelGGL((render_fast_kernel<M, 2, 0, false, true>), grid, dim3(256), lds, st, p);
     return;
   }
   if (p.out_ch == 1)
@@ -252,11 +262,11 @@ void launch_fast_down_mc(const RenderParams &p, dim3 grid, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)fast_lds_floats(OC, M);
   static bool opted = false;
   if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, OC, false, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, OC, 0, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     opted = true;
   }
-  hipLaunchKernelGGL((render_fast_kernel<M, OC, false, true>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((render_fast_kernel<M, OC, 0, true>), grid, dim3(256), lds, st, p);
 }
 bool launch_fast_down(const RenderParams &p, int m, dim3 grid, hipStream_t st) {
   if (m == 8 && p.out_ch == 2) launch_fast_down_mc<8, 2>(p, grid, st);
@@ -501,6 +511,8 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     p.fir_taps = b->fir_taps;
     p.fir_hist = b->d_fir_hist[b->fir_cur];
     p.fir_hist_next = b->d_fir_hist[b->fir_cur ^ 1];
+    p.fir_h16 = b->d_fir_h16;
+    p.fir_inv_scale = b->fir_inv_scale;
   }
   const size_t lds = sizeof(float) * ((size_t)(p.out_ch + 2) * kRing + 3 * kChunk + kHead + 4 +
                                       ((b->dmx || b->demix) ? (size_t)kChCount * kChunk : 0));
@@ -682,6 +694,34 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
     CREATE_CHK(hipMalloc(&b->d_fir_hist[1], hb));
     CREATE_CHK(hipMemset(b->d_fir_hist[0], 0, hb));
     CREATE_CHK(hipMemset(b->d_fir_hist[1], 0, hb));
+    // Tables of render_fir16.hpp: per channel [ear][hi/lo][shift r][304] halves with
+    // table_r[n] = hp[n + r], hp[j] = h[j - 15] * scale split as hi + lo * 2^-11.  The scale is the
+    // power of two that puts the largest tap in [2^13, 2^14).
+    const int taps = cfg->fir_taps;
+    float hmax = 0.f;
+    for (size_t i = 0; i < (size_t)2 * mx.m * taps; ++i) hmax = fmaxf(hmax, fabsf(mx.mat[i]));
+    if (hmax > 0.f && hmax < 1e30f) {
+      int e = 0;
+      (void)frexpf(hmax, &e);  // hmax = f * 2^e, f in [0.5, 1)
+      const float scale = ldexpf(1.f, 14 - e);
+      std::vector<_Float16> tab((size_t)mx.m * 2 * 2 * 8 * kF16Taps, (_Float16)0.f);
+      for (int ch = 0; ch < mx.m; ++ch)
+        for (int ear = 0; ear < 2; ++ear)
+          for (int r = 0; r < 8; ++r)
+            for (int n = 0; n < kF16Taps; ++n) {
+              const int k = n + r - 15;  // tap index of hp[n + r]
+              if (k < 0 || k >= taps) continue;
+              const float v = mx.mat[((size_t)ear * mx.m + ch) * taps + k] * scale;
+              const _Float16 hi = (_Float16)v;
+              const _Float16 lo = (_Float16)((v - (float)hi) * 2048.f);
+              const size_t at = ((((size_t)ch * 2 + ear) * 2 + 0) * 8 + r) * kF16Taps + n;
+              tab[at] = hi;
+              tab[at + (size_t)8 * kF16Taps] = lo;
+            }
+      CREATE_CHK(hipMalloc(&b->d_fir_h16, tab.size() * sizeof(_Float16)));
+      CREATE_CHK(hipMemcpy(b->d_fir_h16, tab.data(), tab.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+      b->fir_inv_scale = 1.f / (scale * kF16InScale);
+    }
   }
   CREATE_CHK(hipMalloc(&b->d_dmx_tab, sizeof(dmx_tab)));
   CREATE_CHK(hipMemcpy(b->d_dmx_tab, dmx_tab, sizeof(dmx_tab), hipMemcpyHostToDevice));
@@ -714,6 +754,7 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_demix_ftab);
   (void)hipFree(b->d_fir_hist[0]);
   (void)hipFree(b->d_fir_hist[1]);
+  (void)hipFree(b->d_fir_h16);
   (void)hipFree(b->d_matrix2);
   (void)hipFree(b->d_gains2);
   (void)hipFree(b->d_src_feed2);

@@ -80,6 +80,8 @@ struct RenderParams {
   int32_t fir_taps;
   const float *fir_hist;    // device [n_streams][M][256] input history before this call
   float *fir_hist_next;     // device, same shape: history after this call
+  const void *fir_h16;      // device: split-f16 filter tables [M][ear][hi/lo][shift 8][304] (render_fir16.hpp) or nullptr
+  float fir_inv_scale;      // 1 / (filter scale * input scale) of those tables
 };
 
 // IAChannel ids (reference IAMF_types.h:61-90; L5/R5 alias L7/R7)

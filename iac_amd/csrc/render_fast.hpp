@@ -156,14 +156,14 @@ __device__ __forceinline__ int chain_wave_pick(const float *slots4) {
 
 // LDS floats the fast kernel needs for an OC-channel layout, M inputs and a limiter table of
 // `tab` entries (host and device use the same carve-up)
-__host__ __device__ constexpr int fast_lds_floats(int oc, int m, bool fir = false) {
+__host__ __device__ constexpr int fast_lds_floats(int oc, int m, int fir = 0) {
   // The limiter's curve table (9651 entries at 48 kHz) stays in global memory.  The matrix variant
   // stages, per chunk, the window of it the chunk can reach without a trigger plus the head that
   // follows a trigger (2 * kFWin floats): 37 KiB of LDS for a stereo layout, four workgroups per CU.
   // The HRTF variant reads the table from global memory (it has no input prefetch that an in-loop
   // load could drain).
   return oc * kFRing + 2 * kFRing + kFRing / 16 + 2 * kFChunk + (fir ? 0 : 2 * kFWin) + ((oc * m + 15) & ~15) + 16 +
-         (fir ? kFirLdsFloats : 16 /* second element's matrix rows */);
+         (fir == 2 ? kF16LdsFloats : (fir ? kFirLdsFloats : 16 /* second element's matrix rows */));
 }
 
 __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
@@ -180,7 +180,9 @@ __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
 //      per-sample ramps (animated mix-gain parameters, iamf_frame_gain with a gains[] array,
 //      IAMF_decoder.c:1383-1408) instead of constants.
 constexpr int kFIn2 = 4;
-template <int M, int OC, bool FIR = false, bool DOWN = false, bool IN2 = false>
+// FIR:  0 = gain matrix; 1 = HRTF stage on the f32 MFMA (render_fir.hpp); 2 = HRTF stage on the f16
+//       MFMA with split operands (render_fir16.hpp)
+template <int M, int OC, int FIR = 0, bool DOWN = false, bool IN2 = false>
 __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2) void render_fast_kernel(const RenderParams p) {
   static_assert(!(FIR && DOWN), "one renderer");
   static_assert(!(IN2 && (FIR || DOWN)), "the second element joins a matrix-rendered first one");
@@ -351,7 +353,8 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
     // ---- element renderer + gains (reference operation order) ----
     float4 y[OC];
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (FIR) fir_stage<M>(p, in_s, fir_hist, c0, fir, fir);  // both ears of the chunk -> LDS partials
+    if constexpr (FIR == 2) fir_stage16<M>(p, in_s, fir_hist, c0, fir, fir);  // both ears of the chunk -> LDS
+    else if constexpr (FIR == 1) fir_stage<M>(p, in_s, fir_hist, c0, fir, fir);  // ... as four partial sums per ear
     float4 yd[DOWN ? OC : 1];
     if constexpr (DOWN) {
       float4 cf[5];
@@ -362,7 +365,11 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
 #pragma unroll
     for (int c = 0; c < OC; ++c) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (FIR) {
+      if constexpr (FIR == 2) {
+        const float *p0 = fir + c * (kFChunk + 32);
+        const int u = 4 * t + ((4 * t) >> 5);
+        v = make_float4(p0[u + 0], p0[u + 1], p0[u + 2], p0[u + 3]);
+      } else if constexpr (FIR == 1) {
         // ear c: the partial sums of the four channel quarters (waves c, c+2, c+4, c+6), in that order
         const float *p0 = fir + c * (kFChunk + 32);
         const int u = 4 * t + ((4 * t) >> 5);  // padded index; 4 consecutive samples stay in one 32-block

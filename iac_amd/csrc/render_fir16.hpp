@@ -1,0 +1,131 @@
+// render_fir16.hpp — the binaural HRTF stage of render_fir.hpp on the f16 matrix cores
+// (v_mfma_f32_16x16x32_f16, 16x the rate of the f32 MFMA) without giving up f32 accuracy: every
+// operand is split into two halves,  v * scale = hi + lo * 2^-11  (hi, lo in f16), and
+//     h * x  =  hi_h*hi_x + (hi_h*lo_x + lo_h*hi_x) * 2^-11          [ + lo*lo * 2^-22, dropped ]
+// costs three MFMAs whose products are exact in the f32 accumulators.  What is dropped is 2^-22
+// of a product, the same order as the f32 rounding of the sum itself (tests: 2^-17 absolute against
+// a float64 convolution, like the f32 stage).  PARITY UNPINNED, see render_fir.hpp.
+//
+// Mapping (as render_fir.hpp: t = 16T + i, D[i][T] = sum_m' hp[m' + i] * x[16T + 15 - m'], hp[j] =
+// h[j - 15]) with K = 32 taps per MFMA.  Lane (i or T = lane & 15, g = lane >> 4) needs 8
+// consecutive k of each operand as ONE 16-byte LDS read:
+//   B (input): x[16T + 15 - 32s - 8g - j], j = 0..7  -> the slice is stored REVERSED, position
+//      q = 1279 - u for slice sample u, so the run starts at q0 = 1008 - 256ct - 16T + 32s + 8g, a
+//      multiple of 8 halves; the wave's 64 reads cover one contiguous stretch (conflict-free);
+//   A (filter): hp[32s + 8g + i + j]: the phase i misaligns it, so the table is kept in 8 copies
+//      shifted by r = i & 7 (built once per batch on the host, staged per channel by plain copies).
+// All eight waves work on ONE channel at a time: wave w = (ear w & 1, column tile w >> 1) keeps two
+// accumulators (hi*hi and the cross terms) for its 256 samples of its ear across the channel loop,
+// so nothing is summed across waves.  Slice and tables of the next channel are fetched into
+// registers before the current channel's MFMAs and stored to the other LDS buffer after them.
+#pragma once
+
+constexpr int kF16Taps = 304;                 // padded hp table, halves (see render_fir.hpp)
+constexpr int kF16Slice = 1312;               // reversed slice: 32 zeros of padding + 1280 samples
+constexpr int kF16HBytes = 2 * 2 * 8 * kF16Taps * 2;   // [ear][hi/lo][shift][taps] halves = 19456 B per channel
+constexpr int kF16BufBytes = 2 * kF16Slice * 2 + kF16HBytes;  // slice hi + lo, tables: 24704 B
+constexpr int kF16LdsFloats = 2 * kF16BufBytes / 4;   // double-buffered: 12352 floats
+constexpr float kF16InScale = 64.f;           // input scale 2^6: |x| < 1023 stays finite, -120 dB stays normal
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+
+// y[e][c0 .. c0+1024) for both ears into part ([2][1024 + 32] floats, padded by one per 32; aliases the
+// staging buffers, which are dead by then).  All 512 threads must call it.
+template <int M>
+__device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *in_s, const float *hist, int c0,
+                                            float *fir, float *part) {
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  const int t = threadIdx.x;  // 0..511
+  const int w = t >> 6, lane = t & 63;
+  const int ear = w & 1, ct = w >> 1;
+  const int col = lane & 15, g = lane >> 4;
+  const int L = p.fir_taps;
+  const int KS = (L + 15 + 31) >> 5;  // steps of 32 taps over m' in [0, L + 14]; <= 9
+  unsigned char *buf0 = reinterpret_cast<unsigned char *>(fir);
+
+  // where this thread's 4 slice samples come from (the same for every channel): slice position
+  // u = 4 (t - 8), sample n = c0 - 256 + u; threads 0..7 write the 32 halves of zero padding
+  const bool xs_on = t < 8 + 320;
+  const int u = 4 * (t - 8);
+  const int n = c0 - kFirHist + u;
+  int xoff = -1;  // >= 0: offset in the channel's plane of the call's input; -1: zeros; <= -2: history
+  if (t >= 8 && xs_on) {
+    if (n < 0) {
+      xoff = -2 - (kFirHist + n);
+    } else if (n < p.total) {
+      const int f = n / p.frame_size;
+      xoff = (int)(f * p.in_frame_stride) + (n - f * p.frame_size);
+    }
+  }
+  float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint4 hr[3];
+  auto fetch = [&](int ch) {  // global -> registers
+    if (xs_on) {
+      xr = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (xoff >= 0) xr = *reinterpret_cast<const float4 *>(in_s + (int64_t)ch * p.frame_size + xoff);
+      else if (xoff <= -2) xr = *reinterpret_cast<const float4 *>(hist + ch * kFirHist + (-2 - xoff));
+    }
+    const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const unsigned char *>(p.fir_h16) + (size_t)ch * kF16HBytes);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (t + 512 * r < kF16HBytes / 16) hr[r] = src[t + 512 * r];
+  };
+  auto stash = [&](int b) {  // registers -> LDS buffer b
+    unsigned char *base = buf0 + b * kF16BufBytes;
+    if (xs_on) {
+      _Float16 *xh = reinterpret_cast<_Float16 *>(base), *xl = xh + kF16Slice;
+      const float v[4] = {xr.x * kF16InScale, xr.y * kF16InScale, xr.z * kF16InScale, xr.w * kF16InScale};
+      f16x4 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // slice sample u + k sits at q = 1279 - u - k: reversed inside the quad
+        const _Float16 h = (_Float16)v[k];
+        hi[3 - k] = h;
+        lo[3 - k] = (_Float16)((v[k] - (float)h) * 2048.f);
+      }
+      const int q = 1276 - u;  // = 1279 - u - 3; u = -32 .. 1276 -> q = 1308 .. 0
+      *reinterpret_cast<f16x4 *>(xh + q) = hi;
+      *reinterpret_cast<f16x4 *>(xl + q) = lo;
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(base + 2 * kF16Slice * 2);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (t + 512 * r < kF16HBytes / 16) dst[t + 512 * r] = hr[r];
+  };
+
+  f32x4 acc_hh = {0.f, 0.f, 0.f, 0.f}, acc_x = {0.f, 0.f, 0.f, 0.f};
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int ch = 0; ch < M; ++ch) {
+    if (ch + 1 < M) fetch(ch + 1);
+    {
+      const unsigned char *base = buf0 + (ch & 1) * kF16BufBytes;
+      const _Float16 *xh = reinterpret_cast<const _Float16 *>(base), *xl = xh + kF16Slice;
+      const _Float16 *hb = reinterpret_cast<const _Float16 *>(base + 2 * kF16Slice * 2);
+      // filter: [ear][hi/lo][shift r = col & 7][taps]; the lane starts at 8g + (col & 8)
+      const _Float16 *ah = hb + ((ear * 2 + 0) * 8 + (col & 7)) * kF16Taps + 8 * g + (col & 8);
+      const _Float16 *al = ah + 8 * kF16Taps;
+      const int q0 = 1008 - 256 * ct - 16 * col + 8 * g;
+      for (int s = 0; s < KS; ++s) {
+        const f16x8 a_hi = *reinterpret_cast<const f16x8 *>(ah + 32 * s);
+        const f16x8 a_lo = *reinterpret_cast<const f16x8 *>(al + 32 * s);
+        const f16x8 b_hi = *reinterpret_cast<const f16x8 *>(xh + q0 + 32 * s);
+        const f16x8 b_lo = *reinterpret_cast<const f16x8 *>(xl + q0 + 32 * s);
+        acc_hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, acc_hh, 0, 0, 0);
+        acc_x = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, acc_x, 0, 0, 0);
+        acc_x = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, acc_x, 0, 0, 0);
+      }
+    }
+    if (ch + 1 < M) stash((ch + 1) & 1);  // the other buffer: its readers finished before the last barrier
+    __syncthreads();
+  }
+  // D[row = phase][col = block]: lane holds block col of its tile, phases 4g + r: four consecutive samples
+  float *pw = part + ear * (kFirChunk + 32);
+  const int nn = 256 * ct + 16 * col + 4 * g;
+  const int uu = nn + (nn >> 5);
+  const float sc = p.fir_inv_scale;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pw[uu + r] = (acc_hh[r] + acc_x[r] * (1.f / 2048.f)) * sc;
+  __syncthreads();
+}
