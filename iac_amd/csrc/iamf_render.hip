@@ -694,8 +694,9 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
     CREATE_CHK(hipMalloc(&b->d_fir_hist[1], hb));
     CREATE_CHK(hipMemset(b->d_fir_hist[0], 0, hb));
     CREATE_CHK(hipMemset(b->d_fir_hist[1], 0, hb));
-    // Tables of render_fir16.hpp: [channel][ear][hi/lo][320] halves, hp[n] = h[n - 15] * scale split
-    // as hi + lo * 2^-11.  The scale is the power of two that puts the largest tap in [2^13, 2^14).
+    // Tables of render_fir16.hpp: per channel [ear][hi/lo][shift r][304] halves with
+    // table_r[n] = hp[n + r], hp[j] = h[j - 15] * scale split as hi + lo * 2^-11.  The scale is the
+    // power of two that puts the largest tap in [2^13, 2^14).
     const int taps = cfg->fir_taps;
     float hmax = 0.f;
     for (size_t i = 0; i < (size_t)2 * mx.m * taps; ++i) hmax = fmaxf(hmax, fabsf(mx.mat[i]));
@@ -703,17 +704,20 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
       int e = 0;
       (void)frexpf(hmax, &e);  // hmax = f * 2^e, f in [0.5, 1)
       const float scale = ldexpf(1.f, 14 - e);
-      std::vector<_Float16> tab((size_t)mx.m * 2 * 2 * kF16Taps, (_Float16)0.f);
+      std::vector<_Float16> tab((size_t)mx.m * 2 * 2 * 8 * kF16Taps, (_Float16)0.f);
       for (int ch = 0; ch < mx.m; ++ch)
         for (int ear = 0; ear < 2; ++ear)
-          for (int k = 0; k < taps; ++k) {
-            const float v = mx.mat[((size_t)ear * mx.m + ch) * taps + k] * scale;
-            const _Float16 hi = (_Float16)v;
-            const _Float16 lo = (_Float16)((v - (float)hi) * 2048.f);
-            const size_t at = (((size_t)ch * 2 + ear) * 2 + 0) * kF16Taps + (k + 15);
-            tab[at] = hi;
-            tab[at + kF16Taps] = lo;
-          }
+          for (int r = 0; r < 8; ++r)
+            for (int n = 0; n < kF16Taps; ++n) {
+              const int k = n + r - 15;  // tap index of hp[n + r]
+              if (k < 0 || k >= taps) continue;
+              const float v = mx.mat[((size_t)ear * mx.m + ch) * taps + k] * scale;
+              const _Float16 hi = (_Float16)v;
+              const _Float16 lo = (_Float16)((v - (float)hi) * 2048.f);
+              const size_t at = ((((size_t)ch * 2 + ear) * 2 + 0) * 8 + r) * kF16Taps + n;
+              tab[at] = hi;
+              tab[at + (size_t)8 * kF16Taps] = lo;
+            }
       CREATE_CHK(hipMalloc(&b->d_fir_h16, tab.size() * sizeof(_Float16)));
       CREATE_CHK(hipMemcpy(b->d_fir_h16, tab.data(), tab.size() * sizeof(_Float16), hipMemcpyHostToDevice));
       b->fir_inv_scale = 1.f / (scale * kF16InScale);

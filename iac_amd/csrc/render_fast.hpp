@@ -163,7 +163,7 @@ __host__ __device__ constexpr int fast_lds_floats(int oc, int m, int fir = 0) {
   // The HRTF variant reads the table from global memory (it has no input prefetch that an in-loop
   // load could drain).
   return oc * kFRing + 2 * kFRing + kFRing / 16 + 2 * kFChunk + (fir ? 0 : 2 * kFWin) + ((oc * m + 15) & ~15) + 16 +
-         (fir == 2 ? f16_lds_floats(m) : (fir ? kFirLdsFloats : 16 /* second element's matrix rows */));
+         (fir == 2 ? kF16LdsFloats : (fir ? kFirLdsFloats : 16 /* second element's matrix rows */));
 }
 
 __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
@@ -245,7 +245,6 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
     }
     chain_wave_publish(misc + 12);
   }
-  if constexpr (FIR == 2) fir16_load_tables<M>(p, fir);  // all 512 threads; published by the barrier below
   LimState ls = p.lim[s];
   float g_cur = ls.g, gs = ls.gs, ge = ls.ge;
   int n_st = ls.n;
@@ -354,7 +353,7 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
     // ---- element renderer + gains (reference operation order) ----
     float4 y[OC];
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (FIR == 2) fir_stage16<M>(p, in_s, fir_hist, c0, fir);  // both ears of the chunk -> LDS
+    if constexpr (FIR == 2) fir_stage16<M>(p, in_s, fir_hist, c0, fir, fir);  // both ears of the chunk -> LDS
     else if constexpr (FIR == 1) fir_stage<M>(p, in_s, fir_hist, c0, fir, fir);  // ... as four partial sums per ear
     float4 yd[DOWN ? OC : 1];
     if constexpr (DOWN) {
@@ -367,7 +366,7 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
     for (int c = 0; c < OC; ++c) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (FIR == 2) {
-        const float *p0 = fir + (M * kF16HBytes) / 4 + c * (kFChunk + 32);  // behind the resident filter tables
+        const float *p0 = fir + c * (kFChunk + 32);
         const int u = 4 * t + ((4 * t) >> 5);
         v = make_float4(p0[u + 0], p0[u + 1], p0[u + 2], p0[u + 3]);
       } else if constexpr (FIR == 1) {
