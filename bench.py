@@ -56,6 +56,7 @@ WORKLOADS = {
     "toa_projection_ssB_limiter_s16": ("h2m_proj", 3, 0x050, 16, 16 * 4 + 6 * 2),
 }
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA, dense (155 TF measured)
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / f16 MFMA, dense
 FIR_TAPS = 256
 
 
@@ -415,13 +416,24 @@ def main():
                          "algorithmic_bytes_per_sample_frame": bytes_per_sf,
                          "frac_of_measured_copy_6290": round(achieved / 6290.0, 4)},
         }
-        if kind == "fir":   # compute-bound: price against the dense f32 MFMA peak
+        if kind == "fir":   # compute-bound: price against the dense MFMA peak of the type the stage multiplies in
             flop_sf = 2 * in_ch * 2 * FIR_TAPS
             tf = flop_sf * sf_per_step / (kernel_ms * 1e-3) / 1e12
-            out["roofline"].update({"bound": "mfma", "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                                    "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+            f32_stage = bool(os.environ.get("IAMF_HIP_FIR_F32"))
+            peak = F32_MFMA_PEAK_TFLOPS if f32_stage else F16_MFMA_PEAK_TFLOPS
+            out["roofline"].update({"bound": "mfma", "achieved": round(tf, 2), "peak": peak,
+                                    "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                                     "algorithmic_flop_per_sample_frame": flop_sf,
                                     "hbm_gbs": round(achieved, 1)})
+            if f32_stage:
+                out["dtype"] = "f32 (f32 MFMA)"
+            else:   # render_fir16.hpp: three f16 MFMAs per block of products, 288 of 256 taps multiplied
+                issued = tf * 3 * 288 / 256
+                out["dtype"] = "f32 via split f16 (hi/lo halves, three f16 MFMAs, f32 accumulate)"
+                out["roofline"].update({"issued_tflops": round(issued, 1), "frac_issued": round(issued / peak, 4),
+                                        "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                                        "note": "bound by the per-channel LDS hand-over, not by the matrix cores "
+                                                "(DESIGN.md 4.2); IAMF_HIP_FIR_F32=1 runs the f32-MFMA stage"})
             out["config"]["parity"] = "unpinned (HRTF arithmetic is not in the reference tree)"
         if not args.no_cpu_baseline:
             wl = {"fir": "toa_binaural_limiter_s16", "demix": "714_ssJ_limiter_s16"}.get(kind, args.workload)
