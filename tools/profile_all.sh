@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profiles
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for W in ${WORKLOADS:-toa_binaural_limiter_s16 714_ssJ_limiter_s16 toa_ssH_limiter_s16 toa_hrtf256_limiter_s16 scalable_714_ssJ_limiter_s16 toa_projection_binaural_limiter_s16 714_downmix_512_limiter_s16 710_downmix_stereo_limiter_s16 toa_plus_stereo_binaural_limiter_s16}; do
+for W in ${WORKLOADS:-toa_binaural_limiter_s16 714_ssJ_limiter_s16 toa_ssH_limiter_s16 toa_hrtf256_limiter_s16 scalable_714_ssJ_limiter_s16 toa_projection_binaural_limiter_s16 714_downmix_512_limiter_s16 710_downmix_stereo_limiter_s16 toa_plus_stereo_binaural_limiter_s16 714_plus_stereo_ssJ_limiter_s16}; do
   P=$R/gpurun_out/prof_$W
   rm -rf "$P"
   ARGS="$R/bench.py --workload $W --no-cpu-baseline --steps 10 --warmup 2"
