@@ -377,18 +377,18 @@ def main():
         value = total_sf / elapsed / 1e6
         achieved = bytes_per_sf * sf_per_step / (kernel_ms * 1e-3) / 1e9
         if kind == "h2m_in2":
-            ktag = "render_fast_kernel<%d, %d, 0, false, true>" % (in_ch, out_ch)
+            ktag = "render_fast_kernel<%d, %d, 0, false, true" % (in_ch, out_ch)
         elif kind == "m2m_in2":
-            ktag = "render_wide4_kernel<%d, %d, false, false, false, true>" % (in_ch, out_ch)
+            ktag = "render_wide4_kernel<%d, %d, false, false, false, true" % (in_ch, out_ch)
         elif kind == "dmx":
             ktag = ("render_fast_kernel<%d, %d, 0, true" if out_ch <= 2 else
-                    "render_wide4_kernel<%d, %d, false, false, true>") % (in_ch, out_ch)
+                    "render_wide4_kernel<%d, %d, false, false, true") % (in_ch, out_ch)
         elif kind == "demix":
-            ktag = "render_wide4_kernel<%d, %d, false, true>" % (in_ch, out_ch)
+            ktag = "render_wide4_kernel<%d, %d, false, true" % (in_ch, out_ch)
         elif kind == "fir":
             ktag = "render_fast_kernel<%d, 2, 2" % in_ch
         elif out_ch <= 2:
-            ktag = "render_fast_kernel<%d, %d, 0, false, false>" % (in_ch, out_ch)
+            ktag = "render_fast_kernel<%d, %d, 0, false, false" % (in_ch, out_ch)
         else:   # whole 1024-sample chunks of s16: the 4-samples-per-lane kernel (else render_wide_kernel)
             ktag = "render_wide4_kernel<%d, %d" % (in_ch, out_ch)
         traffic = measured_traffic(ktag, sf_per_step, args.workload)
