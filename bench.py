@@ -210,6 +210,10 @@ def main():
                     help="N>1: gather packed PCM to rank 0 over RCCL once after the last step (default, the "
                          "job's one exchange), after every step (overlapped with the next render), or never")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pad-kb", type=int, default=4,
+                    help="stagger the streams' input regions: stream stride = frames * channels * frame size "
+                         "+ this many KiB, so that the workgroups, which advance in step, are not all on the "
+                         "same HBM channel at once (0 = the power-of-two stride: -12 %% on the headline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -309,6 +313,11 @@ def main():
         final_recv = [torch.empty_like(pcm[0]) for _ in range(world)]
     stream = torch.cuda.current_stream().cuda_stream
     stream_stride, frame_stride = F * in_ch * fs, in_ch * fs
+    if args.pad_kb:
+        xp = torch.zeros((S, stream_stride + args.pad_kb * 256), dtype=torch.float32, device=dev)
+        xp[:, :stream_stride] = x.reshape(S, -1)
+        x = xp
+        stream_stride += args.pad_kb * 256
 
     def render_into(buf, ev_pair=None):
         # events bracket only the render kernel: the gather runs on RCCL's own stream
@@ -403,6 +412,7 @@ def main():
                        "frame_size": fs, "sample_rate": 48000, "in_channels": in_ch,
                        "out_channels": out_ch, "pcm": "s16", "limiter": "-1 dBFS, 240 look-ahead",
                        "signal": "hot (sigma 0.25 + 1.5 bursts)" if args.signal == "hot" else "quiet (sigma 0.05)", "parallelism": "streams sharded, dp%d" % world,
+                       "input_stagger_kib": args.pad_kb,
                        "gather": args.gather if world > 1 else "n/a (1 GPU)"},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "gather_bytes_per_rank": stride_bytes * S if world > 1 and args.gather == "final" else None,
