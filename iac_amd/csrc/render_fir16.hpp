@@ -84,7 +84,9 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
     unsigned char *base = buf0 + b * kF16BufBytes;
     if (xs_on) {
       _Float16 *xh = reinterpret_cast<_Float16 *>(base), *xl = xh + kF16Slice;
-      const float v[4] = {xr.x * kF16InScale, xr.y * kF16InScale, xr.z * kF16InScale, xr.w * kF16InScale};
+      // |x| >= 1023.5 (60 dB over full scale) saturates instead of becoming an f16 infinity
+      auto sat = [](float a) { return fminf(fmaxf(a * kF16InScale, -65504.f), 65504.f); };
+      const float v[4] = {sat(xr.x), sat(xr.y), sat(xr.z), sat(xr.w)};
       f16x4 hi, lo;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {  // slice sample u + k sits at q = 1279 - u - k: reversed inside the quad
