@@ -229,7 +229,7 @@ _DOWN_PAIRS = [(7, 6), (7, 4), (7, 3), (7, 8), (6, 3), (6, 8), (4, 3), (4, 8), (
 
 
 @pytest.mark.parametrize("il,ol", _DOWN_PAIRS)
-@pytest.mark.parametrize("fs", [1024, 256])
+@pytest.mark.parametrize("fs", [1024, 256, 960])
 def test_downmixer_fast_paths_exact(hip, il, ol, fs, monkeypatch):
     """element -> parametric down-mixer (mode per frame, previous mode for the first `offset` samples,
     offsets not multiples of 4 included) -> limiter -> s16 on render_fast_kernel<.., DOWN> (mono /
