@@ -365,12 +365,9 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
 #pragma unroll
     for (int c = 0; c < OC; ++c) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (FIR == 2) {
-        const float *p0 = fir + c * (kFChunk + 32);
-        const int u = 4 * t + ((4 * t) >> 5);
-        v = make_float4(p0[u + 0], p0[u + 1], p0[u + 2], p0[u + 3]);
-      } else if constexpr (FIR == 1) {
-        // ear c: the partial sums of the four channel quarters (waves c, c+2, c+4, c+6), in that order
+      if constexpr (FIR != 0) {
+        // ear c: four partial sums — the channel quarters of the f32 stage (waves c, c+2, c+4, c+6), the
+        // K quarters of the split-f16 stage — added in that order
         const float *p0 = fir + c * (kFChunk + 32);
         const int u = 4 * t + ((4 * t) >> 5);  // padded index; 4 consecutive samples stay in one 32-block
         constexpr int PS = 2 * (kFChunk + 32);

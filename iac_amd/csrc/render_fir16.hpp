@@ -14,10 +14,12 @@
 //      multiple of 8 halves; the wave's 64 reads cover one contiguous stretch (conflict-free);
 //   A (filter): hp[32s + 8g + i + j]: the phase i misaligns it, so the table is kept in 8 copies
 //      shifted by r = i & 7 (built once per batch on the host, staged per channel by plain copies).
-// All eight waves work on ONE channel at a time: wave w = (ear w & 1, column tile w >> 1) keeps two
-// accumulators (hi*hi and the cross terms) for its 256 samples of its ear across the channel loop,
-// so nothing is summed across waves.  Slice and tables of the next channel are fetched into
-// registers before the current channel's MFMAs and stored to the other LDS buffer after them.
+// All eight waves work on ONE channel at a time.  The stage is bound by LDS bandwidth (a 16x16x32 MFMA
+// eats 2 KB of operands), so a wave takes a 2 x 2 block of output tiles — both ears x two column
+// tiles: 8 operand reads feed 12 MFMAs — and the K steps are dealt round-robin to four such waves
+// (w >> 1), whose partial sums the caller adds, as it adds the channel quarters of the f32 stage.
+// Slice and tables of the next channel are fetched into registers before the current channel's
+// MFMAs and stored to the other LDS buffer after them.
 //
 // Measured (16 channels x 256 taps, MI355X): 9.1 Gsamples/s against 6.2 for the f32 stage.  The time
 // goes into the per-channel hand-over, not the matrix cores (one K step instead of nine: 10.0):
@@ -39,15 +41,16 @@ constexpr float kF16InScale = 64.f;           // input scale 2^6: |x| < 1023 sta
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
-// y[e][c0 .. c0+1024) for both ears into part ([2][1024 + 32] floats, padded by one per 32; aliases the
-// staging buffers, which are dead by then).  All 512 threads must call it.
+// Partial sums of y[e][c0 .. c0+1024) into part ([4 K-quarters][2 ears][1024 + 32] floats, padded by
+// one per 32; aliases the staging buffers, which are dead by then): ear e = part[0][e] + part[1][e] +
+// part[2][e] + part[3][e].  All 512 threads must call it.
 template <int M>
 __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *in_s, const float *hist, int c0,
                                             float *fir, float *part) {
   using f32x4 = __attribute__((ext_vector_type(4))) float;
   const int t = threadIdx.x;  // 0..511
   const int w = t >> 6, lane = t & 63;
-  const int ear = w & 1, ct = w >> 1;
+  const int ctp = w & 1, kq = w >> 1;  // column tiles 2 ctp, 2 ctp + 1; K steps kq, kq + 4, kq + 8
   const int col = lane & 15, g = lane >> 4;
   const int L = p.fir_taps;
   const int KS = (L + 15 + 31) >> 5;  // steps of 32 taps over m' in [0, L + 14]; <= 9
@@ -104,7 +107,11 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
       if (t + 512 * r < kF16HBytes / 16) dst[t + 512 * r] = hr[r];
   };
 
-  f32x4 acc_hh = {0.f, 0.f, 0.f, 0.f}, acc_x = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc_hh[2][2], acc_x[2][2];  // [ear][tile of the pair]: hi*hi and the cross terms
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc_hh[e][c] = acc_x[e][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   fetch(0);
   stash(0);
   __syncthreads();
@@ -115,28 +122,44 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
       const _Float16 *xh = reinterpret_cast<const _Float16 *>(base), *xl = xh + kF16Slice;
       const _Float16 *hb = reinterpret_cast<const _Float16 *>(base + 2 * kF16Slice * 2);
       // filter: [ear][hi/lo][shift r = col & 7][taps]; the lane starts at 8g + (col & 8)
-      const _Float16 *ah = hb + ((ear * 2 + 0) * 8 + (col & 7)) * kF16Taps + 8 * g + (col & 8);
-      const _Float16 *al = ah + 8 * kF16Taps;
-      const int q0 = 1008 - 256 * ct - 16 * col + 8 * g;
-      for (int s = 0; s < KS; ++s) {
-        const f16x8 a_hi = *reinterpret_cast<const f16x8 *>(ah + 32 * s);
-        const f16x8 a_lo = *reinterpret_cast<const f16x8 *>(al + 32 * s);
-        const f16x8 b_hi = *reinterpret_cast<const f16x8 *>(xh + q0 + 32 * s);
-        const f16x8 b_lo = *reinterpret_cast<const f16x8 *>(xl + q0 + 32 * s);
-        acc_hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi, acc_hh, 0, 0, 0);
-        acc_x = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo, acc_x, 0, 0, 0);
-        acc_x = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi, acc_x, 0, 0, 0);
+      const _Float16 *a0 = hb + (col & 7) * kF16Taps + 8 * g + (col & 8);
+      const int q0 = 1008 - 512 * ctp - 16 * col + 8 * g;  // first tile of the pair; the second: - 256
+      for (int s = kq; s < KS; s += 4) {
+        f16x8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          a_hi[e] = *reinterpret_cast<const f16x8 *>(a0 + (e * 2 + 0) * 8 * kF16Taps + 32 * s);
+          a_lo[e] = *reinterpret_cast<const f16x8 *>(a0 + (e * 2 + 1) * 8 * kF16Taps + 32 * s);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          b_hi[c] = *reinterpret_cast<const f16x8 *>(xh + q0 - 256 * c + 32 * s);
+          b_lo[c] = *reinterpret_cast<const f16x8 *>(xl + q0 - 256 * c + 32 * s);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            acc_hh[e][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[e], b_hi[c], acc_hh[e][c], 0, 0, 0);
+            acc_x[e][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[e], b_lo[c], acc_x[e][c], 0, 0, 0);
+            acc_x[e][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[e], b_hi[c], acc_x[e][c], 0, 0, 0);
+          }
       }
     }
     if (ch + 1 < M) stash((ch + 1) & 1);  // the other buffer: its readers finished before the last barrier
     __syncthreads();
   }
-  // D[row = phase][col = block]: lane holds block col of its tile, phases 4g + r: four consecutive samples
-  float *pw = part + ear * (kFirChunk + 32);
-  const int nn = 256 * ct + 16 * col + 4 * g;
-  const int uu = nn + (nn >> 5);
+  // D[row = phase][col = block]: lane holds block col of a tile, phases 4g + r: four consecutive samples
   const float sc = p.fir_inv_scale;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) pw[uu + r] = (acc_hh[r] + acc_x[r] * (1.f / 2048.f)) * sc;
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float *pw = part + (kq * 2 + e) * (kFirChunk + 32);
+      const int nn = 256 * (2 * ctp + c) + 16 * col + 4 * g;
+      const int uu = nn + (nn >> 5);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pw[uu + r] = (acc_hh[e][c][r] + acc_x[e][c][r] * (1.f / 2048.f)) * sc;
+    }
   __syncthreads();
 }
