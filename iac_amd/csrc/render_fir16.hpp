@@ -32,79 +32,94 @@
 #pragma once
 
 constexpr int kF16Taps = 304;                 // padded hp table, halves (see render_fir.hpp)
-constexpr int kF16Slice = 1312;               // reversed slice: 32 zeros of padding + 1280 samples
+constexpr int kF16Span = 2048;                // samples per pass of the stage: TWO chunks (see below)
+constexpr int kF16Slice = kF16Span + 256 + 32;  // reversed slice: history + samples + 32 zeros of padding
 constexpr int kF16HBytes = 2 * 2 * 8 * kF16Taps * 2;   // [ear][hi/lo][shift][taps] halves = 19456 B per channel
-constexpr int kF16BufBytes = 2 * kF16Slice * 2 + kF16HBytes;  // slice hi + lo, tables: 24704 B
-constexpr int kF16LdsFloats = 2 * kF16BufBytes / 4;   // double-buffered: 12352 floats
+constexpr int kF16XBytes = 2 * kF16Slice * 2;          // slice hi + lo: 9344 B
+constexpr int kF16LdsFloats = (kF16XBytes + 2 * kF16HBytes) / 4;  // slice + double-buffered tables: 12064 floats
+constexpr int kF16Part = kFirChunk + 32;      // one (K half, ear, chunk) row of partial sums
+static_assert(8 * kF16Part <= kF16LdsFloats, "the partial sums alias the staging area");
 constexpr float kF16InScale = 64.f;           // input scale 2^6: |x| < 1023 stays finite, -120 dB stays normal
 
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
-// Partial sums of y[e][c0 .. c0+1024) into part ([4 K-quarters][2 ears][1024 + 32] floats, padded by
-// one per 32; aliases the staging buffers, which are dead by then): ear e = part[0][e] + part[1][e] +
-// part[2][e] + part[3][e].  All 512 threads must call it.
+// What the stage costs is moving the shifted tables (19.5 KB per channel) from L2 into LDS, so one pass
+// covers TWO chunks: the caller runs it on even chunks only and reads the odd chunk's sums from the
+// same place one iteration later.  Partial sums of y[e][c0 .. c0+2048) go to part ([2 K halves][2 ears]
+// [2 chunks][1024 + 32] floats, padded by one per 32; aliases the staging area, which is dead by then):
+// ear e of chunk j = part[0][e][j] + part[1][e][j].  All 512 threads must call it.
 template <int M>
 __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *in_s, const float *hist, int c0,
                                             float *fir, float *part) {
   using f32x4 = __attribute__((ext_vector_type(4))) float;
   const int t = threadIdx.x;  // 0..511
   const int w = t >> 6, lane = t & 63;
-  const int ctp = w & 1, kq = w >> 1;  // column tiles 2 ctp, 2 ctp + 1; K steps kq, kq + 4, kq + 8
+  const int ctp = w & 3, kh = w >> 2;  // column tiles 2 ctp, 2 ctp + 1 of the 8; K steps kh, kh + 2, ...
   const int col = lane & 15, g = lane >> 4;
   const int L = p.fir_taps;
   const int KS = (L + 15 + 31) >> 5;  // steps of 32 taps over m' in [0, L + 14]; <= 9
-  unsigned char *buf0 = reinterpret_cast<unsigned char *>(fir);
+  unsigned char *xbuf = reinterpret_cast<unsigned char *>(fir);  // slice: [hi/lo][kF16Slice] halves
+  unsigned char *hbuf = xbuf + kF16XBytes;                       // tables: [2 buffers][kF16HBytes]
 
-  // where this thread's 4 slice samples come from (the same for every channel): slice position
-  // u = 4 (t - 8), sample n = c0 - 256 + u; threads 0..7 write the 32 halves of zero padding
-  const bool xs_on = t < 8 + 320;
-  const int u = 4 * (t - 8);
-  const int n = c0 - kFirHist + u;
-  int xoff = -1;  // >= 0: offset in the channel's plane of the call's input; -1: zeros; <= -2: history
-  if (t >= 8 && xs_on) {
-    if (n < 0) {
-      xoff = -2 - (kFirHist + n);
-    } else if (n < p.total) {
-      const int f = n / p.frame_size;
-      xoff = (int)(f * p.in_frame_stride) + (n - f * p.frame_size);
+  // where this thread's slice quads come from (the same for every channel): quad j = t + 512 r covers
+  // slice positions u = 4 (j - 8) .. + 3, sample n = c0 - 256 + u; quads 0..7 are the zero padding
+  constexpr int kNoQuad = -(1 << 30);
+  int xoff[2];  // >= 0: offset in the channel's plane of the call's input; -1: zeros; <= -2: history; kNoQuad: none
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int j = t + 512 * r;
+    const int n = c0 - kFirHist + 4 * (j - 8);
+    xoff[r] = j < 8 + (kF16Span + 256) / 4 ? -1 : kNoQuad;
+    if (j >= 8 && xoff[r] == -1) {
+      if (n < 0) {
+        xoff[r] = -2 - (kFirHist + n);
+      } else if (n < p.total) {
+        const int f = n / p.frame_size;
+        xoff[r] = (int)(f * p.in_frame_stride) + (n - f * p.frame_size);
+      }
     }
   }
-  float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 xr[2];
   uint4 hr[3];
   auto fetch = [&](int ch) {  // global -> registers
-    if (xs_on) {
-      xr = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (xoff >= 0) xr = *reinterpret_cast<const float4 *>(in_s + (int64_t)ch * p.frame_size + xoff);
-      else if (xoff <= -2) xr = *reinterpret_cast<const float4 *>(hist + ch * kFirHist + (-2 - xoff));
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      xr[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (xoff[r] >= 0) xr[r] = *reinterpret_cast<const float4 *>(in_s + (int64_t)ch * p.frame_size + xoff[r]);
+      else if (xoff[r] <= -2 && xoff[r] != kNoQuad) xr[r] = *reinterpret_cast<const float4 *>(hist + ch * kFirHist + (-2 - xoff[r]));
     }
     const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const unsigned char *>(p.fir_h16) + (size_t)ch * kF16HBytes);
 #pragma unroll
     for (int r = 0; r < 3; ++r)
       if (t + 512 * r < kF16HBytes / 16) hr[r] = src[t + 512 * r];
   };
-  auto stash = [&](int b) {  // registers -> LDS buffer b
-    unsigned char *base = buf0 + b * kF16BufBytes;
-    if (xs_on) {
-      _Float16 *xh = reinterpret_cast<_Float16 *>(base), *xl = xh + kF16Slice;
-      // |x| >= 1023.5 (60 dB over full scale) saturates instead of becoming an f16 infinity
-      auto sat = [](float a) { return fminf(fmaxf(a * kF16InScale, -65504.f), 65504.f); };
-      const float v[4] = {sat(xr.x), sat(xr.y), sat(xr.z), sat(xr.w)};
+  auto stash_h = [&](int b) {  // tables: registers -> buffer b
+    uint4 *dst = reinterpret_cast<uint4 *>(hbuf + b * kF16HBytes);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (t + 512 * r < kF16HBytes / 16) dst[t + 512 * r] = hr[r];
+  };
+  auto stash_x = [&]() {  // slice: registers -> LDS, f32 -> hi/lo f16, reversed
+    _Float16 *xh = reinterpret_cast<_Float16 *>(xbuf), *xl = xh + kF16Slice;
+    // |x| >= 1023.5 (60 dB over full scale) saturates instead of becoming an f16 infinity
+    auto sat = [](float a) { return fminf(fmaxf(a * kF16InScale, -65504.f), 65504.f); };
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (xoff[r] == kNoQuad) continue;
+      const float v[4] = {sat(xr[r].x), sat(xr[r].y), sat(xr[r].z), sat(xr[r].w)};
       f16x4 hi, lo;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {  // slice sample u + k sits at q = 1279 - u - k: reversed inside the quad
+      for (int k = 0; k < 4; ++k) {  // slice sample u + k sits at q = (kF16Span + 255) - u - k: reversed inside the quad
         const _Float16 h = (_Float16)v[k];
         hi[3 - k] = h;
         lo[3 - k] = (_Float16)((v[k] - (float)h) * 2048.f);
       }
-      const int q = 1276 - u;  // = 1279 - u - 3; u = -32 .. 1276 -> q = 1308 .. 0
+      const int u = 4 * (t + 512 * r - 8);
+      const int q = (kF16Span + 255) - u - 3;  // u = -32 .. kF16Span + 252 -> q = kF16Slice - 4 .. 0
       *reinterpret_cast<f16x4 *>(xh + q) = hi;
       *reinterpret_cast<f16x4 *>(xl + q) = lo;
     }
-    uint4 *dst = reinterpret_cast<uint4 *>(base + 2 * kF16Slice * 2);
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-      if (t + 512 * r < kF16HBytes / 16) dst[t + 512 * r] = hr[r];
   };
 
   f32x4 acc_hh[2][2], acc_x[2][2];  // [ear][tile of the pair]: hi*hi and the cross terms
@@ -113,18 +128,19 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
 #pragma unroll
     for (int c = 0; c < 2; ++c) acc_hh[e][c] = acc_x[e][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   fetch(0);
-  stash(0);
+  stash_h(0);
+  stash_x();
   __syncthreads();
   for (int ch = 0; ch < M; ++ch) {
     if (ch + 1 < M) fetch(ch + 1);
     {
-      const unsigned char *base = buf0 + (ch & 1) * kF16BufBytes;
-      const _Float16 *xh = reinterpret_cast<const _Float16 *>(base), *xl = xh + kF16Slice;
-      const _Float16 *hb = reinterpret_cast<const _Float16 *>(base + 2 * kF16Slice * 2);
+      const _Float16 *xh = reinterpret_cast<const _Float16 *>(xbuf), *xl = xh + kF16Slice;
+      const _Float16 *hb = reinterpret_cast<const _Float16 *>(hbuf + (ch & 1) * kF16HBytes);
       // filter: [ear][hi/lo][shift r = col & 7][taps]; the lane starts at 8g + (col & 8)
       const _Float16 *a0 = hb + (col & 7) * kF16Taps + 8 * g + (col & 8);
-      const int q0 = 1008 - 512 * ctp - 16 * col + 8 * g;  // first tile of the pair; the second: - 256
-      for (int s = kq; s < KS; s += 4) {
+      // slice sample u = 256 + 256 tile + 16 col + 15 - m' sits at q = kF16Span + 255 - u
+      const int q0 = (kF16Span - 16) - 512 * ctp - 16 * col + 8 * g;  // first tile of the pair; the second: - 256
+      for (int s = kh; s < KS; s += 2) {
         f16x8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -146,8 +162,12 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
           }
       }
     }
-    if (ch + 1 < M) stash((ch + 1) & 1);  // the other buffer: its readers finished before the last barrier
-    __syncthreads();
+    if (ch + 1 < M) stash_h((ch + 1) & 1);  // the other table buffer: its readers finished before the last barrier
+    __syncthreads();                          // everybody has read this channel's slice
+    if (ch + 1 < M) {
+      stash_x();
+      __syncthreads();
+    }
   }
   // D[row = phase][col = block]: lane holds block col of a tile, phases 4g + r: four consecutive samples
   const float sc = p.fir_inv_scale;
@@ -155,8 +175,9 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
   for (int e = 0; e < 2; ++e)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      float *pw = part + (kq * 2 + e) * (kFirChunk + 32);
-      const int nn = 256 * (2 * ctp + c) + 16 * col + 4 * g;
+      const int tile = 2 * ctp + c;  // chunk tile >> 2, 256-sample tile (tile & 3) inside it
+      float *pw = part + ((kh * 2 + e) * 2 + (tile >> 2)) * kF16Part;
+      const int nn = 256 * (tile & 3) + 16 * col + 4 * g;
       const int uu = nn + (nn >> 5);
 #pragma unroll
       for (int r = 0; r < 4; ++r) pw[uu + r] = (acc_hh[e][c][r] + acc_x[e][c][r] * (1.f / 2048.f)) * sc;
