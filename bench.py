@@ -442,7 +442,7 @@ def main():
                 out["dtype"] = "f32 via split f16 (hi/lo halves, three f16 MFMAs, f32 accumulate)"
                 out["roofline"].update({"issued_tflops": round(issued, 1), "frac_issued": round(issued / peak, 4),
                                         "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
-                                        "note": "bound by the per-channel LDS hand-over, not by the matrix cores "
+                                        "note": "bound by staging the filter tables from L2 into LDS, not by the matrix cores "
                                                 "(DESIGN.md 4.2); IAMF_HIP_FIR_F32=1 runs the f32-MFMA stage"})
             out["config"]["parity"] = "unpinned (HRTF arithmetic is not in the reference tree)"
         if not args.no_cpu_baseline:

@@ -353,8 +353,8 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
     // ---- element renderer + gains (reference operation order) ----
     float4 y[OC];
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (FIR == 2) {  // both ears of this chunk AND the next -> LDS (one pass per two chunks)
-      if (((c0 >> 10) & 1) == 0) fir_stage16<M>(p, in_s, fir_hist, c0, fir, fir);
+    if constexpr (FIR == 2) {  // both ears of this chunk AND the next three -> LDS (one pass per four chunks)
+      if (((c0 >> 10) & 3) == 0) fir_stage16<M>(p, in_s, fir_hist, c0, fir, fir);
     }
     else if constexpr (FIR == 1) fir_stage<M>(p, in_s, fir_hist, c0, fir, fir);  // ... as four partial sums per ear
     float4 yd[DOWN ? OC : 1];
@@ -368,14 +368,10 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
     for (int c = 0; c < OC; ++c) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (FIR == 2) {
-        // ear c of this chunk: the two K halves of the split-f16 stage
-        const float *p0 = fir + (c * 2 + ((c0 >> 10) & 1)) * kF16Part;
+        // ear c of this chunk, left by the split-f16 stage's last pass
+        const float *p0 = fir + (c * 4 + ((c0 >> 10) & 3)) * kF16Part;
         const int u = 4 * t + ((4 * t) >> 5);  // padded index; 4 consecutive samples stay in one 32-block
-        constexpr int PS = 4 * kF16Part;
-        v.x = p0[u + 0] + p0[PS + u + 0];
-        v.y = p0[u + 1] + p0[PS + u + 1];
-        v.z = p0[u + 2] + p0[PS + u + 2];
-        v.w = p0[u + 3] + p0[PS + u + 3];
+        v = make_float4(p0[u + 0], p0[u + 1], p0[u + 2], p0[u + 3]);
       } else if constexpr (FIR == 1) {
         // ear c: the partial sums of the four channel quarters (waves c, c+2, c+4, c+6), in that order
         const float *p0 = fir + c * (kFChunk + 32);

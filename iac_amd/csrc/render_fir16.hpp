@@ -14,60 +14,61 @@
 //      multiple of 8 halves; the wave's 64 reads cover one contiguous stretch (conflict-free);
 //   A (filter): hp[32s + 8g + i + j]: the phase i misaligns it, so the table is kept in 8 copies
 //      shifted by r = i & 7 (built once per batch on the host, staged per channel by plain copies).
-// All eight waves work on ONE channel at a time.  The stage is bound by LDS bandwidth (a 16x16x32 MFMA
-// eats 2 KB of operands), so a wave takes a 2 x 2 block of output tiles — both ears x two column
-// tiles: 8 operand reads feed 12 MFMAs — and the K steps are dealt round-robin to four such waves
-// (w >> 1), whose partial sums the caller adds, as it adds the channel quarters of the f32 stage.
-// Slice and tables of the next channel are fetched into registers before the current channel's
-// MFMAs and stored to the other LDS buffer after them.
+// All eight waves work on ONE channel at a time; a wave takes a 2 x 2 block of output tiles (both ears
+// x two 256-sample column tiles: 8 operand reads feed 12 MFMAs).  Slice and tables of the next channel
+// are fetched into registers during the current channel's MFMAs and stored to LDS between two barriers.
 //
-// Measured (16 channels x 256 taps, MI355X): 9.1 Gsamples/s against 6.2 for the f32 stage.  The time
-// goes into the per-channel hand-over, not the matrix cores (one K step instead of nine: 10.0):
-// without the table loads 12.3, without any load 14.5.  Tried: ONE table copy per channel read at
-// its 2-byte boundary, all 16 channels resident in LDS (no per-channel table traffic at all) —
-// correct, but a ds_read_b128 that is not 16-byte aligned is served one lane per cycle
-// (tools/lds_unaligned_probe.hip: 64 instead of 23 cycles per wave-read at 2, 4 or 8 bytes off): 3.7;
-// the same with the reads aligned (wrong taps) 13.5.  Reading the next K step's operands ahead of the
-// current MFMAs in source order changes nothing (8.3-9.1, four waves per SIMD already overlap).
+// Measured (16 channels x 256 taps, MI355X): 15.4 Gsamples/s against 6.2 for the f32 stage.  How it got
+// there: the first version (one tile per wave, one chunk per pass, tables double-buffered) ran at 9.1
+// and its time was NOT in the matrix cores (no MFMA loop at all: 10.7) but in moving the shifted tables
+// from L2 into LDS, 19.5 KB per channel and chunk (no loads: 24.7; no LDS stores either: 92).  2 x 2
+// tiles per wave (LDS reads per MFMA halved): 9.3; two chunks per pass: 12.5; four chunks per pass with
+// single-buffered tables (what fits 80 KB): 15.4.  Tried: ONE table copy per channel read at its
+// 2-byte boundary, all 16 channels resident in LDS (no table traffic at all) — correct, but a
+// ds_read_b128 that is not 16-byte aligned is served one lane per cycle (tools/lds_unaligned_probe.hip:
+// 64 instead of 23 cycles per wave-read at 2, 4 or 8 bytes off): 3.7; with the reads forced aligned
+// (wrong taps) 13.5 at one chunk per pass.
 #pragma once
 
 constexpr int kF16Taps = 304;                 // padded hp table, halves (see render_fir.hpp)
-constexpr int kF16Span = 2048;                // samples per pass of the stage: TWO chunks (see below)
+constexpr int kF16Span = 4096;                // samples per pass of the stage: FOUR chunks (see below)
 constexpr int kF16Slice = kF16Span + 256 + 32;  // reversed slice: history + samples + 32 zeros of padding
 constexpr int kF16HBytes = 2 * 2 * 8 * kF16Taps * 2;   // [ear][hi/lo][shift][taps] halves = 19456 B per channel
-constexpr int kF16XBytes = 2 * kF16Slice * 2;          // slice hi + lo: 9344 B
-constexpr int kF16LdsFloats = (kF16XBytes + 2 * kF16HBytes) / 4;  // slice + double-buffered tables: 12064 floats
-constexpr int kF16Part = kFirChunk + 32;      // one (K half, ear, chunk) row of partial sums
-static_assert(8 * kF16Part <= kF16LdsFloats, "the partial sums alias the staging area");
+constexpr int kF16XBytes = 2 * kF16Slice * 2;          // slice hi + lo: 17536 B
+constexpr int kF16LdsFloats = (kF16XBytes + kF16HBytes) / 4;  // slice + tables: 9248 floats
+constexpr int kF16Part = kFirChunk + 32;      // one (ear, chunk) row of sums
+static_assert(8 * kF16Part <= kF16LdsFloats, "the sums alias the staging area");
 constexpr float kF16InScale = 64.f;           // input scale 2^6: |x| < 1023 stays finite, -120 dB stays normal
 
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
 // What the stage costs is moving the shifted tables (19.5 KB per channel) from L2 into LDS, so one pass
-// covers TWO chunks: the caller runs it on even chunks only and reads the odd chunk's sums from the
-// same place one iteration later.  Partial sums of y[e][c0 .. c0+2048) go to part ([2 K halves][2 ears]
-// [2 chunks][1024 + 32] floats, padded by one per 32; aliases the staging area, which is dead by then):
-// ear e of chunk j = part[0][e][j] + part[1][e][j].  All 512 threads must call it.
+// covers FOUR chunks: the caller runs it on every fourth chunk and reads the other chunks' sums from
+// the same place in the following iterations.  Wave w takes column tiles 2w and 2w + 1 of the 16, both
+// ears, all K steps (tiles past the end of the call are skipped).  y[e][c0 .. c0+4096) goes to part
+// ([2 ears][4 chunks][1024 + 32] floats, padded by one per 32; aliases the staging area, which is dead
+// by then).  All 512 threads must call it.
 template <int M>
 __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *in_s, const float *hist, int c0,
                                             float *fir, float *part) {
   using f32x4 = __attribute__((ext_vector_type(4))) float;
   const int t = threadIdx.x;  // 0..511
   const int w = t >> 6, lane = t & 63;
-  const int ctp = w & 3, kh = w >> 2;  // column tiles 2 ctp, 2 ctp + 1 of the 8; K steps kh, kh + 2, ...
+  const int ctp = w;  // column tiles 2 ctp, 2 ctp + 1 of the 16
+  const bool work = c0 + 512 * ctp < p.total;  // else both tiles lie past the end of the call
   const int col = lane & 15, g = lane >> 4;
   const int L = p.fir_taps;
   const int KS = (L + 15 + 31) >> 5;  // steps of 32 taps over m' in [0, L + 14]; <= 9
   unsigned char *xbuf = reinterpret_cast<unsigned char *>(fir);  // slice: [hi/lo][kF16Slice] halves
-  unsigned char *hbuf = xbuf + kF16XBytes;                       // tables: [2 buffers][kF16HBytes]
+  unsigned char *hbuf = xbuf + kF16XBytes;                       // tables: [kF16HBytes]
 
   // where this thread's slice quads come from (the same for every channel): quad j = t + 512 r covers
   // slice positions u = 4 (j - 8) .. + 3, sample n = c0 - 256 + u; quads 0..7 are the zero padding
   constexpr int kNoQuad = -(1 << 30);
-  int xoff[2];  // >= 0: offset in the channel's plane of the call's input; -1: zeros; <= -2: history; kNoQuad: none
+  int xoff[3];  // >= 0: offset in the channel's plane of the call's input; -1: zeros; <= -2: history; kNoQuad: none
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < 3; ++r) {
     const int j = t + 512 * r;
     const int n = c0 - kFirHist + 4 * (j - 8);
     xoff[r] = j < 8 + (kF16Span + 256) / 4 ? -1 : kNoQuad;
@@ -80,11 +81,11 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
       }
     }
   }
-  float4 xr[2];
+  float4 xr[3];
   uint4 hr[3];
   auto fetch = [&](int ch) {  // global -> registers
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < 3; ++r) {
       xr[r] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (xoff[r] >= 0) xr[r] = *reinterpret_cast<const float4 *>(in_s + (int64_t)ch * p.frame_size + xoff[r]);
       else if (xoff[r] <= -2 && xoff[r] != kNoQuad) xr[r] = *reinterpret_cast<const float4 *>(hist + ch * kFirHist + (-2 - xoff[r]));
@@ -94,8 +95,8 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
     for (int r = 0; r < 3; ++r)
       if (t + 512 * r < kF16HBytes / 16) hr[r] = src[t + 512 * r];
   };
-  auto stash_h = [&](int b) {  // tables: registers -> buffer b
-    uint4 *dst = reinterpret_cast<uint4 *>(hbuf + b * kF16HBytes);
+  auto stash_h = [&]() {  // tables: registers -> LDS
+    uint4 *dst = reinterpret_cast<uint4 *>(hbuf);
 #pragma unroll
     for (int r = 0; r < 3; ++r)
       if (t + 512 * r < kF16HBytes / 16) dst[t + 512 * r] = hr[r];
@@ -105,7 +106,7 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
     // |x| >= 1023.5 (60 dB over full scale) saturates instead of becoming an f16 infinity
     auto sat = [](float a) { return fminf(fmaxf(a * kF16InScale, -65504.f), 65504.f); };
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < 3; ++r) {
       if (xoff[r] == kNoQuad) continue;
       const float v[4] = {sat(xr[r].x), sat(xr[r].y), sat(xr[r].z), sat(xr[r].w)};
       f16x4 hi, lo;
@@ -128,19 +129,19 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
 #pragma unroll
     for (int c = 0; c < 2; ++c) acc_hh[e][c] = acc_x[e][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   fetch(0);
-  stash_h(0);
+  stash_h();
   stash_x();
   __syncthreads();
   for (int ch = 0; ch < M; ++ch) {
     if (ch + 1 < M) fetch(ch + 1);
-    {
+    if (work) {
       const _Float16 *xh = reinterpret_cast<const _Float16 *>(xbuf), *xl = xh + kF16Slice;
-      const _Float16 *hb = reinterpret_cast<const _Float16 *>(hbuf + (ch & 1) * kF16HBytes);
+      const _Float16 *hb = reinterpret_cast<const _Float16 *>(hbuf);
       // filter: [ear][hi/lo][shift r = col & 7][taps]; the lane starts at 8g + (col & 8)
       const _Float16 *a0 = hb + (col & 7) * kF16Taps + 8 * g + (col & 8);
       // slice sample u = 256 + 256 tile + 16 col + 15 - m' sits at q = kF16Span + 255 - u
       const int q0 = (kF16Span - 16) - 512 * ctp - 16 * col + 8 * g;  // first tile of the pair; the second: - 256
-      for (int s = kh; s < KS; s += 2) {
+      for (int s = 0; s < KS; ++s) {
         f16x8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -162,9 +163,9 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
           }
       }
     }
-    if (ch + 1 < M) stash_h((ch + 1) & 1);  // the other table buffer: its readers finished before the last barrier
-    __syncthreads();                          // everybody has read this channel's slice
+    __syncthreads();  // everybody has read this channel's slice and tables
     if (ch + 1 < M) {
+      stash_h();
       stash_x();
       __syncthreads();
     }
@@ -176,7 +177,7 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int tile = 2 * ctp + c;  // chunk tile >> 2, 256-sample tile (tile & 3) inside it
-      float *pw = part + ((kh * 2 + e) * 2 + (tile >> 2)) * kF16Part;
+      float *pw = part + (e * 4 + (tile >> 2)) * kF16Part;
       const int nn = 256 * (tile & 3) + 16 * col + 4 * g;
       const int uu = nn + (nn >> 5);
 #pragma unroll
