@@ -55,6 +55,9 @@ __device__ __forceinline__ void limiter_wave(const float *arr_p, float *arr_g,
                                              Lookup ctab, int b0, int nblk, int &n, float &gs,
                                              float &ge, float &g_last, float thr, int n_atk, int n_end) {
   const int lane = threadIdx.x & 63;
+  // A dependent chain: whenever this wave has an instruction ready it should go first, ahead of the
+  // co-resident workgroup's wave on the same SIMD (which has a whole chunk of independent work).
+  __builtin_amdgcn_s_setprio(3);
   const float a1 = ctab(1);  // attack-curve value one step after a trigger
   float gacc = 1.0f;
   for (int b = b0; b < nblk; ++b) {
@@ -128,6 +131,7 @@ __device__ __forceinline__ void limiter_wave(const float *arr_p, float *arr_g,
     arr_g[b * 64 + lane] = gacc;
   }
   g_last = readlane_f(gacc, 63);
+  __builtin_amdgcn_s_setprio(0);
 }
 
 // Which of the workgroup's 4 waves runs the serial limiter recurrence.  Workgroups that share a CU
