@@ -178,3 +178,60 @@ def test_random_mix_configuration_matches_oracle(hip, seed):
         want = O.pack(z, bits)
         assert got[s].shape == want.shape, (seed, s, got[s].shape, want.shape)
         assert np.array_equal(got[s], want), (seed, s)
+
+
+_DEMIX_STACKS = [[1, 3, 7], [0, 1, 2, 5], [1, 8], [2, 4], [3, 4], [8, 3, 6], [7], [1, 2, 4], [0, 1, 2], [1, 2, 5], [2, 5],
+                 [1, 3, 6], [3, 7], [2, 3, 7], [1, 2, 3, 4], [0, 1, 8, 3, 7], [5], [4], [1, 2, 3, 6]]
+
+
+@pytest.mark.parametrize("seed", range(_N_SEEDS or 24))
+def test_random_demixer_configuration_matches_oracle(hip, seed):
+    """random scalable stacks, output gains, demixing-mode schedules, recon gains, frame sizes and call
+    partitions: decoded layers -> demixer -> layout matrix -> limiter -> s16 (wide4 demixer variant
+    where it applies, else the generic kernel) against the oracle demixer + renderer chain"""
+    import demix_cases as D
+    from test_gpu_wide4 import _demix_render, _LAYOUT_SS
+    A, G = hip
+    rng = np.random.default_rng(5000 + seed)
+    layers = _DEMIX_STACKS[int(rng.integers(len(_DEMIX_STACKS)))]
+    if layers[-1] < 2:
+        layers = [1, 3, 7]
+    gains = {}
+    for li in range(len(layers)):
+        if rng.random() < 0.4:
+            gains[li] = (int(rng.integers(1, 64)), float(np.float32(10 ** (float(rng.integers(-6, 7)) / 20))))
+    fs = int(rng.choice([256, 512, 960, 1024]))
+    offset = int(rng.choice([0, 0, 4, 8, 37])) if fs >= 512 else 0
+    try:
+        c = D.make_case(layers, gains, default=(int(rng.choice([0, 1, 2, 4, 5, 6])), int(rng.integers(0, 11))),
+                        offset=offset, fs=fs, seed=900 + seed)
+    except Exception:
+        pytest.skip("stack not accepted by the case builder")
+    F = len(c["schedule"])
+    ch = len(c["order"])
+    S = int(rng.integers(1, 3))
+    x = np.stack([np.stack([synth.uniform(c["seed"] + 100 * s + f, ch, fs, 0.8) for f in range(F)]) for s in range(S)])
+    dem = [D.drive_demixer(O.lib(), "orc_demixer_", c, x[s]) for s in range(S)]
+    src = _LAYOUT_SS[c["layout"]]
+    out = str(rng.choice(["J", "B", "D", "A", "H", "id"]))
+    if out == "id":
+        mx, omx, och = G.identity_matrix(ch), None, ch
+    else:
+        try:
+            mx, omx = A.get_m2m_matrix(A.SS[src], A.SS[out]), O.get_m2m(O.SS[src], O.SS[out])
+        except (KeyError, AssertionError):
+            mx, omx, och = G.identity_matrix(ch), None, ch
+            out = "id"
+        else:
+            och = A.layout_channels(A.SS[out])
+    calls = _partition(rng, F)
+    got = _demix_render(A, c, mx, och, x, calls)
+    for s in range(S):
+        xd = np.ascontiguousarray(dem[s].transpose(1, 0, 2).reshape(ch, F * fs))
+        if omx is None:
+            z, _ = O.limiter_run(xd, [fs] * F)
+            want = O.pack(z, 16)
+        else:
+            want = O.stream_run(omx, och, xd, fs)
+        assert got[s].shape == want.shape, (seed, layers, out, s)
+        assert np.array_equal(got[s], want), (seed, layers, out, s)
