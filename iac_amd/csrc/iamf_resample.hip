@@ -38,6 +38,8 @@ struct RsParams {
   uint32_t num, den, int_adv;
   int32_t ls0;
   uint32_t fr0;
+  const float *table4;    // interpolated mode: [oversample][N][4] = the four table values a tap multiplies, per offset
+  int32_t win_cap;        // resample_tile_kernel: samples of [hist | in] one workgroup stages
 };
 
 // resample.c:246-256
@@ -105,6 +107,97 @@ __global__ __launch_bounds__(256) void resample_kernel(const RsParams p) {
   p.out[(int64_t)s * p.out_stream_stride + e] = sum;
 }
 
+// Both filter modes (interpolated: every rate pair but the small-denominator ones, e.g. 44.1 <-> 48
+// kHz; direct: 2:1, 3:2 ...) with the operands in LDS.  A workgroup owns 1024 consecutive (output, channel) elements of one stream: the
+// stretch of [hist | in] they read is staged once (interleaved as in memory: lanes read consecutive
+// floats), and so is the filter table, re-laid per interpolation offset so that the four values
+// a tap multiplies are one aligned 16-byte read.  The same f32 operations in the same order as
+// resample_kernel (resample.c:372-400): bit-exact.
+constexpr int kRsTile = 1024;  // (output, channel) elements per workgroup: 4 per thread
+__global__ __launch_bounds__(256) void resample_tile_kernel(const RsParams p) {
+  extern __shared__ float rs_lds[];
+  const int s = blockIdx.y;
+  const int64_t e0 = (int64_t)blockIdx.x * kRsTile;
+  const int hist_len = p.N - 1;
+  const int N = p.N, ch = p.ch;
+  const float *in = p.in ? p.in + (int64_t)s * p.in_stream_stride : nullptr;
+  const float *hist = p.hist + (int64_t)s * hist_len * ch;
+  float *win = rs_lds;                                  // [win_cap][ch]
+  float4 *tab = reinterpret_cast<float4 *>(rs_lds + (((size_t)p.win_cap * ch + 3) & ~(size_t)3));  // [oversample][N + 1]
+
+  // history for the next call: [hist | in] shifted by the consumed samples (resample.c:801-809)
+  for (int64_t e = e0 + threadIdx.x; e < e0 + kRsTile && e < (int64_t)hist_len * ch; e += 256) {
+    const int j = (int)(e / ch), c = (int)(e - (int64_t)j * ch);
+    const int src = j + p.consumed;  // index into [hist | in]
+    float v = 0.f;
+    if (src < hist_len)
+      v = hist[src * ch + c];
+    else if (in)
+      v = in[(int64_t)(src - hist_len) * ch + c];
+    p.hist_next[((int64_t)s * hist_len + j) * ch + c] = v;
+  }
+  // first window position of the workgroup's first output (positions grow with the output index)
+  const int64_t k_first = e0 / ch;
+  const int base = p.ls0 + (int)(((uint64_t)p.fr0 + (uint64_t)k_first * p.num) / p.den);
+  for (int i = threadIdx.x; i < p.win_cap * ch; i += 256) {
+    const int idx = base + i / ch, c = i - (i / ch) * ch;
+    float v = 0.f;
+    if (idx < hist_len)
+      v = hist[idx * ch + c];
+    else if (in && idx - hist_len < p.ns)
+      v = in[(int64_t)(idx - hist_len) * ch + c];
+    win[i] = v;
+  }
+  // one row per offset (interpolated mode) or per phase (direct mode), rows padded by 16 bytes: the
+  // lanes of a wave sit on several rows at the same tap, and a row is a multiple of the LDS bank span
+  const int N4 = N >> 2;  // direct mode: N is a multiple of 8, a row = N / 4 float4 of consecutive taps
+  if (p.direct) {
+    const float4 *t4 = reinterpret_cast<const float4 *>(p.table);
+    for (int i = threadIdx.x; i < (int)p.den * N4; i += 256) tab[i + i / N4] = t4[i];
+  } else {
+    const float4 *t4 = reinterpret_cast<const float4 *>(p.table4);
+    for (int i = threadIdx.x; i < p.oversample * N; i += 256) tab[i + i / N] = t4[i];
+  }
+  __syncthreads();
+  for (int64_t e = e0 + threadIdx.x; e < e0 + kRsTile && e < (int64_t)p.n_out * ch; e += 256) {
+    const int k = (int)(e / ch), c = (int)(e - (int64_t)k * ch);
+    const uint64_t tot = (uint64_t)p.fr0 + (uint64_t)k * p.num;
+    const int pos = p.ls0 + (int)(tot / p.den);
+    const uint32_t frac = (uint32_t)(tot % p.den);
+    const int offset = (int)(frac * (uint32_t)p.oversample / p.den);
+    const float fr = ((float)((frac * (uint32_t)p.oversample) % p.den)) / (float)p.den;
+    const float *wp = win + (size_t)(pos - base) * ch + c;
+    float sum;
+    if (p.direct) {  // resample.c:273-281
+      const float4 *tp = tab + (size_t)frac * (N4 + 1);
+      sum = 0.f;
+      for (int j = 0; j < N4; ++j) {
+        const float4 w = tp[j];
+        sum = sum + w.x * wp[(size_t)(4 * j + 0) * ch];
+        sum = sum + w.y * wp[(size_t)(4 * j + 1) * ch];
+        sum = sum + w.z * wp[(size_t)(4 * j + 2) * ch];
+        sum = sum + w.w * wp[(size_t)(4 * j + 3) * ch];
+      }
+    } else {  // resample.c:372-400
+      const float4 *tp = tab + (size_t)offset * (N + 1);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      for (int j = 0; j < N; ++j) {
+        const float cur = wp[(size_t)j * ch];
+        const float4 w = tp[j];
+        a0 = a0 + cur * w.x;
+        a1 = a1 + cur * w.y;
+        a2 = a2 + cur * w.z;
+        a3 = a3 + cur * w.w;
+      }
+      float interp[4];
+      cubic_coef(fr, interp);
+      sum = interp[0] * a0 + interp[1] * a1 + interp[2] * a2 + interp[3] * a3;
+    }
+    sum = sum < -1.0f ? -1.0f : (sum > 1.0f ? 1.0f : sum);  // FLTADJUST, resample.c:84,959
+    p.out[(int64_t)s * p.out_stream_stride + e] = sum;
+  }
+}
+
 // ---- filter design on the host: resample.c:194-231 (window, sinc) and :527-611 ----
 double window_at(float x) {
   float y, frac;
@@ -158,7 +251,7 @@ struct iamf_hip_resampler {
   float cutoff = 0.f;
   int last_sample = 0;
   unsigned frac = 0;
-  float *d_table = nullptr, *d_hist[2] = {nullptr, nullptr};
+  float *d_table = nullptr, *d_table4 = nullptr, *d_hist[2] = {nullptr, nullptr};
   int cur = 0;
 };
 
@@ -203,7 +296,19 @@ int rs_run(iamf_hip_resampler *r, const float *d_in, int64_t in_stride, int ns, 
   p.fr0 = r->frac;
   const int64_t work = (int64_t)(n_out > (int)r->filt_len - 1 ? n_out : (int)r->filt_len - 1) * r->ch;
   dim3 grid((unsigned)((work + 255) / 256), (unsigned)r->n_streams);
-  hipLaunchKernelGGL(resample_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  // the LDS-tiled kernel where its operands fit: 256 / ch outputs advance num / den samples each, plus the taps
+  const int outs = kRsTile / r->ch + 2;
+  const int64_t win_cap = ((int64_t)outs * r->num + r->den - 1) / r->den + (int64_t)r->filt_len + 2;
+  const size_t tab_floats = r->direct ? (size_t)r->den * (r->filt_len + 4) : (size_t)4 * r->oversample * (r->filt_len + 1);
+  const size_t lds = sizeof(float) * ((((size_t)win_cap * r->ch + 3) & ~(size_t)3) + tab_floats);
+  if ((r->direct ? (r->filt_len & 7) == 0 : r->d_table4 != nullptr) && lds <= 48 * 1024 && !getenv("IAMF_HIP_RESAMPLE_PLAIN")) {
+    p.table4 = r->d_table4;
+    p.win_cap = (int)win_cap;
+    dim3 tgrid((unsigned)((work + kRsTile - 1) / kRsTile), (unsigned)r->n_streams);
+    hipLaunchKernelGGL(resample_tile_kernel, tgrid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  } else {
+    hipLaunchKernelGGL(resample_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  }
   RS_HIPCHK(hipGetLastError());
   r->last_sample = ls - consumed;
   r->frac = fr;
@@ -261,12 +366,22 @@ int iamf_hip_resampler_create(int n_streams, int channels, int in_rate, int out_
     for (int i = -4; i < (int)(r->oversample * r->filt_len + 4); i++)
       tab[i + 4] = sinc_at(r->cutoff, (i / (float)r->oversample - r->filt_len / 2), (int)r->filt_len);
   }
+  std::vector<float> tab4;
+  if (!r->direct) {  // resample_tile_kernel: the four values tap j multiplies at interpolation offset o, contiguous
+    tab4.resize((size_t)4 * r->oversample * r->filt_len);
+    for (unsigned o = 0; o < r->oversample; ++o)
+      for (unsigned j = 0; j < r->filt_len; ++j)
+        for (int q = 0; q < 4; ++q)
+          tab4[((size_t)o * r->filt_len + j) * 4 + q] = tab[4 + (size_t)(j + 1) * r->oversample - o + (q - 2)];
+  }
   r->last_sample = (int)(r->filt_len / 2);  // speex_resampler_skip_zeros (IAMF_decoder.c:1902)
   r->frac = 0;
   const size_t hist_bytes = sizeof(float) * (size_t)n_streams * (r->filt_len - 1) * channels;
   if (hipMalloc(&r->d_table, sizeof(float) * tab.size()) != hipSuccess ||
       hipMalloc(&r->d_hist[0], hist_bytes) != hipSuccess || hipMalloc(&r->d_hist[1], hist_bytes) != hipSuccess ||
       hipMemcpy(r->d_table, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      (!tab4.empty() && (hipMalloc(&r->d_table4, sizeof(float) * tab4.size()) != hipSuccess ||
+                         hipMemcpy(r->d_table4, tab4.data(), sizeof(float) * tab4.size(), hipMemcpyHostToDevice) != hipSuccess)) ||
       hipMemset(r->d_hist[0], 0, hist_bytes) != hipSuccess || hipMemset(r->d_hist[1], 0, hist_bytes) != hipSuccess) {
     iamf_hip_resampler_destroy(r);
     return IAMF_HIP_ERR_DEVICE;
@@ -278,6 +393,7 @@ int iamf_hip_resampler_create(int n_streams, int channels, int in_rate, int out_
 void iamf_hip_resampler_destroy(iamf_hip_resampler *r) {
   if (!r) return;
   (void)hipFree(r->d_table);
+  (void)hipFree(r->d_table4);
   (void)hipFree(r->d_hist[0]);
   (void)hipFree(r->d_hist[1]);
   delete r;
