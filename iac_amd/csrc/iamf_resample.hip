@@ -5,7 +5,8 @@
 // The reference walks each channel serially with a phase accumulator.  Output k of a call is a
 // pure function of the call's start state: pos_k = last_sample + floor((frac + k*num)/den),
 // phase_k = (frac + k*num) mod den, so every (stream, output, channel) is one independent thread
-// doing the reference's 64-tap f32 dot product in the reference's order (bit-exact).  Buffers are
+// doing the reference's 64-tap f32 dot product in the reference's order (bit-exact); the tiled
+// kernel stages a workgroup's stretch of input and the filter table in LDS first.  Buffers are
 // interleaved f32 ([sample][channel]) — what the render kernels emit with IAMF_HIP_FMT_F32 and
 // what a frame_size-1 batch consumes — so the resampled path is: render(F32, limiter off) ->
 // resample -> render(identity matrix, loudness, limiter, PCM pack).
