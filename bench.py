@@ -205,7 +205,9 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="frames per stream per step")
     ap.add_argument("--frame-size", type=int, default=1024)
     ap.add_argument("--workload", default="toa_binaural_limiter_s16", choices=sorted(WORKLOADS))
-    ap.add_argument("--signal", default="hot", choices=["hot", "quiet"])
+    ap.add_argument("--signal", default="hot", choices=["hot", "quiet", "sparse"],
+                    help="hot: the limiter re-triggers in almost every 64-sample block; quiet: never; sparse: a "
+                         "quiet programme with a short peak every ~1500 samples (one or two isolated trigger runs per chunk)")
     ap.add_argument("--gather", default="final", choices=["final", "step", "none"],
                     help="N>1: gather packed PCM to rank 0 over RCCL once after the last step (default, the "
                          "job's one exchange), after every step (overlapped with the next render), or never")
@@ -245,6 +247,13 @@ def main():
     x = synth_hot_device(S, in_ch, F, fs, 1000 + rank, dev)
     if args.signal == "quiet":
         x = (torch.randn_like(x) * 0.05).contiguous()
+    if args.signal == "sparse":
+        x = torch.randn_like(x) * 0.05
+        tt = torch.arange(F * fs, device=dev).view(1, F, 1, fs)
+        ph = (torch.arange(S, device=dev) * 389 % 1531).view(S, 1, 1, 1)
+        x += (((tt - ph) % 1531) < 8) * torch.where(tt % 2 == 0, 1.0, -1.0) * 1.5
+        x = x.contiguous()
+        del tt, ph
     batch = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True,
                     fir_taps=FIR_TAPS if kind == "fir" else 0)
     demix_args = None
@@ -411,7 +420,8 @@ def main():
             "config": {"workload": args.workload, "streams_per_gpu": S, "frames_per_step": F,
                        "frame_size": fs, "sample_rate": 48000, "in_channels": in_ch,
                        "out_channels": out_ch, "pcm": "s16", "limiter": "-1 dBFS, 240 look-ahead",
-                       "signal": "hot (sigma 0.25 + 1.5 bursts)" if args.signal == "hot" else "quiet (sigma 0.05)", "parallelism": "streams sharded, dp%d" % world,
+                       "signal": {"hot": "hot (sigma 0.25 + 1.5 bursts)", "quiet": "quiet (sigma 0.05)",
+                                  "sparse": "sparse (sigma 0.05 + an 8-sample 1.5 peak every 1531 samples)"}[args.signal], "parallelism": "streams sharded, dp%d" % world,
                        "input_stagger_kib": args.pad_kb,
                        "gather": args.gather if world > 1 else "n/a (1 GPU)"},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),

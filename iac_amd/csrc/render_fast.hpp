@@ -50,20 +50,26 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 // arr_g.  (n, gs, ge) is the state before the first sample of block b0 and is updated to the
 // state after the last sample.  Restates audio_effect_peak_limiter.c:237-265 sample by sample:
 // every accepted gain is produced by exactly the reference's f32 operations.
+// With stop_clean the walk ends behind the first block after b0 in which nothing triggered (the caller
+// then re-evaluates the rest of the chunk in parallel from the state reached); the return value is
+// the first block NOT processed.
 template <typename Lookup>
-__device__ __forceinline__ void limiter_wave(const float *arr_p, float *arr_g,
-                                             Lookup ctab, int b0, int nblk, int &n, float &gs,
-                                             float &ge, float &g_last, float thr, int n_atk, int n_end) {
+__device__ __forceinline__ int limiter_wave(const float *arr_p, float *arr_g,
+                                            Lookup ctab, int b0, int nblk, int &n, float &gs,
+                                            float &ge, float &g_last, float thr, int n_atk, int n_end,
+                                            bool stop_clean = false) {
   const int lane = threadIdx.x & 63;
   // A dependent chain: whenever this wave has an instruction ready it should go first, ahead of the
   // co-resident workgroup's wave on the same SIMD (which has a whole chunk of independent work).
   __builtin_amdgcn_s_setprio(3);
   const float a1 = ctab(1);  // attack-curve value one step after a trigger
   float gacc = 1.0f;
-  for (int b = b0; b < nblk; ++b) {
+  int b = b0;
+  for (; b < nblk; ++b) {
     const float pk = arr_p[b * 64 + lane];
     const float e = thr / pk;  // targetEndGain if this sample triggers (IEEE division, as the reference)
     int l0 = 0;
+    bool clean = true;
     while (true) {
       // speculate: no trigger in lanes l0..63 given the state before lane l0
       int n_pre = n + (lane - l0);
@@ -79,6 +85,7 @@ __device__ __forceinline__ void limiter_wave(const float *arr_p, float *arr_g,
         n = n + (64 - l0) < n_end ? n + (64 - l0) : n_end;
         break;
       }
+      clean = false;
       const int f = __builtin_ctzll(mask);  // first trigger: lanes l0..f are settled
       if (lane >= l0 && lane <= f) gacc = g;
       gs = readlane_f(g, f);
@@ -109,6 +116,8 @@ __device__ __forceinline__ void limiter_wave(const float *arr_p, float *arr_g,
                      : [g] "+v"(G), [t] "=&v"(tmp)
                      : [ep] "v"(ep), [a1] "v"(a1));
 #undef IAMF_SWEEP
+        // (leaving the loop as soon as the run is seen to have ended among the settled lanes costs more
+        //  than it saves: 58 vs 61 Gsamples/s on a programme of short isolated peaks)
       }
       const bool tr2 = pk * G > thr;
       const unsigned long long stop = __ballot(lane > f && !tr2);
@@ -129,9 +138,14 @@ __device__ __forceinline__ void limiter_wave(const float *arr_p, float *arr_g,
       if (l0 >= 64) break;
     }
     arr_g[b * 64 + lane] = gacc;
+    if (stop_clean && clean && b > b0) {
+      ++b;
+      break;
+    }
   }
   g_last = readlane_f(gacc, 63);
   __builtin_amdgcn_s_setprio(0);
+  return b;
 }
 
 // Which of the workgroup's 4 waves runs the serial limiter recurrence.  Workgroups that share a CU
@@ -484,6 +498,7 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
     // ---- 240-sample window maximum = tail of block b-15, blocks b-14..b-1, head of block b ----
     const int rd = ring_wrap(base + 4 * t - kDelay);  // ring position of sample gk - 240
     float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 pk4 = make_float4(0.f, 0.f, 0.f, 0.f);  // the lane's four window maxima
     if (act) {
       const int bpos = rp >> 4;
       float w14 = 0.f;
@@ -499,68 +514,82 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
       pk.y = fmaxf(fmaxf(so.y, w14), pre_ex.y);
       pk.z = fmaxf(fmaxf(so.z, w14), pre_ex.z);
       pk.w = fmaxf(fmaxf(so.w, w14), pre_ex.w);
-      // ---- gains under the hypothesis "no trigger in this chunk" ----
-      float gh[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int np = n_st + 4 * t + j;
-        np = np < n_end ? np : n_end;
-        const int ci = np + 1 < n_end ? np + 1 : n_end;
-        gh[j] = gain_at(np, gs, ge, FIR ? p.ctab[ci] : win[4 * t + j + 1], n_atk, n_end);
-      }
-      g = make_float4(gh[0], gh[1], gh[2], gh[3]);
-      int kfirst = kBig;
-      if (valid) {
-        if (pk.w * g.w > thr) kfirst = 4 * t + 3;
-        if (pk.z * g.z > thr) kfirst = 4 * t + 2;
-        if (pk.y * g.y > thr) kfirst = 4 * t + 1;
-        if (pk.x * g.x > thr) kfirst = 4 * t + 0;
-      }
       *reinterpret_cast<float4 *>(&arr_p[4 * t]) = pk;
-      const unsigned long long any = __ballot(kfirst != kBig);
-      if (lane == 0) misc[wave] = __int_as_float(any ? __builtin_amdgcn_readlane(kfirst, __builtin_ctzll(any)) : kBig);
-      if (4 * t + 4 == cnt) misc[8] = g.w;  // gain of the chunk's last sample under the hypothesis
+      pk4 = pk;
     }
-    __syncthreads();
-    int kf = __float_as_int(misc[0]);
-    kf = min(kf, __float_as_int(misc[1]));
-    kf = min(kf, __float_as_int(misc[2]));
-    kf = min(kf, __float_as_int(misc[3]));
-
-    if (kf == kBig) {
-      // the hypothesis holds for the whole chunk
-      g_cur = misc[8];
-      n_st = n_st + cnt < n_end ? n_st + cnt : n_end;
-    } else {
+    // ---- limiter gains in rounds.  Every lane evaluates its gains under the hypothesis "no trigger
+    //      from block bs on" (state = the one reached before block bs; round 0: the whole chunk, state
+    //      of the chunk's start), a workgroup vote finds the first sample that contradicts it.  None:
+    //      done.  Else the chain wave walks the recurrence from that block through the blocks that
+    //      trigger and one more, and the next round re-evaluates what is left from the state it reached
+    //      — so a chunk with a few isolated trigger runs costs a few short walks, not one walk to its end.
+    const int n_chunk = n_st;  // what the staged table window is based on
+    auto look = [&](int ci) {  // before the chunk's first trigger: the window; after one: the head
+      if constexpr (FIR) {
+        return p.ctab[ci];
+      } else {
+        const int d = ci - n_chunk;
+        return (d >= 0 && d < kFWin) ? win[d] : head[ci < kFWin ? ci : kFWin - 1];
+      }
+    };
+    const int nblk = cnt >> 6;
+    int bs = 0;
+    while (true) {
+      if (act) {
+        int kfirst = kBig;
+        if (4 * t >= 64 * bs) {
+          float gh[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            int np = n_st + (4 * t + j - 64 * bs);
+            np = np < n_end ? np : n_end;
+            const int ci = np + 1 < n_end ? np + 1 : n_end;
+            gh[j] = gain_at(np, gs, ge, look(ci), n_atk, n_end);
+          }
+          g = make_float4(gh[0], gh[1], gh[2], gh[3]);
+          if (valid) {
+            if (pk4.w * g.w > thr) kfirst = 4 * t + 3;
+            if (pk4.z * g.z > thr) kfirst = 4 * t + 2;
+            if (pk4.y * g.y > thr) kfirst = 4 * t + 1;
+            if (pk4.x * g.x > thr) kfirst = 4 * t + 0;
+          }
+          if (4 * t + 4 == cnt) misc[8] = g.w;  // gain of the chunk's last sample under the hypothesis
+        }
+        const unsigned long long any = __ballot(kfirst != kBig);
+        if (lane == 0) misc[wave] = __int_as_float(any ? __builtin_amdgcn_readlane(kfirst, __builtin_ctzll(any)) : kBig);
+      }
+      __syncthreads();
+      int kf = __float_as_int(misc[0]);
+      kf = min(kf, __float_as_int(misc[1]));
+      kf = min(kf, __float_as_int(misc[2]));
+      kf = min(kf, __float_as_int(misc[3]));
+      if (kf == kBig) {  // the hypothesis holds for the rest of the chunk
+        g_cur = misc[8];
+        n_st = n_st + (cnt - 64 * bs) < n_end ? n_st + (cnt - 64 * bs) : n_end;
+        break;
+      }
       const int b0 = kf >> 6;
       if (act && wave == cw) {
-        int ln = n_st + 64 * b0 < n_end ? n_st + 64 * b0 : n_end;
+        int ln = n_st + 64 * (b0 - bs) < n_end ? n_st + 64 * (b0 - bs) : n_end;
         float lgs = gs, lge = ge, lgl = g_cur;
-        if constexpr (FIR) {
-          const float *ctl = p.ctab;
-          limiter_wave(arr_p, arr_g, [ctl](int ci) { return ctl[ci]; }, b0, cnt >> 6, ln, lgs, lge, lgl, thr, n_atk,
-                       n_end);
-        } else {
-          const int n_chunk = n_st;
-          auto look = [win, head, n_chunk](int ci) {  // before a trigger: the window; after one: the head
-            const int d = ci - n_chunk;
-            return (d >= 0 && d < kFWin) ? win[d] : head[ci < kFWin ? ci : kFWin - 1];
-          };
-          limiter_wave(arr_p, arr_g, look, b0, cnt >> 6, ln, lgs, lge, lgl, thr, n_atk, n_end);
-        }
+        const int be = limiter_wave(arr_p, arr_g, look, b0, nblk, ln, lgs, lge, lgl, thr, n_atk, n_end, true);
         if (lane == 0) {
           misc[4] = lgl;
           misc[5] = lgs;
           misc[6] = lge;
           misc[7] = __int_as_float(ln);
+          misc[9] = __int_as_float(be);
         }
       }
       __syncthreads();
-      if (4 * t >= 64 * b0) g = *reinterpret_cast<const float4 *>(&arr_g[4 * t]);
+      const int be = __float_as_int(misc[9]);
+      if (4 * t >= 64 * b0 && 4 * t < 64 * be) g = *reinterpret_cast<const float4 *>(&arr_g[4 * t]);
       g_cur = misc[4];
       gs = misc[5];
       ge = misc[6];
       n_st = __float_as_int(misc[7]);
+      bs = be;
+      if (bs >= nblk) break;
     }
 
     if (c0 + kFChunk < p.total) fetch_window(n_st);  // for the next chunk, ahead of the stores
