@@ -704,60 +704,76 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
     pk.y = fmaxf(fmaxf(so.y, w14), pre_ex.y);
     pk.z = fmaxf(fmaxf(so.z, w14), pre_ex.z);
     pk.w = fmaxf(fmaxf(so.w, w14), pre_ex.w);
-    // ---- gains under the hypothesis "no trigger in this chunk": win[i] = ctab[min(n_st+i, n_end)] ----
-    float gh[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int np = n_st + 4 * tv + j;
-      np = np < n_end ? np : n_end;
-      gh[j] = gain_at(np, gs, ge, win[4 * tv + j + 1], n_atk, n_end);
-    }
-    const float4 g = make_float4(gh[0], gh[1], gh[2], gh[3]);
-    int kfirst = kBig;
-    if (valid) {
-      if (pk.w * g.w > thr) kfirst = 4 * tv + 3;
-      if (pk.z * g.z > thr) kfirst = 4 * tv + 2;
-      if (pk.y * g.y > thr) kfirst = 4 * tv + 1;
-      if (pk.x * g.x > thr) kfirst = 4 * tv + 0;
-    }
     *reinterpret_cast<float4 *>(&arr_p[4 * tv]) = pk;
-    *reinterpret_cast<float4 *>(&arr_g[4 * tv]) = g;
+    // ---- limiter gains in rounds, as in render_fast.hpp: hypothesis "no trigger from block bs on" for
+    //      every sample not yet settled -> vote -> the chain wave walks the blocks that trigger and one
+    //      more -> the next round re-evaluates the rest from the state reached.  win[i] = ctab[min(n_chunk
+    //      + i, n_end)] serves round 0 directly, `look` every later one.
     {
-      const unsigned long long any = __ballot(kfirst != kBig);
-      if (lane == 0) misc[wave] = __int_as_float(any ? __builtin_amdgcn_readlane(kfirst, __builtin_ctzll(any)) : kBig);
-      if (4 * tv + 4 == cnt) misc[8] = g.w;  // gain of the chunk's last sample under the hypothesis
-    }
-    __syncthreads();  // (2) vote, gains and window maxima visible
-    int kf = __float_as_int(misc[0]);
-    kf = min(kf, __float_as_int(misc[1]));
-    kf = min(kf, __float_as_int(misc[2]));
-    kf = min(kf, __float_as_int(misc[3]));
-    if (kf == kBig) {
-      g_cur = misc[8];
-      n_st = n_st + cnt < n_end ? n_st + cnt : n_end;
-    } else {
-      const int b0 = kf >> 6;
-      if (wave == cw) {
-        const int n_chunk = n_st;
-        int ln = n_st + 64 * b0 < n_end ? n_st + 64 * b0 : n_end;
-        float lgs = gs, lge = ge, lgl = g_cur;
-        auto look = [win, head, n_chunk](int ci) {
-          const int d = ci - n_chunk;
-          return (d >= 0 && d < kW4Win) ? win[d] : head[ci < kW4Win ? ci : kW4Win - 1];
-        };
-        limiter_wave(arr_p, arr_g, look, b0, cnt >> 6, ln, lgs, lge, lgl, thr, n_atk, n_end);
-        if (lane == 0) {
-          misc[4] = lgl;
-          misc[5] = lgs;
-          misc[6] = lge;
-          misc[7] = __int_as_float(ln);
+      const int n_chunk = n_st;
+      auto look = [win, head, n_chunk](int ci) {
+        const int d = ci - n_chunk;
+        return (d >= 0 && d < kW4Win) ? win[d] : head[ci < kW4Win ? ci : kW4Win - 1];
+      };
+      const int nblk = cnt >> 6;
+      int bs = 0;
+      while (true) {
+        int kfirst = kBig;
+        if (4 * tv >= 64 * bs) {
+          float gh[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            int np = n_st + (4 * tv + j - 64 * bs);
+            np = np < n_end ? np : n_end;
+            const int ci = np + 1 < n_end ? np + 1 : n_end;
+            gh[j] = gain_at(np, gs, ge, look(ci), n_atk, n_end);
+          }
+          const float4 g = make_float4(gh[0], gh[1], gh[2], gh[3]);
+          const float4 pq = *reinterpret_cast<const float4 *>(&arr_p[4 * tv]);  // the lane's own maxima, back from LDS
+          if (valid) {
+            if (pq.w * g.w > thr) kfirst = 4 * tv + 3;
+            if (pq.z * g.z > thr) kfirst = 4 * tv + 2;
+            if (pq.y * g.y > thr) kfirst = 4 * tv + 1;
+            if (pq.x * g.x > thr) kfirst = 4 * tv + 0;
+          }
+          *reinterpret_cast<float4 *>(&arr_g[4 * tv]) = g;
+          if (4 * tv + 4 == cnt) misc[8] = g.w;  // gain of the chunk's last sample under the hypothesis
         }
+        {
+          const unsigned long long any = __ballot(kfirst != kBig);
+          if (lane == 0) misc[wave] = __int_as_float(any ? __builtin_amdgcn_readlane(kfirst, __builtin_ctzll(any)) : kBig);
+        }
+        __syncthreads();  // (2) vote, gains and window maxima visible
+        int kf = __float_as_int(misc[0]);
+        kf = min(kf, __float_as_int(misc[1]));
+        kf = min(kf, __float_as_int(misc[2]));
+        kf = min(kf, __float_as_int(misc[3]));
+        if (kf == kBig) {
+          g_cur = misc[8];
+          n_st = n_st + (cnt - 64 * bs) < n_end ? n_st + (cnt - 64 * bs) : n_end;
+          break;
+        }
+        const int b0 = kf >> 6;
+        if (wave == cw) {
+          int ln = n_st + 64 * (b0 - bs) < n_end ? n_st + 64 * (b0 - bs) : n_end;
+          float lgs = gs, lge = ge, lgl = g_cur;
+          const int be = limiter_wave(arr_p, arr_g, look, b0, nblk, ln, lgs, lge, lgl, thr, n_atk, n_end, true);
+          if (lane == 0) {
+            misc[4] = lgl;
+            misc[5] = lgs;
+            misc[6] = lge;
+            misc[7] = __int_as_float(ln);
+            misc[9] = __int_as_float(be);
+          }
+        }
+        __syncthreads();  // (3) recurrence gains visible
+        g_cur = misc[4];
+        gs = misc[5];
+        ge = misc[6];
+        n_st = __float_as_int(misc[7]);
+        bs = __float_as_int(misc[9]);
+        if (bs >= nblk) break;
       }
-      __syncthreads();  // (3) recurrence gains visible
-      g_cur = misc[4];
-      gs = misc[5];
-      ge = misc[6];
-      n_st = __float_as_int(misc[7]);
     }
 
     // ---- emit 4 sample-frames per lane: lanes < 196 their own (gains at +240 in this chunk),
