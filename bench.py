@@ -11,7 +11,14 @@ region starts.  One process per GPU; streams shard over ranks with no collective
 path; the job's one exchange is the gather of the packed PCM to rank 0 over RCCL after the last
 step (--gather step gathers every step instead, overlapped with the next render).
 
-Prints ONE JSON line on rank 0.  value = sample-frames rendered by all ranks / wall time.
+`python bench.py --gpus N` with no launcher around it starts the N rank processes itself (before
+any GPU call, iac_amd/launch.py) and relays rank 0's line; under torchrun it is one rank.  It
+refuses to print a line whose n_gpus differs from --gpus.
+
+Prints ONE JSON line on rank 0.  value = sample-frames rendered by all ranks / wall time of the
+median of --repeats timed regions of exactly --steps launches each (all regions are listed under
+"repeats").  At N=1 the line also carries "configs": BASELINE configs 2, 3 and the HRTF form of
+config 4 measured in the same process with the same harness.
 """
 import argparse
 import json
@@ -48,7 +55,8 @@ WORKLOADS = {
     # parametric down-mixer (downmix_renderer.c) with a mode per frame, instead of a gain matrix
     # (the reference takes the down-mixer unless the input has height channels and the output none)
     "714_downmix_512_limiter_s16": ("dmx", 7, 3, 12, 12 * 4 + 8 * 2),
-    "710_downmix_stereo_limiter_s16": ("dmx", 5, 1, 8, 8 * 4 + 2 * 2),
+    # (the kernel never reads the LFE row: 7 of the 8 input channels reach a stereo down-mix)
+    "710_downmix_stereo_limiter_s16": ("dmx", 5, 1, 8, 7 * 4 + 2 * 2),
     # projection-mode 3rd-order ambisonics: 16 decoded channels -> de-mapping matrix ->
     # 16 ambisonics channels -> binaural / 5.1.  Tolerance mode (AUTO): one composed matrix on the
     # fast / wide4-MFMA kernel; IAMF_HIP_PROJECTION=exact in the environment gives the two exact stages
@@ -196,294 +204,408 @@ def reference_baseline(workload, fs, seconds_target=12.0):
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=512, help="streams per GPU")
-    ap.add_argument("--frames", type=int, default=64, help="frames per stream per step")
-    ap.add_argument("--frame-size", type=int, default=1024)
-    ap.add_argument("--workload", default="toa_binaural_limiter_s16", choices=sorted(WORKLOADS))
-    ap.add_argument("--signal", default="hot", choices=["hot", "quiet", "sparse"],
-                    help="hot: the limiter re-triggers in almost every 64-sample block; quiet: never; sparse: a "
-                         "quiet programme with a short peak every ~1500 samples (one or two isolated trigger runs per chunk)")
-    ap.add_argument("--gather", default="final", choices=["final", "step", "none"],
-                    help="N>1: gather packed PCM to rank 0 over RCCL once after the last step (default, the "
-                         "job's one exchange), after every step (overlapped with the next render), or never")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pad-kb", type=int, default=4,
-                    help="stagger the streams' input regions: stream stride = frames * channels * frame size "
-                         "+ this many KiB, so that the workgroups, which advance in step, are not all on the "
-                         "same HBM channel at once (0 = the power-of-two stride: -12 %% on the headline)")
-    args = ap.parse_args()
+SIGNALS = {"hot": "hot (sigma 0.25 + 1.5 bursts)", "quiet": "quiet (sigma 0.05)",
+           "sparse": "sparse (sigma 0.05 + an 8-sample 1.5 peak every 1531 samples)"}
+# BASELINE.json configs that fit one GPU besides the headline (configs[3] matrix form): measured in
+# the same process and reported under "configs" of the one JSON line (N=1 only)
+EXTRA_CONFIGS = ["714_ssJ_limiter_s16", "toa_ssH_limiter_s16", "toa_hrtf256_limiter_s16"]
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
 
-    import iac_amd as A
-    kind, in_id, out_id, in_ch, bytes_per_sf = WORKLOADS[args.workload]
-    if kind == "fir":
-        rng = np.random.default_rng(5)
-        hr = (rng.standard_normal((2, in_ch, FIR_TAPS)) * np.exp(-np.arange(FIR_TAPS) / 40.0) * 0.08).astype(np.float32)
-        mx = A.fir_matrix(hr)
-    elif kind == "dmx":
-        mx = A.dmx_matrix(in_id, out_id)
-    else:
-        mx = A.get_h2m_matrix(in_id, out_id) if kind in ("h2m", "h2m_proj", "h2m_in2") else A.get_m2m_matrix(in_id, out_id)
-    out_ch = mx.channels if kind == "dmx" else A.layout_channels(out_id)
-    S, F, fs = args.streams, args.frames, args.frame_size
-
-    x = synth_hot_device(S, in_ch, F, fs, 1000 + rank, dev)
-    if args.signal == "quiet":
-        x = (torch.randn_like(x) * 0.05).contiguous()
-    if args.signal == "sparse":
-        x = torch.randn_like(x) * 0.05
-        tt = torch.arange(F * fs, device=dev).view(1, F, 1, fs)
-        ph = (torch.arange(S, device=dev) * 389 % 1531).view(S, 1, 1, 1)
-        x += (((tt - ph) % 1531) < 8) * torch.where(tt % 2 == 0, 1.0, -1.0) * 1.5
-        x = x.contiguous()
-        del tt, ph
-    batch = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True,
-                    fir_taps=FIR_TAPS if kind == "fir" else 0)
-    demix_args = None
-    x2 = None
-    if kind in ("h2m_in2", "m2m_in2"):
-        batch.set_second_element(A.get_m2m_matrix(A.SS["STEREO"], out_id), [0.7] * S)
-        x2 = synth_hot_device(S, 2, F, fs, 2000 + rank, dev) * 0.5
-        demix_args = x2   # any non-None value: the call goes through render_ex
-    if kind == "dmx":   # host control plane: a down-mix mode per frame and stream (DMRenderer_set_mode_weight)
-        import ctypes as C
-        fr_ = (A.DmxFrame * (S * F))()
-        st_ = A.DmxState()
-        for s_ in range(S):
-            A.lib().iamf_hip_dmx_state_init(C.byref(st_))
-            A.lib().iamf_hip_dmx_set_mode_weight(C.byref(st_), 1, 3)
-            for f_ in range(F):
-                fr_[s_ * F + f_].offset = 0
-                A.lib().iamf_hip_dmx_coefficients(C.byref(st_), fr_[s_ * F + f_].prev)
-                A.lib().iamf_hip_dmx_set_mode_weight(C.byref(st_), (0, 1, 2, 4, 5, 6)[(s_ + f_) % 6], -1)
-                A.lib().iamf_hip_dmx_coefficients(C.byref(st_), fr_[s_ * F + f_].cur)
-        demix_args = torch.from_numpy(np.frombuffer(bytes(fr_), dtype=np.uint8).copy()).to(dev)
-    if kind == "h2m_proj":   # a well-conditioned Q15 de-mapping matrix (identity/2 + noise)
-        rngp = np.random.default_rng(5)
-        Pm = rngp.integers(-6000, 6000, size=(in_ch, in_ch)).astype(np.float32) * np.float32(2.0 ** -15)
-        Pm[np.arange(in_ch), np.arange(in_ch)] += np.float32(0.5)
-        batch.set_projection(Pm.astype(np.float32))
+def kernel_tag(kind, in_ch, out_ch):
+    if kind == "h2m_in2":
+        return "render_fast_kernel<%d, %d, 0, false, true" % (in_ch, out_ch)
+    if kind == "m2m_in2":
+        return "render_wide4_kernel<%d, %d, false, false, false, true" % (in_ch, out_ch)
+    if kind == "dmx":
+        return ("render_fast_kernel<%d, %d, 0, true" if out_ch <= 2 else
+                "render_wide4_kernel<%d, %d, false, false, true") % (in_ch, out_ch)
     if kind == "demix":
-        import ctypes as C
-        import demix_cases as D
-        layers = [1, 3, 7]
-        order, _ = D.channels_order(layers)
-        rec = D.recon_order(7, D.recon_flags(1, 7))
-        batch.set_demixer(7, order, D.output_gain_list(layers, {0: (0b110000, 0.7079458), 1: (0b001111, 1.4125376)}))
-        frames_rec = (A.DemixFrame * (S * F))()
-        rc = (C.c_int32 * 12)(*rec)
-        st = A.DemixState()
-        for s_ in range(S):   # host control plane: a demixing mode and recon gains per frame and stream
-            A.lib().iamf_hip_demix_state_init(C.byref(st))
-            A.lib().iamf_hip_demix_set_info(C.byref(st), 1, 3)
-            for f_ in range(F):
-                A.lib().iamf_hip_demix_set_info(C.byref(st), (0, 1, 2, 4, 5, 6)[(s_ + f_) % 6], -1)
-                gains_ = (C.c_float * 12)(*[0.75 + 0.25 * ((s_ * 7 + f_ * 3 + i) % 16) / 15.0 for i in range(len(rec))])
-                A.lib().iamf_hip_demix_frame_fill(C.byref(st), len(rec), rc, gains_, C.byref(frames_rec[s_ * F + f_]))
-        d_frames = torch.from_numpy(np.frombuffer(bytes(frames_rec), dtype=np.uint8).copy()).to(dev)
-        demix_args = d_frames
-        # The decoded layers are the DOWN-MIX of the programme x (7.1.4 playback order), made with the
-        # same per-frame factors the demixer will use (the encoder side of the codec: IAMF spec 7.2),
-        # so that what leaves the demixer is the programme every other workload renders.
-        raw = np.frombuffer(bytes(frames_rec), dtype=np.float32).reshape(S, F, -1)
-        cf = torch.from_numpy(raw[:, :, 5:10].copy()).to(dev).view(S, F, 5, 1)   # cur: alpha beta gamma delta w
-        al, be, ga, de = cf[:, :, 0], cf[:, :, 1], cf[:, :, 2], cf[:, :, 3]
-        L7, R7, Cc, LFE, SL7, SR7, BL7, BR7, HFL, HFR, HBL, HBR = [x[:, :, i] for i in range(12)]
-        SL5, SR5 = al * SL7 + be * BL7, al * SR7 + be * BR7
-        L2, R2 = L7 + de * SL5 + 0.707 * Cc, R7 + de * SR5 + 0.707 * Cc
-        HL, HR = HFL + ga * HBL, HFR + ga * HBR
-        x = torch.stack([L2 / 0.7079458, R2 / 0.7079458, L7, R7, HL / 1.4125376, HR / 1.4125376, Cc, LFE,
-                         SL7, SR7, HFL, HFR], dim=2).contiguous()
-        del L7, R7, Cc, LFE, SL7, SR7, BL7, BR7, HFL, HFR, HBL, HBR, SL5, SR5, L2, R2, HL, HR
-    stride_bytes = F * fs * out_ch * 2
-    pcm = [torch.zeros((S, stride_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
-    gather_on = world > 1 and args.gather != "none"
-    from iac_amd.sharding import GatherPipeline
-    pipe = GatherPipeline(pcm, world, rank, enabled=world > 1 and args.gather == "step")
-    final_recv = None
-    if world > 1 and args.gather == "final" and rank == 0:
-        final_recv = [torch.empty_like(pcm[0]) for _ in range(world)]
-    stream = torch.cuda.current_stream().cuda_stream
-    stream_stride, frame_stride = F * in_ch * fs, in_ch * fs
-    if args.pad_kb:
-        xp = torch.zeros((S, stream_stride + args.pad_kb * 256), dtype=torch.float32, device=dev)
-        xp[:, :stream_stride] = x.reshape(S, -1)
-        x = xp
-        stream_stride += args.pad_kb * 256
+        return "render_wide4_kernel<%d, %d, false, true" % (in_ch, out_ch)
+    if kind == "fir":
+        return "render_fast_kernel<%d, 2, 2" % in_ch
+    if out_ch <= 2:
+        return "render_fast_kernel<%d, %d, 0, false, false" % (in_ch, out_ch)
+    # whole 1024-sample chunks of s16: the 4-samples-per-lane kernel (else render_wide_kernel)
+    return "render_wide4_kernel<%d, %d" % (in_ch, out_ch)
 
-    def render_into(buf, ev_pair=None):
-        # events bracket only the render kernel: the gather runs on RCCL's own stream
+
+class Workload:
+    """One named workload set up on one device: synthetic element PCM resident in HBM, the batch,
+    two PCM buffers, and render_into(buf, events) = ONE launch of the hot path over the batch."""
+
+    def __init__(self, A, name, args, rank, dev):
+        self.A, self.name = A, name
+        kind, in_id, out_id, in_ch, self.bytes_per_sf = WORKLOADS[name]
+        self.kind, self.in_ch = kind, in_ch
+        if kind == "fir":
+            rng = np.random.default_rng(5)
+            hr = (rng.standard_normal((2, in_ch, FIR_TAPS)) * np.exp(-np.arange(FIR_TAPS) / 40.0) * 0.08).astype(np.float32)
+            mx = A.fir_matrix(hr)
+        elif kind == "dmx":
+            mx = A.dmx_matrix(in_id, out_id)
+        else:
+            mx = A.get_h2m_matrix(in_id, out_id) if kind in ("h2m", "h2m_proj", "h2m_in2") else A.get_m2m_matrix(in_id, out_id)
+        out_ch = self.out_ch = mx.channels if kind == "dmx" else A.layout_channels(out_id)
+        S, F, fs = args.streams, args.frames, args.frame_size
+        self.S, self.F, self.fs = S, F, fs
+
+        x = synth_hot_device(S, in_ch, F, fs, 1000 + rank, dev)
+        if args.signal == "quiet":
+            x = (torch.randn_like(x) * 0.05).contiguous()
+        if args.signal == "sparse":
+            x = torch.randn_like(x) * 0.05
+            tt = torch.arange(F * fs, device=dev).view(1, F, 1, fs)
+            ph = (torch.arange(S, device=dev) * 389 % 1531).view(S, 1, 1, 1)
+            x += (((tt - ph) % 1531) < 8) * torch.where(tt % 2 == 0, 1.0, -1.0) * 1.5
+            x = x.contiguous()
+            del tt, ph
+        batch = self.batch = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True,
+                                     fir_taps=FIR_TAPS if kind == "fir" else 0)
+        self.extra = None
+        self.x2 = None
+        if kind in ("h2m_in2", "m2m_in2"):
+            batch.set_second_element(A.get_m2m_matrix(A.SS["STEREO"], out_id), [0.7] * S)
+            self.x2 = synth_hot_device(S, 2, F, fs, 2000 + rank, dev) * 0.5
+            self.extra = self.x2   # any non-None value: the call goes through render_ex
+        if kind == "dmx":   # host control plane: a down-mix mode per frame and stream (DMRenderer_set_mode_weight)
+            import ctypes as C
+            fr_ = (A.DmxFrame * (S * F))()
+            st_ = A.DmxState()
+            for s_ in range(S):
+                A.lib().iamf_hip_dmx_state_init(C.byref(st_))
+                A.lib().iamf_hip_dmx_set_mode_weight(C.byref(st_), 1, 3)
+                for f_ in range(F):
+                    fr_[s_ * F + f_].offset = 0
+                    A.lib().iamf_hip_dmx_coefficients(C.byref(st_), fr_[s_ * F + f_].prev)
+                    A.lib().iamf_hip_dmx_set_mode_weight(C.byref(st_), (0, 1, 2, 4, 5, 6)[(s_ + f_) % 6], -1)
+                    A.lib().iamf_hip_dmx_coefficients(C.byref(st_), fr_[s_ * F + f_].cur)
+            self.extra = torch.from_numpy(np.frombuffer(bytes(fr_), dtype=np.uint8).copy()).to(dev)
+        if kind == "h2m_proj":   # a well-conditioned Q15 de-mapping matrix (identity/2 + noise)
+            rngp = np.random.default_rng(5)
+            Pm = rngp.integers(-6000, 6000, size=(in_ch, in_ch)).astype(np.float32) * np.float32(2.0 ** -15)
+            Pm[np.arange(in_ch), np.arange(in_ch)] += np.float32(0.5)
+            batch.set_projection(Pm.astype(np.float32))
+        if kind == "demix":
+            import ctypes as C
+            import demix_cases as D
+            layers = [1, 3, 7]
+            order, _ = D.channels_order(layers)
+            rec = D.recon_order(7, D.recon_flags(1, 7))
+            batch.set_demixer(7, order, D.output_gain_list(layers, {0: (0b110000, 0.7079458), 1: (0b001111, 1.4125376)}))
+            frames_rec = (A.DemixFrame * (S * F))()
+            rc = (C.c_int32 * 12)(*rec)
+            st = A.DemixState()
+            for s_ in range(S):   # host control plane: a demixing mode and recon gains per frame and stream
+                A.lib().iamf_hip_demix_state_init(C.byref(st))
+                A.lib().iamf_hip_demix_set_info(C.byref(st), 1, 3)
+                for f_ in range(F):
+                    A.lib().iamf_hip_demix_set_info(C.byref(st), (0, 1, 2, 4, 5, 6)[(s_ + f_) % 6], -1)
+                    gains_ = (C.c_float * 12)(*[0.75 + 0.25 * ((s_ * 7 + f_ * 3 + i) % 16) / 15.0 for i in range(len(rec))])
+                    A.lib().iamf_hip_demix_frame_fill(C.byref(st), len(rec), rc, gains_, C.byref(frames_rec[s_ * F + f_]))
+            self.extra = torch.from_numpy(np.frombuffer(bytes(frames_rec), dtype=np.uint8).copy()).to(dev)
+            # The decoded layers are the DOWN-MIX of the programme x (7.1.4 playback order), made with the
+            # same per-frame factors the demixer will use (the encoder side of the codec: IAMF spec 7.2),
+            # so that what leaves the demixer is the programme every other workload renders.
+            raw = np.frombuffer(bytes(frames_rec), dtype=np.float32).reshape(S, F, -1)
+            cf = torch.from_numpy(raw[:, :, 5:10].copy()).to(dev).view(S, F, 5, 1)   # cur: alpha beta gamma delta w
+            al, be, ga, de = cf[:, :, 0], cf[:, :, 1], cf[:, :, 2], cf[:, :, 3]
+            L7, R7, Cc, LFE, SL7, SR7, BL7, BR7, HFL, HFR, HBL, HBR = [x[:, :, i] for i in range(12)]
+            SL5, SR5 = al * SL7 + be * BL7, al * SR7 + be * BR7
+            L2, R2 = L7 + de * SL5 + 0.707 * Cc, R7 + de * SR5 + 0.707 * Cc
+            HL, HR = HFL + ga * HBL, HFR + ga * HBR
+            x = torch.stack([L2 / 0.7079458, R2 / 0.7079458, L7, R7, HL / 1.4125376, HR / 1.4125376, Cc, LFE,
+                             SL7, SR7, HFL, HFR], dim=2).contiguous()
+            del L7, R7, Cc, LFE, SL7, SR7, BL7, BR7, HFL, HFR, HBL, HBR, SL5, SR5, L2, R2, HL, HR
+        self.stride_bytes = F * fs * out_ch * 2
+        self.pcm = [torch.zeros((S, self.stride_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.stream_stride, self.frame_stride = F * in_ch * fs, in_ch * fs
+        if args.pad_kb:
+            xp = torch.zeros((S, self.stream_stride + args.pad_kb * 256), dtype=torch.float32, device=dev)
+            xp[:, :self.stream_stride] = x.reshape(S, -1)
+            x = xp
+            self.stream_stride += args.pad_kb * 256
+        self.x = x
+        self.sf_per_step = S * F * fs     # sample-frames one launch processes on this GPU
+        self.ktag = kernel_tag(kind, in_ch, out_ch)
+
+    def render_into(self, buf, ev_pair=None):
+        # events bracket only the render kernel (recorded on the stream it is launched on); the
+        # gather runs on RCCL's own stream
+        A, kind = self.A, self.kind
         if ev_pair:
             ev_pair[0].record()
-        if demix_args is not None:
+        if self.extra is not None:
             a = A.RenderArgs()
-            a.d_in, a.in_stream_stride, a.in_frame_stride = x.data_ptr(), stream_stride, frame_stride
-            a.n_frames, a.d_pcm, a.pcm_stream_stride_bytes, a.stream = F, buf.data_ptr(), stride_bytes, stream
+            a.d_in, a.in_stream_stride, a.in_frame_stride = self.x.data_ptr(), self.stream_stride, self.frame_stride
+            a.n_frames, a.d_pcm, a.pcm_stream_stride_bytes, a.stream = self.F, buf.data_ptr(), self.stride_bytes, self.stream
             if kind in ("h2m_in2", "m2m_in2"):
-                a.d_in2, a.in2_stream_stride, a.in2_frame_stride = x2.data_ptr(), F * 2 * fs, 2 * fs
+                a.d_in2, a.in2_stream_stride, a.in2_frame_stride = self.x2.data_ptr(), self.F * 2 * self.fs, 2 * self.fs
             elif kind == "dmx":
-                a.d_dmx_frames = demix_args.data_ptr()
+                a.d_dmx_frames = self.extra.data_ptr()
             else:
-                a.d_demix_frames = demix_args.data_ptr()
-            n = batch.render_ex(a)
+                a.d_demix_frames = self.extra.data_ptr()
+            n = self.batch.render_ex(a)
         else:
-            n = batch.render(x.data_ptr(), stream_stride, frame_stride, F, buf.data_ptr(), stride_bytes, stream)
+            n = self.batch.render(self.x.data_ptr(), self.stream_stride, self.frame_stride, self.F,
+                                  buf.data_ptr(), self.stride_bytes, self.stream)
         if ev_pair:
             ev_pair[1].record()
         return n
 
-    for i in range(args.warmup):
-        pipe.step(render_into)
-    pipe.drain()
-    if world > 1 and args.gather == "final":   # untimed: sets up RCCL's point-to-point connections
-        dist.gather(pcm[0], final_recv, dst=0)
+    def close(self):
+        self.batch.close()
+        self.x = self.x2 = self.extra = self.pcm = None
+        torch.cuda.empty_cache()
+
+    def roofline(self, kernel_ms):
+        """the dominant kernel's roofline entry from its mean launch duration (HIP events)"""
+        achieved = self.bytes_per_sf * self.sf_per_step / (kernel_ms * 1e-3) / 1e9
+        traffic = measured_traffic(self.ktag, self.sf_per_step, self.name)
+        r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(achieved / HBM_PEAK_GBS, 4),
+             "traffic": round(traffic[0]) if traffic else None,
+             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+             "traffic_source": traffic[1] if traffic else None,
+             "algorithmic_bytes_per_launch": self.bytes_per_sf * self.sf_per_step,
+             "kernel": self.ktag, "kernel_ms": round(kernel_ms, 4),
+             "algorithmic_bytes_per_sample_frame": self.bytes_per_sf,
+             "frac_of_measured_copy_6290": round(achieved / 6290.0, 4)}
+        dtype = "f32"
+        if self.kind == "fir":   # compute-bound: price against the dense MFMA peak of the type the stage multiplies in
+            flop_sf = 2 * self.in_ch * 2 * FIR_TAPS
+            tf = flop_sf * self.sf_per_step / (kernel_ms * 1e-3) / 1e12
+            f32_stage = bool(os.environ.get("IAMF_HIP_FIR_F32"))
+            peak = F32_MFMA_PEAK_TFLOPS if f32_stage else F16_MFMA_PEAK_TFLOPS
+            r.update({"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                      "frac": round(tf / peak, 4), "algorithmic_flop_per_sample_frame": flop_sf,
+                      "hbm_gbs": round(achieved, 1)})
+            if f32_stage:
+                dtype = "f32 (f32 MFMA)"
+            else:   # render_fir16.hpp: three f16 MFMAs per block of products, 288 of 256 taps multiplied
+                issued = tf * 3 * 288 / 256
+                eff_peak = peak / 3 * 256 / 288   # what the 3-MFMA split scheme can deliver as convolution flops
+                dtype = "f32 via split f16 (hi/lo halves, three f16 MFMAs, f32 accumulate)"
+                r.update({"issued_tflops": round(issued, 1), "frac_issued": round(issued / peak, 4),
+                          "effective_peak": round(eff_peak, 1), "frac_of_effective_peak": round(tf / eff_peak, 4),
+                          "note": "effective_peak = 2.5 PF / 3 MFMAs per product block x 256/288 useful taps "
+                                  "(DESIGN.md 4.2); IAMF_HIP_FIR_F32=1 runs the f32-MFMA stage"})
+        return r, dtype
+
+
+def timed_region(wl, pipe, steps, world, dist):
+    """EXACTLY `steps` launches between barrier + synchronize on both sides.
+    Returns (wall seconds on this rank, mean kernel ms from the HIP events, sample-frames emitted per stream)."""
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     emitted = 0
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        emitted += pipe.step(lambda buf, i=i: render_into(buf, ev[i]))
+    for i in range(steps):
+        emitted += pipe.step(lambda buf, i=i: wl.render_into(buf, ev[i]))
     pipe.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    return elapsed, kernel_ms, emitted
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="timed regions of --steps launches each; value is the MEDIAN region, all are listed")
+    ap.add_argument("--streams", type=int, default=512, help="streams per GPU")
+    ap.add_argument("--frames", type=int, default=64, help="frames per stream per step")
+    ap.add_argument("--frame-size", type=int, default=1024)
+    ap.add_argument("--workload", default="toa_binaural_limiter_s16", choices=sorted(WORKLOADS))
+    ap.add_argument("--signal", default="hot", choices=sorted(SIGNALS),
+                    help="hot: the limiter re-triggers in almost every 64-sample block; quiet: never; sparse: a "
+                         "quiet programme with a short peak every ~1500 samples (one or two isolated trigger runs per chunk)")
+    ap.add_argument("--gather", default="final", choices=["final", "step", "none"],
+                    help="N>1: gather packed PCM to rank 0 over RCCL once after the last step (default, the "
+                         "job's one exchange), after every step (overlapped with the next render), or never")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="N=1, default workload: do not also measure BASELINE configs 2, 3 and the HRTF form of 4")
+    ap.add_argument("--pad-kb", type=int, default=4,
+                    help="stagger the streams' input regions: stream stride = frames * channels * frame size "
+                         "+ this many KiB, so that the workgroups, which advance in step, are not all on the "
+                         "same HBM channel at once (0 = the power-of-two stride: -12 %% on the headline)")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    from iac_amd import launch
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and not launch.under_launcher():
+        # `python bench.py --gpus N` with no launcher around it: THIS process becomes the launcher.
+        # It has made no GPU call (torch is imported, nothing under torch.cuda was called, the HIP
+        # library is not loaded) and makes none: it starts N fresh rank processes, relays rank 0's
+        # line and exits non-zero if any rank failed.
+        child = os.environ.get("IAMF_BENCH_CHILD")   # test hook: a stub rank program
+        argv = ([sys.executable, child] if child else [sys.executable, os.path.abspath(__file__)]) + sys.argv[1:]
+        raise SystemExit(launch.launch_ranks(args.gpus, argv))
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to measure a different job than the one asked for"
+                         % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ranks_seen, rccl = 1, None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+        ranks_seen = dist.get_world_size()
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = "unknown"
+        # every rank must sit on its own device: gather (device index, PCI bus id) and compare
+        mine = torch.tensor([local_rank], dtype=torch.int64, device=dev)
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        devices_seen = sorted(int(t.item()) for t in seen)
+        if len(set(devices_seen)) != world:
+            raise SystemExit("ranks share a device: %s" % devices_seen)
+
+    import iac_amd as A
+    from iac_amd.sharding import GatherPipeline
+    wl = Workload(A, args.workload, args, rank, dev)
+    S, F, fs = wl.S, wl.F, wl.fs
+    pipe = GatherPipeline(wl.pcm, world, rank, enabled=world > 1 and args.gather == "step")
+    final_recv = None
+    if world > 1 and args.gather == "final" and rank == 0:
+        final_recv = [torch.empty_like(wl.pcm[0]) for _ in range(world)]
+
+    for i in range(args.warmup):
+        pipe.step(wl.render_into)
+    pipe.drain()
+    if world > 1 and args.gather == "final":   # untimed: sets up RCCL's point-to-point connections
+        dist.gather(wl.pcm[0], final_recv, dst=0)
+
+    regions = []
+    for r in range(max(1, args.repeats)):
+        elapsed, kernel_ms, emitted = timed_region(wl, pipe, args.steps, world, dist)
+        assert emitted >= args.steps * F * fs - 240, "every step must emit its F*fs sample-frames per stream"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)   # the slowest rank's time
+        regions.append((float(tmax.item()), kernel_ms))
     gather_ms = None
     if world > 1 and args.gather == "final":
         # the job's one exchange: every rank's packed PCM of the last step -> rank 0 (RCCL over xGMI).
         # It happens once per job whatever the number of steps, so it is timed on its own and
         # reported beside the K-step rate instead of being folded into it.
         tg = time.perf_counter()
-        dist.gather(pcm[(args.steps - 1) % 2], final_recv, dst=0)
+        dist.gather(wl.pcm[(args.steps * len(regions) - 1) % 2], final_recv, dst=0)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
-    assert emitted >= args.steps * F * fs - 240, "every step must emit its F*fs sample-frames per stream"
-
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+        if rank == 0:   # what arrived from rank r is rank r's PCM, not a copy of ours: ranks render different seeds
+            same = sum(int(torch.equal(final_recv[r], final_recv[0])) for r in range(1, world))
+            assert same == 0, "gather delivered identical PCM from %d other rank(s)" % same
 
     if rank == 0:
-        sf_per_step = S * F * fs                 # sample-frames one launch processes per GPU
-        total_sf = sf_per_step * args.steps * world
+        order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+        med = order[len(order) // 2]     # the median region is the one reported (upper median for even counts)
+        elapsed, kernel_ms = regions[med]
+        total_sf = wl.sf_per_step * args.steps * world
         value = total_sf / elapsed / 1e6
-        achieved = bytes_per_sf * sf_per_step / (kernel_ms * 1e-3) / 1e9
-        if kind == "h2m_in2":
-            ktag = "render_fast_kernel<%d, %d, 0, false, true" % (in_ch, out_ch)
-        elif kind == "m2m_in2":
-            ktag = "render_wide4_kernel<%d, %d, false, false, false, true" % (in_ch, out_ch)
-        elif kind == "dmx":
-            ktag = ("render_fast_kernel<%d, %d, 0, true" if out_ch <= 2 else
-                    "render_wide4_kernel<%d, %d, false, false, true") % (in_ch, out_ch)
-        elif kind == "demix":
-            ktag = "render_wide4_kernel<%d, %d, false, true" % (in_ch, out_ch)
-        elif kind == "fir":
-            ktag = "render_fast_kernel<%d, 2, 2" % in_ch
-        elif out_ch <= 2:
-            ktag = "render_fast_kernel<%d, %d, 0, false, false" % (in_ch, out_ch)
-        else:   # whole 1024-sample chunks of s16: the 4-samples-per-lane kernel (else render_wide_kernel)
-            ktag = "render_wide4_kernel<%d, %d" % (in_ch, out_ch)
-        traffic = measured_traffic(ktag, sf_per_step, args.workload)
+        roof, dtype = wl.roofline(kernel_ms)
         out = {
             "metric": "Msamples/s rendered (3rd-order HOA->binaural, 48 kHz)",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
             "x_realtime": round(value / 0.048, 1),
+            "ranks_seen": ranks_seen, "rccl_version": rccl,
+            "launched_by": os.environ.get("IAMF_LAUNCHED_BY", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
+            "repeats": {"n": len(regions), "steps_each": args.steps, "reported": "median",
+                        "ms_per_step": [round(e / args.steps * 1e3, 4) for e, _ in regions],
+                        "value_min": round(total_sf / max(e for e, _ in regions) / 1e6, 2),
+                        "value_median": round(value, 2),
+                        "value_max": round(total_sf / min(e for e, _ in regions) / 1e6, 2),
+                        "kernel_ms": [round(k, 4) for _, k in regions]},
             "config": {"workload": args.workload, "streams_per_gpu": S, "frames_per_step": F,
-                       "frame_size": fs, "sample_rate": 48000, "in_channels": in_ch,
-                       "out_channels": out_ch, "pcm": "s16", "limiter": "-1 dBFS, 240 look-ahead",
-                       "signal": {"hot": "hot (sigma 0.25 + 1.5 bursts)", "quiet": "quiet (sigma 0.05)",
-                                  "sparse": "sparse (sigma 0.05 + an 8-sample 1.5 peak every 1531 samples)"}[args.signal], "parallelism": "streams sharded, dp%d" % world,
+                       "frame_size": fs, "sample_rate": 48000, "in_channels": wl.in_ch,
+                       "out_channels": wl.out_ch, "pcm": "s16", "limiter": "-1 dBFS, 240 look-ahead",
+                       "signal": SIGNALS[args.signal], "parallelism": "streams sharded, dp%d" % world,
                        "input_stagger_kib": args.pad_kb,
                        "gather": args.gather if world > 1 else "n/a (1 GPU)"},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
-            "gather_bytes_per_rank": stride_bytes * S if world > 1 and args.gather == "final" else None,
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": round(traffic[0]) if traffic else None,
-                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
-                         "traffic_source": traffic[1] if traffic else None,
-                         "algorithmic_bytes_per_launch": bytes_per_sf * sf_per_step,
-                         "kernel": ktag, "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_sample_frame": bytes_per_sf,
-                         "frac_of_measured_copy_6290": round(achieved / 6290.0, 4)},
+            "gather_bytes_per_rank": wl.stride_bytes * S if world > 1 and args.gather == "final" else None,
+            "roofline": roof,
         }
-        if kind == "fir":   # compute-bound: price against the dense MFMA peak of the type the stage multiplies in
-            flop_sf = 2 * in_ch * 2 * FIR_TAPS
-            tf = flop_sf * sf_per_step / (kernel_ms * 1e-3) / 1e12
-            f32_stage = bool(os.environ.get("IAMF_HIP_FIR_F32"))
-            peak = F32_MFMA_PEAK_TFLOPS if f32_stage else F16_MFMA_PEAK_TFLOPS
-            out["roofline"].update({"bound": "mfma", "achieved": round(tf, 2), "peak": peak,
-                                    "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                                    "algorithmic_flop_per_sample_frame": flop_sf,
-                                    "hbm_gbs": round(achieved, 1)})
-            if f32_stage:
-                out["dtype"] = "f32 (f32 MFMA)"
-            else:   # render_fir16.hpp: three f16 MFMAs per block of products, 288 of 256 taps multiplied
-                issued = tf * 3 * 288 / 256
-                out["dtype"] = "f32 via split f16 (hi/lo halves, three f16 MFMAs, f32 accumulate)"
-                out["roofline"].update({"issued_tflops": round(issued, 1), "frac_issued": round(issued / peak, 4),
-                                        "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
-                                        "note": "bound by staging the filter tables from L2 into LDS, not by the matrix cores "
-                                                "(DESIGN.md 4.2); IAMF_HIP_FIR_F32=1 runs the f32-MFMA stage"})
+        if wl.kind == "fir":
             out["config"]["parity"] = "unpinned (HRTF arithmetic is not in the reference tree)"
+        if out["n_gpus"] != args.gpus:   # cannot happen past the check above; never print a line for another job
+            raise SystemExit("n_gpus %d != --gpus %d" % (out["n_gpus"], args.gpus))
+    headline_kind = wl.kind
+    wl.close()
+
+    if rank == 0 and world == 1 and args.workload == "toa_binaural_limiter_s16" and not args.no_extra_configs:
+        # BASELINE configs 2, 3 and the HRTF form of 4 in the same process, same harness, one region each
+        out["configs"] = {}
+        for name in EXTRA_CONFIGS:
+            w2 = Workload(A, name, args, rank, dev)
+            p2 = GatherPipeline(w2.pcm, 1, 0, enabled=False)
+            for i in range(args.warmup):
+                p2.step(w2.render_into)
+            el, kms, em = timed_region(w2, p2, args.steps, 1, dist)
+            assert em >= args.steps * F * fs - 240
+            v2 = w2.sf_per_step * args.steps / el / 1e6
+            r2, dt2 = w2.roofline(kms)
+            out["configs"][name] = {"value": round(v2, 2), "unit": "Msamples/s", "steps": args.steps,
+                                    "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": dt2,
+                                    "in_channels": w2.in_ch, "out_channels": w2.out_ch, "roofline": r2}
+            if w2.kind == "fir":
+                out["configs"][name]["parity"] = "unpinned (HRTF arithmetic is not in the reference tree)"
+            w2.close()
+
+    if rank == 0:
+        kind = headline_kind
         if not args.no_cpu_baseline:
-            wl = {"fir": "toa_binaural_limiter_s16", "demix": "714_ssJ_limiter_s16"}.get(kind, args.workload)
-            wl = wl.replace("toa_projection_", "toa_")
-            if kind == "dmx":
-                wl = "714_ssJ_limiter_s16"
+            wlname = {"fir": "toa_binaural_limiter_s16", "demix": "714_ssJ_limiter_s16"}.get(kind, args.workload)
+            wlname = wlname.replace("toa_projection_", "toa_")
+            if kind in ("dmx", "m2m_in2"):
+                wlname = "714_ssJ_limiter_s16"
             if kind == "h2m_in2":
-                wl = "toa_binaural_limiter_s16"
-            if kind == "m2m_in2":
-                wl = "714_ssJ_limiter_s16"
-            refb = reference_baseline(wl, fs)
-            port = cpu_baseline(wl, fs, seconds_target=6.0 if refb else 12.0)
+                wlname = "toa_binaural_limiter_s16"
+            refb = reference_baseline(wlname, fs)
+            port = cpu_baseline(wlname, fs, seconds_target=6.0 if refb else 12.0)
             if refb:   # the reference itself is the baseline; the oracle port is reported beside it
                 refb["oracle_port"] = {k: port[k] for k in ("value", "unit", "cores", "single_core_value")}
             out["cpu_baseline"] = refb or port
-            if kind == "fir":   # the reference's buildable binaural path is the 16->2 matrix, not an HRTF
-                out["cpu_baseline"]["sample"] += " [the matrix binaural path: the reference has no buildable HRTF]"
-            if kind == "demix":
-                out["cpu_baseline"]["sample"] += " [the single-layer 7.1.4 stream: without the demixer stage]"
-            if kind == "dmx":
-                out["cpu_baseline"]["sample"] += " [the 7.1.4 -> J matrix stream: the reference's down-mixer needs a demixing-parameter stream]"
-            if kind in ("h2m_in2", "m2m_in2"):
-                out["cpu_baseline"]["sample"] += " [the one-element stream: without the stereo element]"
-            if kind == "h2m_proj":
-                out["cpu_baseline"]["sample"] += " [the mono-mode stream: without the de-mapping stage]"
-        print(json.dumps(out))
+            notes = {"fir": " [the matrix binaural path: the reference has no buildable HRTF]",
+                     "demix": " [the single-layer 7.1.4 stream: without the demixer stage]",
+                     "dmx": " [the 7.1.4 -> J matrix stream: the reference's down-mixer needs a demixing-parameter stream]",
+                     "h2m_in2": " [the one-element stream: without the stereo element]",
+                     "m2m_in2": " [the one-element stream: without the stereo element]",
+                     "h2m_proj": " [the mono-mode stream: without the de-mapping stage]"}
+            out["cpu_baseline"]["sample"] += notes.get(kind, "")
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    batch.close()
 
 
 if __name__ == "__main__":
