@@ -26,6 +26,7 @@
 #define MAX_SUBSTREAMS 24
 #define MAX_SEGMENTS 16
 #define MAX_PARAMS 16
+#define MAX_FRAME_SIZE (1u << 20) /* samples; LPCM frames of real streams are <= 8192 */
 
 /* ---- byte reader: every field the path needs is byte aligned or the leading bits of a byte ---- */
 typedef struct {
@@ -233,6 +234,8 @@ struct IAMF_Decoder {
   hipStream_t stream;
   int flushed;
   uint32_t last_frame;
+  int started;      /* a configure call with data has been made: status left INIT */
+  int need_reconf;  /* a new IA sequence header was met while decoding: status RECONFIGURE */
 };
 
 /* ---- small tables ---- */
@@ -399,16 +402,19 @@ static Param *param_get(struct IAMF_Decoder *d, const ParamDef *def, int type) {
 static int parse_codec_config(struct IAMF_Decoder *d, const Obu *o) { /* IAMF_OBU.c:303-343 */
   Rd r = {o->payload, o->payload_size, 0, 0};
   char cc[4];
+  uint64_t fs64;
   rd_leb128(&r);
   for (int i = 0; i < 4; ++i) cc[i] = (char)rd_u8(&r);
-  d->frame_size = (uint32_t)rd_leb128(&r);
+  fs64 = rd_leb128(&r);
+  d->frame_size = fs64 > MAX_FRAME_SIZE ? 0 : (uint32_t)fs64;
   rd_u16(&r); /* roll distance */
   if (memcmp(cc, "ipcm", 4)) return IAMF_ERR_UNIMPLEMENTED; /* Opus / AAC / FLAC: upstream of this path */
   d->little_endian = rd_u8(&r) & 1; /* pcm/IAMF_pcm_decoder.c:60-62 */
   d->sample_size = rd_u8(&r);
   d->rate = rd_u32(&r);
-  if (r.err || !d->frame_size || (d->sample_size != 16 && d->sample_size != 24 && d->sample_size != 32))
+  if (r.err || !fs64 || (d->sample_size != 16 && d->sample_size != 24 && d->sample_size != 32))
     return IAMF_ERR_INVALID_PACKET;
+  if (fs64 > MAX_FRAME_SIZE) return IAMF_ERR_UNIMPLEMENTED; /* every per-frame buffer is sized from it */
   d->have_codec = 1;
   return IAMF_OK;
 }
@@ -421,8 +427,14 @@ static int parse_element(struct IAMF_Decoder *d, const Obu *o) { /* IAMF_OBU.c:3
   e.id = rd_leb128(&r);
   e.type = rd_u8(&r) >> 5;
   rd_leb128(&r); /* codec config id */
-  e.nsub = (int)rd_leb128(&r);
-  if (e.nsub > MAX_SUBSTREAMS) return IAMF_ERR_UNIMPLEMENTED;
+  {
+    /* untrusted: compare as uint64 before narrowing; an element without sub-streams would make every
+     * temporal unit "complete" and leave the unpacker without a sample count */
+    const uint64_t nsub = rd_leb128(&r);
+    if (r.err || nsub < 1) return IAMF_ERR_INVALID_PACKET;
+    if (nsub > MAX_SUBSTREAMS) return IAMF_ERR_UNIMPLEMENTED;
+    e.nsub = (int)nsub;
+  }
   for (int i = 0; i < e.nsub; ++i) e.sub_ids[i] = rd_leb128(&r);
   np = rd_leb128(&r);
   for (uint64_t i = 0; i < np; ++i) {
@@ -466,6 +478,7 @@ static int parse_element(struct IAMF_Decoder *d, const Obu *o) { /* IAMF_OBU.c:3
         l->gain_q = (int16_t)rd_u16(&r);
       }
       if (l->layout > IA_CHANNEL_LAYOUT_312) return IAMF_ERR_UNIMPLEMENTED;
+      if (l->nsub < 1 || l->ncoupled > l->nsub) return IAMF_ERR_INVALID_PACKET;
       subs += l->nsub;
     }
     if (subs != e.nsub) return IAMF_ERR_INVALID_PACKET;
@@ -478,7 +491,7 @@ static int parse_element(struct IAMF_Decoder *d, const Obu *o) { /* IAMF_OBU.c:3
     uint64_t mode = rd_leb128(&r);
     if (mode == AMBISONICS_MONO) {
       e.amb_channels = rd_u8(&r);
-      rd_u8(&r);
+      if (rd_u8(&r) != e.nsub) return IAMF_ERR_INVALID_PACKET; /* substream_count of the mono mapping */
       if (e.amb_channels > MAX_SUBSTREAMS) return IAMF_ERR_INVALID_PACKET;
       for (int i = 0; i < e.amb_channels; ++i) e.amb_map[i] = rd_u8(&r);
     } else if (mode == AMBISONICS_PROJECTION) { /* IAMF_OBU.c:562-583, IAMF_core_decoder.c:228-252 */
@@ -488,7 +501,8 @@ static int parse_element(struct IAMF_Decoder *d, const Obu *o) { /* IAMF_OBU.c:3
       subs = rd_u8(&r);
       e.amb_coupled = rd_u8(&r);
       l_in = subs + e.amb_coupled;
-      if (e.amb_channels > 16 || l_in > MAX_SUBSTREAMS * 2 || subs != e.nsub) return IAMF_ERR_INVALID_PACKET;
+      if (e.amb_channels > 16 || l_in > MAX_SUBSTREAMS * 2 || subs != e.nsub || e.amb_coupled > subs)
+        return IAMF_ERR_INVALID_PACKET;
       for (int i = 0; i < l_in * e.amb_channels; ++i) e.proj[i] = q_to_float((int16_t)rd_u16(&r), 15);
     } else {
       return IAMF_ERR_UNIMPLEMENTED;
@@ -776,6 +790,7 @@ IAMF_DecoderHandle IAMF_decoder_open(void) { /* IAMF_decoder.c:3726-3744 */
   d->mix_id = -1;
   d->out_type = IAMF_LAYOUT_TYPE_NOT_DEFINED;
   d->pts_base = 90000;
+  d->out_rate = 48000; /* OUTPUT_SAMPLERATE, IAMF_decoder.c:56,3734: other stream rates are resampled to it */
   return d;
 }
 
@@ -814,6 +829,33 @@ static void free_runtime(struct IAMF_Decoder *d) {
   if (d->stream) (void)hipStreamDestroy(d->stream);
   d->stream = 0;
   d->configured = 0;
+}
+
+/* iamf_database_reset + iamf_database_init (IAMF_decoder.c:1182-1196, 3801-3806): everything parsed
+ * from the previous IA sequence goes — descriptors, the parameter timelines with their queues and
+ * timestamps, the per-element runtime derived from them; the user's settings stay */
+static void reset_descriptors(struct IAMF_Decoder *d) {
+  free_runtime(d);
+  for (int i = 0; i < d->nparam; ++i) free(d->param[i].rq);
+  memset(d->param, 0, sizeof(d->param));
+  memset(d->el, 0, sizeof(d->el));
+  memset(d->pr, 0, sizeof(d->pr));
+  d->nel = d->npr = d->nparam = 0;
+  d->have_header = d->have_codec = 0;
+  d->frame_size = d->sample_size = d->rate = 0;
+  d->sel = 0;
+  d->sel_el[0] = d->sel_el[1] = 0;
+  d->el_gain_p[0] = d->el_gain_p[1] = d->out_gain_p = d->demix_p = 0;
+  d->use_dmx = d->use_demix = 0;
+  d->dmx_mode = -1;
+  d->rec_flags = 0;
+  d->rec_n = 0;
+  memset(d->layer_rec_flags, 0, sizeof(d->layer_rec_flags));
+  memset(d->layer_rec_gain, 0, sizeof(d->layer_rec_gain));
+  d->tu_trim_start = d->tu_trim_end = 0;
+  d->timestamp = 0;
+  d->last_frame = 0;
+  d->need_reconf = 0;
 }
 
 int IAMF_decoder_close(IAMF_DecoderHandle d) {
@@ -895,7 +937,6 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   }
   d->out_gain_p = param_get(d, &p->out_gain_def, IAMF_PARAMETER_TYPE_MIX_GAIN);
   d->out_channels = d->out_type == IAMF_LAYOUT_TYPE_BINAURAL ? 2 : k_ss_channels[d->out_ss];
-  if (!d->out_rate) d->out_rate = d->rate;
   resample = d->out_rate != d->rate; /* IAMF_decoder.c:3193-3199 */
   d->info.max_frame_size = d->frame_size <= 1024 ? 6144 : 6 * d->frame_size; /* :1628-1630 */
 
@@ -1065,6 +1106,12 @@ int IAMF_decoder_configure(IAMF_DecoderHandle d, const uint8_t *data, uint32_t s
   int saw_data = 0, rc;
   if (!d) return IAMF_ERR_BAD_ARG;
   if (rsize) *rsize = 0;
+  if (data && size > 0) {
+    /* status RECEIVE (a configuration completed) or RECONFIGURE (decode met a new sequence header) ->
+     * the database is reset before the new descriptors are read (IAMF_decoder.c:3796-3806) */
+    if (d->configured || d->need_reconf) reset_descriptors(d);
+    d->started = 1;
+  }
   while (data && pos < size) { /* iamf_decoder_internal_read_descriptors_OBUs, IAMF_decoder.c:2784-2831 */
     Obu o;
     uint32_t n = obu_split(data + pos, size - pos, &o);
@@ -1136,6 +1183,7 @@ static int unpack_element(struct IAMF_Decoder *d, int ei) {
       for (int k = 0; k < w; ++k) tmp[(size_t)(c + k) * fs + i] = lpcm_sample(d, d->pkt[ei][s] + (size_t)(i * w + k) * bps);
     c += w;
   }
+  if (ns < 0) return IAMF_ERR_INVALID_PACKET; /* no sub-stream at all: nothing fixed the sample count */
   if (e->amb_projection || demix) { /* decoded channel order goes to the device: de-mapping / demixer run there */
     for (int l = 0; l < c; ++l) memcpy(dst + (size_t)l * fs, tmp + (size_t)l * fs, sizeof(float) * ns);
     return ns;
@@ -1171,10 +1219,18 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
   }
   /* iamf_frame_trim (IAMF_decoder.c:1361-1381): rendering is memoryless, so trimming the
    * element PCM before the renderer equals trimming the rendered frame */
-  s0 = (int)d->tu_trim_start;
-  keep = ns - s0 - (int)d->tu_trim_end;
   for (int e = 0; e < d->sel->nel; ++e)
     for (int s = 0; s < d->sel_el[e]->nsub; ++s) d->pkt_have[e][s] = 0;
+  /* the trims are LEB128 fields of the OBU header: compared as uint64 BEFORE narrowing.  The reference
+   * refuses start < 0 || end < 0 || samples - start - end < 0 with IAMF_ERR_BAD_ARG and moves the
+   * stream time on (iamf_frame_trim :1364-1370, :3424-3428) */
+  if (d->tu_trim_start > (uint64_t)ns || d->tu_trim_end > (uint64_t)ns ||
+      d->tu_trim_start + d->tu_trim_end > (uint64_t)ns) {
+    d->timestamp += fs;
+    return IAMF_ERR_BAD_ARG;
+  }
+  s0 = (int)d->tu_trim_start;
+  keep = ns - s0 - (int)d->tu_trim_end;
   if (keep <= 0) {
     d->timestamp += fs;
     return 0;
@@ -1304,7 +1360,7 @@ int IAMF_decoder_decode(IAMF_DecoderHandle d, const uint8_t *data, int32_t size,
   uint32_t pos = 0;
   if (!d || !pcm) return IAMF_ERR_BAD_ARG;
   if (rsize) *rsize = 0;
-  if (!d->configured) return IAMF_ERR_INVALID_STATE;
+  if (!d->configured || d->need_reconf) return IAMF_ERR_INVALID_STATE; /* status != RECEIVE, :3941-3942 */
   if (!data || size <= 0) return flush_tail(d, pcm); /* IAMF_decoder.c:3508-3519 */
   while (pos < (uint32_t)size) { /* iamf_decoder_internal_parse_OBUs, IAMF_decoder.c:2871-2995 */
     Obu o;
@@ -1313,6 +1369,7 @@ int IAMF_decoder_decode(IAMF_DecoderHandle d, const uint8_t *data, int32_t size,
     pos += n;
     if (o.type == 31 && !o.redundant) { /* a new IA sequence: the caller must reconfigure (:2918-2921) */
       if (rsize) *rsize = pos - n;
+      d->need_reconf = 1;
       return IAMF_ERR_INVALID_STATE;
     }
     if (o.type == 3) {
@@ -1397,7 +1454,8 @@ int IAMF_decoder_peak_limiter_set_threshold(IAMF_DecoderHandle d, float db) {
 float IAMF_decoder_peak_limiter_get_threshold(IAMF_DecoderHandle d) { return d ? d->limiter_db : 0.f; }
 int IAMF_decoder_set_sampling_rate(IAMF_DecoderHandle d, uint32_t rate) { /* IAMF_decoder.c:4112-4130 */
   static const uint32_t ok[] = {8000, 12000, 16000, 24000, 32000, 44100, 48000};
-  if (!d || d->configured) return IAMF_ERR_BAD_ARG;
+  if (!d) return IAMF_ERR_BAD_ARG;
+  if (d->started) return IAMF_ERR_INVALID_STATE; /* only before the first configure call (status INIT, :4117-4120) */
   for (unsigned i = 0; i < sizeof(ok) / sizeof(ok[0]); ++i)
     if (ok[i] == rate) {
       d->out_rate = rate;

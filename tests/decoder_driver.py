@@ -50,6 +50,15 @@ def decode_stream(ref, stream_bytes, layout, bit_depth=16, out_rate=0, loudness=
         rsize.value = 0
         rest = stream_bytes[used:]
         n = ref.IAMF_decoder_decode(d, rest, len(rest), C.byref(rsize), pcm)
+        if n == -5:   # IAMF_ERR_INVALID_STATE: a new IA sequence starts here -> configure again (iamfplayer.c:569-588,622-625)
+            used += rsize.value
+            rest = stream_bytes[used:]
+            rsize.value = 0
+            r = ref.IAMF_decoder_configure(d, rest, len(rest), C.byref(rsize))
+            assert r == 0, "reconfigure failed: %d" % r
+            used += rsize.value
+            rets.append(-5)
+            continue
         assert n >= 0, "decode failed: %d" % n
         if n > 0:
             chunks.append(pcm.raw[:n * ch * bps])

@@ -78,6 +78,11 @@ CASES = {
     # scalable channel audio (N2): stereo -> 5.1.2 -> 7.1.4 with output gains on the first two layers,
     # recon-gain and demixing parameter blocks; the output layout selects the layer that is decoded
     # (IAMF_decoder.c:1776-1822), the demixer rebuilds the rest (demixer.c)
+    # a reconfiguration must start from a clean database.  Three IA sequences in one file; the
+    # first and third carry mix-gain parameter blocks on the SAME parameter ids (stale queues / timestamps
+    # would shift or refuse the third one's ramps), the middle one has another frame count and trims
+    "l714_A_ramps": dict(layout=_ss_layout("A"), bit_depth=16, frames=7, fs=1024, seed=57, ramps=True),
+    "three_sequences_A_s16": dict(layout=_ss_layout("A"), bit_depth=16, concat=["l714_A_ramps", "stereo_trim", "l714_A_ramps"]),
     "scalable_J_s16": dict(layout=_ss_layout("J"), bit_depth=16, frames=8, fs=1024, seed=56, scalable=True),
     "scalable_C_s16": dict(layout=_ss_layout("C"), bit_depth=16, frames=8, fs=1024, seed=56, scalable=True),
     "scalable_A_s16": dict(layout=_ss_layout("A"), bit_depth=16, frames=8, fs=1024, seed=56, scalable=True),
@@ -118,6 +123,9 @@ def _toa_element(eid, x, first_sid, sample_size):
 
 def build(name):
     c = CASES[name]
+    if c.get("concat"):   # several IA sequences back to back: the decoder must be reconfigured at each header
+        parts = [build(p) for p in c["concat"]]
+        return b"".join(p[0] for p in parts), dict(case=c, elements=[], parts=[p[1] for p in parts])
     fs, F = c["fs"], c["frames"]
     n = fs * F
     ss = c.get("sample_size", 16)
@@ -144,7 +152,7 @@ def build(name):
             stream += W.temporal_delimiter()
             stream += W.audio_frames(W.channel_element_substreams(1, x_al[:, f * fs:(f + 1) * fs], 0, ss),
                                      trim=c.get("trims", {}).get(f))
-    elif name == "l714_J_ramps":
+    elif name in ("l714_J_ramps", "l714_A_ramps"):
         x = np.clip(synth.hot(c["seed"], 12, n, sigma=0.2, burst_amp=0.6, burst_phase=500, burst_period=3000),
                     -1, 1 - 2 ** -15).astype(np.float32)
         desc, x_al, xq = _channel_element(1, 7, x, 0, ss)

@@ -1,0 +1,139 @@
+/*
+ * TEST INFRASTRUCTURE — not a CPU path of the product.
+ *
+ * Stand-ins for the HIP runtime and for the batch ABI (include/iamf_hip.h), so that the plain-C host
+ * side of the decoder facade (OBU parser, LPCM unpack, parameter timeline, call protocol) can be
+ * compiled with gcc -fsanitize=address,undefined and fed malformed bitstreams on a machine without a
+ * GPU (tests/test_facade_malformed.py).  Nothing here renders: "device" memory is malloc, copies
+ * are memcpy (so ASan sees every host-side length), a render call reports the samples it was
+ * asked for and writes zeros.  It is never linked into libiamf_hip.so.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include "iamf_hip.h"
+
+hipError_t hipMalloc(void **p, size_t n) { return (*p = calloc(1, n ? n : 1)) ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned f) { (void)f; return hipMalloc(p, n); }
+hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t st) {
+  (void)k; (void)st; memcpy(d, s, n); return hipSuccess;
+}
+hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st) { (void)st; memset(d, v, n); return hipSuccess; }
+hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)calloc(1, 8); return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) { (void)s; return hipSuccess; }
+
+struct iamf_hip_batch { iamf_hip_batch_config cfg; int pad_left; };
+struct iamf_hip_resampler { int ch, in, out; };
+
+static const int k_ch[] = {2, 6, 8, 10, 11, 12, 14, 24, 8, 12};
+int iamf_hip_layout_channels(int id) {
+  switch (id) {
+    case IAMF_HIP_SS_A: case IAMF_HIP_L_STEREO: case IAMF_HIP_L_BINAURAL: return 2;
+    case IAMF_HIP_L_MONO: return 1;
+    case IAMF_HIP_SS_B: case IAMF_HIP_L_51: case IAMF_HIP_L_312: return 6;
+    case IAMF_HIP_SS_C: case IAMF_HIP_L_512: case IAMF_HIP_L_71: case IAMF_HIP_SS_I: return 8;
+    case IAMF_HIP_SS_D: case IAMF_HIP_L_514: case IAMF_HIP_L_712: return 10;
+    case IAMF_HIP_SS_E: return 11;
+    case IAMF_HIP_SS_F: case IAMF_HIP_SS_J: case IAMF_HIP_L_714: return 12;
+    case IAMF_HIP_SS_G: return 14;
+    case IAMF_HIP_SS_H: return 24;
+  }
+  (void)k_ch;
+  return 0;
+}
+static float g_zero[24 * 24];
+static int fill_matrix(int kind, int m, int out_id, iamf_hip_matrix *mx) {
+  memset(mx, 0, sizeof(*mx));
+  mx->kind = kind; mx->out_id = out_id; mx->channels = iamf_hip_layout_channels(out_id);
+  mx->lfe1 = mx->lfe2 = -1; mx->m = m; mx->n = mx->channels; mx->mat = g_zero;
+  return mx->channels ? 0 : IAMF_HIP_ERR_BAD_ARG;
+}
+int iamf_hip_get_h2m_matrix(int order, int out_id, iamf_hip_matrix *mx) {
+  return fill_matrix(IAMF_HIP_KIND_H2M, (order + 1) * (order + 1), out_id, mx);
+}
+int iamf_hip_get_m2m_matrix(int in_id, int out_id, iamf_hip_matrix *mx) {
+  return fill_matrix(IAMF_HIP_KIND_M2M, iamf_hip_layout_channels(in_id), out_id, mx);
+}
+int iamf_hip_format_bytes(int f) { return f == 16 ? 2 : f == 24 ? 3 : (f == 32 || f == -32) ? 4 : 0; }
+
+int iamf_hip_batch_create(const iamf_hip_batch_config *c, iamf_hip_batch **out) {
+  if (c->frame_size <= 0 || c->out_channels <= 0 || c->out_channels > 24) return IAMF_HIP_ERR_BAD_ARG;
+  *out = (iamf_hip_batch *)calloc(1, sizeof(**out));
+  (*out)->cfg = *c;
+  (*out)->pad_left = c->limiter_enable ? 240 : 0;
+  return 0;
+}
+void iamf_hip_batch_destroy(iamf_hip_batch *b) { free(b); }
+int iamf_hip_batch_set_gains(iamf_hip_batch *b, const float *a, const float *c, const float *d) {
+  (void)b; (void)a; (void)c; (void)d; return 0;
+}
+int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *m, const float *g) {
+  (void)b; (void)m; (void)g; return 0;
+}
+int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *p, int l) { (void)b; (void)p; (void)l; return 0; }
+int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *c) { (void)b; (void)c; return 0; }
+static int emit(iamf_hip_batch *b, void *pcm, int64_t cap, int n) {
+  int skip = n < b->pad_left ? n : b->pad_left;
+  b->pad_left -= skip;
+  n -= skip;
+  int64_t need = (int64_t)n * b->cfg.out_channels * iamf_hip_format_bytes(b->cfg.out_format);
+  if (need > cap) return IAMF_HIP_ERR_BAD_ARG;
+  memset(pcm, 0, (size_t)need); /* a real write: ASan checks the "device" buffer the facade sized */
+  return n;
+}
+int iamf_hip_batch_render(iamf_hip_batch *b, const float *in, int64_t ss, int64_t fs, int32_t nf, void *pcm,
+                          int64_t cap, void *st) {
+  (void)in; (void)ss; (void)fs; (void)st;
+  return emit(b, pcm, cap, nf * b->cfg.frame_size);
+}
+int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *a) {
+  int n = a->n_samples ? a->n_samples : a->n_frames * b->cfg.frame_size;
+  const volatile float *in = (const volatile float *)a->d_in; /* touch what a kernel would read */
+  float acc = 0;
+  for (int64_t i = 0; i < (int64_t)b->cfg.matrix.m * b->cfg.frame_size && b->cfg.matrix.kind != IAMF_HIP_KIND_DMX; ++i) acc += in[i];
+  (void)acc;
+  return emit(b, a->d_pcm, a->pcm_stream_stride_bytes, n);
+}
+int iamf_hip_batch_flush(iamf_hip_batch *b, void *pcm, int64_t cap, void *st) {
+  (void)st;
+  int n = b->cfg.limiter_enable ? 240 - b->pad_left : 0;
+  b->pad_left = 0;
+  return emit(b, pcm, cap, n);
+}
+int iamf_hip_resampler_create(int ns, int ch, int in, int out, iamf_hip_resampler **r) {
+  (void)ns;
+  *r = (iamf_hip_resampler *)calloc(1, sizeof(**r));
+  (*r)->ch = ch; (*r)->in = in; (*r)->out = out;
+  return 0;
+}
+void iamf_hip_resampler_destroy(iamf_hip_resampler *r) { free(r); }
+int iamf_hip_resampler_out_capacity(const iamf_hip_resampler *r, int n) { return (int)((int64_t)n * r->out / r->in) + 2; }
+int iamf_hip_resampler_flush_capacity(const iamf_hip_resampler *r) { (void)r; return 64; }
+int iamf_hip_resampler_process(iamf_hip_resampler *r, const float *in, int64_t iss, int n, float *out, int64_t oss, void *st) {
+  (void)in; (void)iss; (void)st;
+  int m = (int)((int64_t)n * r->out / r->in);
+  if ((int64_t)m * r->ch > oss) return IAMF_HIP_ERR_BAD_ARG;
+  memset(out, 0, sizeof(float) * (size_t)m * r->ch);
+  return m;
+}
+int iamf_hip_resampler_flush(iamf_hip_resampler *r, float *out, int64_t oss, void *st) {
+  (void)r; (void)out; (void)oss; (void)st; return 0;
+}
+void iamf_hip_dmx_state_init(iamf_hip_dmx_state *s) { memset(s, 0, sizeof(*s)); }
+int iamf_hip_dmx_set_mode_weight(iamf_hip_dmx_state *s, int mode, int w) { (void)w; s->mode = mode; return 0; }
+void iamf_hip_dmx_coefficients(const iamf_hip_dmx_state *s, float *c) { (void)s; memset(c, 0, 5 * sizeof(float)); }
+int iamf_hip_dmx_valid(int in, int out) { return in > out && in >= 0 && out >= 0 && in < 9 && out < 9; }
+void iamf_hip_demix_state_init(iamf_hip_demix_state *s) { memset(s, 0, sizeof(*s)); }
+int iamf_hip_demix_set_info(iamf_hip_demix_state *s, int mode, int w) { (void)w; s->mode = mode; return 0; }
+void iamf_hip_demix_frame_fill(iamf_hip_demix_state *s, int n, const int32_t *ch, const float *g, iamf_hip_demix_frame *f) {
+  (void)s; memset(f, 0, sizeof(*f));
+  f->n_recon = n;
+  for (int i = 0; i < n && i < 12; ++i) { f->recon_ch[i] = ch[i]; f->recon_cur[i] = g[i]; }
+}
