@@ -527,6 +527,13 @@ int orc_stream_open(orc_stream *s, const orc_matrix *mx, int out_channels, float
   return 0;
 }
 
+/* IAMF_decoder.c:2630-2633: only if the output layout has an LFE; lfefilter_init(plfe, 120, rate) */
+void orc_stream_enable_lfe(orc_stream *s, int rate) {
+  if (s->mx.kind != 0 || (s->mx.lfe1 < 0 && s->mx.lfe2 < 0)) return;
+  s->lfe_on = 1;
+  orc_lfe_init(&s->lfe, 120, (float)rate);
+}
+
 void orc_stream_close(orc_stream *s) {
   free(s->buf_a);
   free(s->buf_b);
@@ -543,7 +550,7 @@ int orc_stream_frame(orc_stream *s, const float *in, int ns, void *pcm) {
   int n = ns;
   memset(s->buf_a, 0, sizeof(float) * (size_t)ch * ns);
   if (s->mx.kind == 0)
-    orc_render_h2m(&s->mx, in, s->buf_a, ns);
+    orc_render_h2m_lfe(&s->mx, in, s->buf_a, ns, s->lfe_on ? &s->lfe : 0);
   else
     orc_render_m2m(&s->mx, in, s->buf_a, ns);
   orc_frame_gain_const(s->buf_a, ch, ns, s->element_gain);

@@ -49,6 +49,18 @@ void orc_render_h2m(const orc_matrix *mx, const float *in, float *out, int ns);
 /* reference src/iamf_dec/m2m_rdr.c:1820-1840 */
 void orc_render_m2m(const orc_matrix *mx, const float *in, float *out, int ns);
 
+/* ---- HOA LFE generator (iamf_oracle_lfe.c) ---- reference h2m_rdr.c:1151-1239, compiled in only
+ * with the reference's switch -DDISABLE_LFE_HOA=0; struct = lfe_filter_t, ae_rdr.h:92-96 */
+typedef struct {
+  int init;
+  float c, a1, a2, a3, b1, b2;
+  float ih[2], oh[2];
+} orc_lfe;
+void orc_lfe_init(orc_lfe *f, float cutoff_freq, float sample_rate);
+float orc_lfe_update(orc_lfe *f, float input);
+void orc_render_h2m_lfe(const orc_matrix *mx, const float *in, float *out, int ns, orc_lfe *lfe);
+int orc_sizeof_lfe(void);
+
 /* ---- gains, mixer, loudness ---- */
 /* reference src/iamf_dec/IAMF_decoder.c:1392-1397 (constant) and :1401-1405 (per-sample) */
 void orc_frame_gain_const(float *data, int channels, int ns, float gain);
@@ -128,7 +140,11 @@ typedef struct {
   orc_limiter lim;
   float *buf_a, *buf_b; /* scratch [ORC_MAX_CH][max_ns] */
   int max_ns;
+  int lfe_on;          /* HOA LFE generator (IAMF_decoder.c:2625-2633): set with orc_stream_enable_lfe */
+  orc_lfe lfe;
 } orc_stream;
+/* after orc_stream_open: h2m element into a layout with an LFE slot, reference built -DDISABLE_LFE_HOA=0 */
+void orc_stream_enable_lfe(orc_stream *s, int rate);
 
 int orc_stream_open(orc_stream *s, const orc_matrix *mx, int out_channels, float element_gain,
                     float output_gain, int loudness_on, float loudness_gain, int limiter_on,

@@ -1,0 +1,77 @@
+"""Cases of the HOA LFE generator (reference h2m_rdr.c:1151-1239, enabled by the
+reference's own build switch -DDISABLE_LFE_HOA=0): stage level (render_H2M with a filter carried over
+several calls) and end to end (synthetic LPCM .iamf streams through IAMF_decoder_*).  Shared by
+oracle/gen_golden_lfe.py (which asks the real reference) and the tests (oracle, HIP path)."""
+import numpy as np
+
+import iamf_writer as W
+import synth
+
+SS = dict(A=0x020, B=0x050, C=0x250, D=0x450, E=0x451, F=0x370, G=0x490, H=0x9A3, I=0x070,
+          J=0x470, L312=0x312, L712=0x712)
+SS_ENUM = dict(A=0, B=1, C=2, D=3, E=4, F=5, G=6, H=7, I=8, J=9, L712=10, L312=11)   # IAMF_SoundSystem
+
+# name: (ambisonics order, output rendering id, sample rate of lfefilter_init, call sizes, seed)
+STAGE = {
+    "toa_B": (3, SS["B"], 48000, [320, 64, 1024, 7], 101),
+    "toa_J": (3, SS["J"], 48000, [1024, 1024], 102),
+    "toa_F_two_lfe": (3, SS["F"], 48000, [512, 33, 479], 103),
+    "toa_H": (3, SS["H"], 48000, [256, 256], 104),
+    "toa_G": (3, SS["G"], 48000, [300], 105),
+    "toa_E": (3, SS["E"], 48000, [300], 106),
+    "toa_D": (3, SS["D"], 48000, [128, 128], 107),
+    "soa_312": (2, SS["L312"], 48000, [400], 108),
+    "foa_B": (1, SS["B"], 48000, [640, 640], 109),
+    "zoa_C": (0, SS["C"], 48000, [1000], 110),
+    "toa_B_44k1": (3, SS["B"], 44100, [441, 1024], 111),
+    "toa_I_16k": (3, SS["I"], 16000, [960], 112),
+    "toa_A_no_lfe_slot": (3, SS["A"], 48000, [200], 113),
+}
+
+
+def programme(seed, channels, ns, rate=48000, silence_from=None):
+    """Gaussian noise on every channel plus low-frequency content on W (a 50 Hz and a 90 Hz tone, a slow
+    sweep) so that the 120 Hz low-pass has something to pass; optional digital silence from a sample on
+    (the filter then decays through the denormal range)."""
+    x = synth.gaussian(seed, channels, ns, 0.12)
+    t = np.arange(ns, dtype=np.float64) / rate
+    lf = 0.35 * np.sin(2 * np.pi * 50.0 * t) + 0.2 * np.sin(2 * np.pi * 90.0 * t + 0.3) \
+        + 0.15 * np.sin(2 * np.pi * (20.0 + 200.0 * t) * t)
+    x[0] = (x[0] + lf.astype(np.float32)).astype(np.float32)
+    if silence_from is not None:
+        x[:, silence_from:] = 0.0
+    return np.clip(x, -1.0, 1.0 - 2.0 ** -15).astype(np.float32)
+
+
+def stage_input(name):
+    order, _, rate, sizes, seed = STAGE[name]
+    return programme(seed, (order + 1) ** 2, sum(sizes), rate)
+
+
+# end to end: name -> dict(order, layout (IAMF_SoundSystem name), bit_depth, frames, fs, seed, rate, silence_from)
+E2E = {
+    "toa_B_s16": dict(order=3, ss="B", bit_depth=16, frames=6, fs=1024, seed=201),
+    "toa_J_s24": dict(order=3, ss="J", bit_depth=24, frames=4, fs=1024, seed=202),
+    "foa_F_s16": dict(order=1, ss="F", bit_depth=16, frames=5, fs=960, seed=203),
+    "toa_H_s16": dict(order=3, ss="H", bit_depth=16, frames=3, fs=1024, seed=204),
+    "soa_C_441_to_48k": dict(order=2, ss="C", bit_depth=16, frames=5, fs=1024, seed=205, rate=44100),
+    "toa_B_decay_s32": dict(order=3, ss="B", bit_depth=32, frames=14, fs=1024, seed=206, silence_from=2500),
+    "toa_A_s16": dict(order=3, ss="A", bit_depth=16, frames=3, fs=1024, seed=207),   # no LFE slot: unchanged path
+}
+
+
+def build(name):
+    c = E2E[name]
+    fs, F, rate = c["fs"], c["frames"], c.get("rate", 48000)
+    m = (c["order"] + 1) ** 2
+    x = programme(c["seed"], m, fs * F, rate, c.get("silence_from"))
+    xq = W.quantize(x, 16)
+    pd = lambda pid: W.param_definition(pid, rate, mode=1)
+    s = W.sequence_header(1) + W.codec_config_lpcm(0, fs, 16, rate)
+    s += W.audio_element_ambisonics_mono(1, 0, m, list(range(m)))
+    s += W.mix_presentation(1, [dict(eid=1, pdef=pd(100), default_q78=0)], dict(pdef=pd(101), default_q78=0),
+                            [("ss", SS_ENUM[c["ss"]])])
+    for f in range(F):
+        s += W.temporal_delimiter()
+        s += W.audio_frames([(i, W.lpcm_bytes(xq[i:i + 1, f * fs:(f + 1) * fs], 16)) for i in range(m)])
+    return s, xq

@@ -67,6 +67,9 @@ def lib():
         L.orc_stream_open.argtypes = [C.c_void_p, C.POINTER(Matrix), C.c_int, C.c_float, C.c_float,
                                       C.c_int, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
         L.orc_stream_close.argtypes = [C.c_void_p]
+        L.orc_stream_enable_lfe.argtypes = [C.c_void_p, C.c_int]
+        L.orc_lfe_init.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        L.orc_render_h2m_lfe.argtypes = [C.POINTER(Matrix), FP, FP, C.c_int, C.c_void_p]
         L.orc_stream_frame.argtypes = [C.c_void_p, FP, C.c_int, C.c_void_p]
         L.orc_stream_flush.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_stream_run_frames.restype = C.c_long
@@ -112,6 +115,21 @@ def render(mx, x, out_channels, prefill=0.0):
     return out[:out_channels].copy()
 
 
+
+
+def render_h2m_lfe(mx, x, out_channels, rate, sizes):
+    """orc_render_h2m_lfe over consecutive calls with one filter (state carried): [out_channels][total]"""
+    L = lib()
+    f = C.create_string_buffer(L.orc_sizeof_lfe())
+    L.orc_lfe_init(f, 120.0, float(rate))
+    parts, pos = [], 0
+    for ns in sizes:
+        xi = np.ascontiguousarray(x[:, pos:pos + ns], dtype=np.float32)
+        o = np.zeros((max(out_channels, mx.n + 2), ns), dtype=np.float32)
+        L.orc_render_h2m_lfe(C.byref(mx), fp(xi), fp(o), ns, f)
+        parts.append(o[:out_channels].copy())
+        pos += ns
+    return np.concatenate(parts, axis=1)
 
 
 class Limiter:
@@ -204,7 +222,8 @@ class Stream:
     """orc_stream: render -> gains -> mix -> loudness -> limiter -> pack for one stream."""
 
     def __init__(self, mx, out_channels, element_gain=1.0, output_gain=1.0, loudness_on=0,
-                 loudness_gain=1.0, limiter_on=1, thr_db=-1.0, rate=48000, bit_depth=16, max_ns=6144):
+                 loudness_gain=1.0, limiter_on=1, thr_db=-1.0, rate=48000, bit_depth=16, max_ns=6144,
+                 lfe_rate=0):
         self.buf = C.create_string_buffer(lib().orc_sizeof_stream())
         self.ch = out_channels
         self.bd = bit_depth
@@ -212,6 +231,8 @@ class Stream:
         r = lib().orc_stream_open(self.buf, C.byref(mx), out_channels, element_gain, output_gain,
                                   loudness_on, loudness_gain, limiter_on, thr_db, rate, bit_depth, max_ns)
         assert r == 0
+        if lfe_rate:   # HOA LFE generator on (the reference built -DDISABLE_LFE_HOA=0), filter at the stream's rate
+            lib().orc_stream_enable_lfe(self.buf, lfe_rate)
 
     def _view(self, raw, n):
         if self.bd == 16:
