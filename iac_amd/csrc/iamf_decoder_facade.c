@@ -234,6 +234,7 @@ struct IAMF_Decoder {
   hipStream_t stream;
   int flushed;
   uint32_t last_frame;
+  int lfe_hoa;      /* HOA LFE generator on: the reference built -DDISABLE_LFE_HOA=0 (ae_rdr.h:63-65) */
   int started;      /* a configure call with data has been made: status left INIT */
   int need_reconf;  /* a new IA sequence header was met while decoding: status RECONFIGURE */
 };
@@ -790,6 +791,12 @@ IAMF_DecoderHandle IAMF_decoder_open(void) { /* IAMF_decoder.c:3726-3744 */
   d->mix_id = -1;
   d->out_type = IAMF_LAYOUT_TYPE_NOT_DEFINED;
   d->pts_base = 90000;
+  {
+    /* the reference decides this at build time (DISABLE_LFE_HOA, default 1 = generator compiled out);
+     * here it is a run-time switch with the same default: the environment, or iamf_hip_decoder_set_hoa_lfe */
+    const char *e = getenv("IAMF_HIP_LFE_HOA");
+    d->lfe_hoa = e && e[0] == '1';
+  }
   d->out_rate = 48000; /* OUTPUT_SAMPLERATE, IAMF_decoder.c:56,3734: other stream rates are resampled to it */
   return d;
 }
@@ -946,6 +953,15 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   cfg.sample_rate = (int32_t)d->rate;
   cfg.out_channels = d->out_channels;
   cfg.projection = IAMF_HIP_PROJ_EXACT; /* a single decoder handle is not throughput bound */
+  /* IAMF_decoder.c:2625-2633: scene-based element, LFE generator compiled in, layout with an LFE.  The
+   * reference keeps ONE filter per output layout, so two scene-based elements would run their W
+   * channels through the same histories in turn; only the single-filter case is taken here */
+  if (d->lfe_hoa && d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION) {
+    int scene = 0;
+    for (int i = 0; i < p->nel; ++i) scene += d->sel_el[i]->type == AUDIO_ELEMENT_SCENE_BASED;
+    if (scene > 1 || (scene == 1 && d->sel_el[0]->type != AUDIO_ELEMENT_SCENE_BASED)) return IAMF_ERR_UNIMPLEMENTED;
+    cfg.lfe_hoa = scene == 1;
+  }
   /* element 0: the parametric down-mixer when the element carries demixing info and the target
    * is a smaller IAMF layout (iamf_stream_renderer_enable_downmix, IAMF_decoder.c:2448-2478) */
   d->use_dmx = 0;
@@ -1401,6 +1417,15 @@ int IAMF_decoder_decode(IAMF_DecoderHandle d, const uint8_t *data, int32_t size,
   }
   if (rsize) *rsize = pos;
   return 0;
+}
+
+/* extension (include/iamf_hip.h): the run-time form of the reference's DISABLE_LFE_HOA build switch */
+int iamf_hip_decoder_set_hoa_lfe(void *handle, int enable) {
+  struct IAMF_Decoder *d = (struct IAMF_Decoder *)handle;
+  if (!d) return IAMF_ERR_BAD_ARG;
+  if (d->configured) return IAMF_ERR_INVALID_STATE; /* like the sampling rate: before configuration */
+  d->lfe_hoa = enable ? 1 : 0;
+  return IAMF_OK;
 }
 
 /* ---- setters / getters (IAMF_decoder.c:3948-4168) ---- */

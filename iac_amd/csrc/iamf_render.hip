@@ -57,6 +57,7 @@ namespace {
 #include "render_fast.hpp"
 #include "render_generic.hpp"
 #include "render_wide.hpp"
+#include "render_lfe.hpp"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -172,6 +173,12 @@ struct iamf_hip_batch {
   void *d_fir_h16 = nullptr;    // split-f16 filter tables (render_fir16.hpp)
   float fir_inv_scale = 1.f;
   int fir_cur = 0;
+  // HOA LFE generator (render_lfe.hpp)
+  bool lfe = false;
+  float lfe_a1 = 0.f, lfe_a2 = 0.f, lfe_a3 = 0.f, lfe_b1 = 0.f, lfe_b2 = 0.f;
+  double lfe_div = 0.0;
+  float *d_lfe_state = nullptr, *d_lfe_next = nullptr, *d_lfe_u = nullptr, *d_lfe_y = nullptr;
+  size_t lfe_u_floats = 0, lfe_y_floats = 0;
 };
 
 namespace {
@@ -193,6 +200,10 @@ int reset_state(iamf_hip_batch *b) {
     const size_t hb = sizeof(float) * (size_t)ns * b->m * 256;
     HIPCHK(hipMemset(b->d_fir_hist[0], 0, hb));
     HIPCHK(hipMemset(b->d_fir_hist[1], 0, hb));
+  }
+  if (b->lfe) {  // lfefilter_init zeroes both histories (h2m_rdr.c:1210-1211)
+    HIPCHK(hipMemset(b->d_lfe_state, 0, sizeof(float) * 4 * (size_t)ns));
+    HIPCHK(hipMemset(b->d_lfe_next, 0, sizeof(float) * 2 * (size_t)ns));
   }
   b->pos = 0;
   b->flushed = false;
@@ -376,10 +387,10 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return IAMF_HIP_OK;
   }
-  const bool fast = fast_path_ok(p);
-  const bool wide = !fast && wide_path_ok(p, m);
+  const bool fast = !p.lfe && fast_path_ok(p);   // an LFE slot is filled by the generic kernel only
+  const bool wide = !p.lfe && !fast && wide_path_ok(p, m);
   const bool mixing = p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp;
-  if ((wide || ((p.demix_on || p.dmx_on || mixing) && wide_path_ok(p, m, true))) && wide4_path_ok(p, m) &&
+  if (!p.lfe && (wide || ((p.demix_on || p.dmx_on || mixing) && wide_path_ok(p, m, true))) && wide4_path_ok(p, m) &&
       (mixing ? iamf_hip_wide4_mix_launch(&p, m, st) : iamf_hip_wide4_launch(&p, m, st))) {
     HIPCHK(hipGetLastError());
     return IAMF_HIP_OK;
@@ -514,6 +525,48 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     p.fir_h16 = b->d_fir_h16;
     p.fir_inv_scale = b->fir_inv_scale;
   }
+  if (b->lfe && a.d_in && total > 0) {
+    // HOA LFE generator: feed-forward part in parallel, the recurrence one lane per stream, both on the
+    // caller's stream ahead of the render kernel (render_lfe.hpp)
+    hipStream_t st = static_cast<hipStream_t>(a.stream);
+    const int ns = b->cfg.n_streams, nb = (ns + 63) / 64, t4 = (total + 3) / 4;
+    const size_t need_u = (size_t)nb * t4 * 64 * 4, need_y = (size_t)ns * t4 * 4;
+    if (need_u > b->lfe_u_floats || need_y > b->lfe_y_floats) {  // grows with the largest call seen
+      HIPCHK(hipStreamSynchronize(st));
+      (void)hipFree(b->d_lfe_u);
+      (void)hipFree(b->d_lfe_y);
+      b->d_lfe_u = b->d_lfe_y = nullptr;
+      b->lfe_u_floats = b->lfe_y_floats = 0;
+      HIPCHK(hipMalloc(&b->d_lfe_u, sizeof(float) * need_u));
+      HIPCHK(hipMalloc(&b->d_lfe_y, sizeof(float) * need_y));
+      b->lfe_u_floats = need_u;
+      b->lfe_y_floats = need_y;
+    }
+    LfeParams lp;
+    memset(&lp, 0, sizeof(lp));
+    lp.in = a.d_in;
+    lp.in_stream_stride = a.in_stream_stride;
+    lp.in_frame_stride = a.in_frame_stride;
+    lp.pre_matrix = b->d_pre;   // projection mode: W is channel 0 AFTER the de-mapping, in every mode
+    lp.pre_l = b->pre_l;
+    lp.pre_m = b->m;
+    lp.frame_size = b->cfg.frame_size;
+    lp.n_streams = ns;
+    lp.total = total;
+    lp.t4 = t4;
+    lp.a1 = b->lfe_a1; lp.a2 = b->lfe_a2; lp.a3 = b->lfe_a3; lp.b1 = b->lfe_b1; lp.b2 = b->lfe_b2;
+    lp.state = b->d_lfe_state;
+    lp.state_next = b->d_lfe_next;
+    lp.u_t = reinterpret_cast<float4 *>(b->d_lfe_u);
+    lp.y = b->d_lfe_y;
+    lp.y_stride = (int64_t)t4 * 4;
+    hipLaunchKernelGGL(lfe_ff_kernel, dim3((unsigned)((t4 + kLfeTileQ - 1) / kLfeTileQ), (unsigned)nb), dim3(256), 0, st, lp);
+    hipLaunchKernelGGL(lfe_chain_kernel, dim3((unsigned)nb), dim3(64), 0, st, lp);
+    HIPCHK(hipGetLastError());
+    p.lfe = b->d_lfe_y;
+    p.lfe_stride = lp.y_stride;
+    p.lfe_div = b->lfe_div;
+  }
   const size_t lds = sizeof(float) * ((size_t)(p.out_ch + 2) * kRing + 3 * kChunk + kHead + 4 +
                                       ((b->dmx || b->demix) ? (size_t)kChCount * kChunk : 0));
   const int r = launch(p, m_eff, lds, static_cast<hipStream_t>(a.stream));
@@ -638,6 +691,22 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
     fm.assign(mx.mat, mx.mat + (size_t)2 * mx.m * cfg->fir_taps);
   } else {
     build_feed_map(mx, cfg->out_channels, fm, b->src_feed);
+    if (cfg->lfe_hoa && mx.kind == IAMF_HIP_KIND_H2M && (mx.lfe1 >= 0 || mx.lfe2 >= 0)) {
+      // HOA LFE generator on (the reference built -DDISABLE_LFE_HOA=0): lfefilter_init(plfe, 120, rate),
+      // h2m_rdr.c:1192-1212, in the reference's own expression types
+      const float sample_rate = (float)cfg->sample_rate, cutoff_freq = 120;
+      const float delta_time = 1 / sample_rate + 1.0e-10;
+      const float c = 1.0f / (float)tanf(M_PI * cutoff_freq * delta_time);
+      b->lfe = true;
+      b->lfe_a1 = 1.0f / (1.0f + c + c * c);
+      b->lfe_a2 = 2.0f * b->lfe_a1;
+      b->lfe_a3 = b->lfe_a1;
+      b->lfe_b1 = 2.0f * (1.0f - c * c) * b->lfe_a1;
+      b->lfe_b2 = (1.0f - c + c * c) * b->lfe_a1;
+      b->lfe_div = mx.n <= 2 ? 0.0 : sqrt((double)mx.n);
+      if (mx.lfe1 >= 0 && mx.lfe1 < cfg->out_channels) b->src_feed[mx.lfe1] = -2;
+      if (mx.lfe2 >= 0 && mx.lfe2 < cfg->out_channels) b->src_feed[mx.lfe2] = -2;
+    }
     // sparsity of the matrix as the output slots see it (render_wide4.hpp skips all-zero weight batches)
     int set = 0, all = 0;
     for (int g = 0; g < 6 && 4 * g < cfg->out_channels; ++g)
@@ -686,6 +755,10 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
   CREATE_CHK(hipMalloc(&b->d_lim, sizeof(LimState) * ns));
   CREATE_CHK(hipMalloc(&b->d_ring_y, sizeof(float) * (size_t)ns * cfg->out_channels * kSave));
   CREATE_CHK(hipMalloc(&b->d_ring_pm, sizeof(float) * (size_t)ns * kSave));
+  if (b->lfe) {
+    CREATE_CHK(hipMalloc(&b->d_lfe_state, sizeof(float) * 4 * (size_t)ns));
+    CREATE_CHK(hipMalloc(&b->d_lfe_next, sizeof(float) * 2 * (size_t)ns));
+  }
   CREATE_CHK(hipMalloc(&b->d_src_feed, sizeof(int32_t) * kMaxOut));
   CREATE_CHK(hipMemcpy(b->d_src_feed, b->src_feed, sizeof(int32_t) * kMaxOut, hipMemcpyHostToDevice));
   if (fir) {
@@ -755,6 +828,10 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_fir_hist[0]);
   (void)hipFree(b->d_fir_hist[1]);
   (void)hipFree(b->d_fir_h16);
+  (void)hipFree(b->d_lfe_state);
+  (void)hipFree(b->d_lfe_next);
+  (void)hipFree(b->d_lfe_u);
+  (void)hipFree(b->d_lfe_y);
   (void)hipFree(b->d_matrix2);
   (void)hipFree(b->d_gains2);
   (void)hipFree(b->d_src_feed2);

@@ -41,7 +41,8 @@ struct RenderParams {
   int32_t use_mfma;         // wide kernel: projection on v_mfma_f32_32x32x2_f32 instead of VALU
   int32_t n_atk, n_end;     // limiter table split points
   float thr;
-  const int32_t *src_feed;  // device [out_ch]: output slot -> feed index, or -1 = silent slot
+  const int32_t *src_feed;  // device [out_ch]: output slot -> feed index, -1 = silent slot, -2 = LFE slot
+                            // fed by the HOA LFE generator (render_lfe.hpp; generic kernel only)
   // wide4 VALU projection: bit m of nz_mask[g] = some output slot 4g..4g+3 has a non-zero weight for
   // input m; sparse = less than half of those bits are set (then all-zero weight batches are skipped)
   uint32_t nz_mask[6];
@@ -76,6 +77,10 @@ struct RenderParams {
   int32_t demix_layout;     // IAChannelLayoutType of the target layout (render_wide4_kernel<.., DMX>)
   int32_t demix_gmask;      // bit m: decoded channel m takes the output gain demix_ftab[12 + 2*frame_size + m]
   int32_t demix_w4;         // 1 if the in-register demixer of render_wide4.hpp covers this configuration
+  // ---- HOA LFE generator (render_lfe.hpp): raw low-pass output of this call or nullptr ----
+  const float *lfe;         // device [n_streams][lfe_stride]
+  int64_t lfe_stride;
+  double lfe_div;           // sqrt(n) of h2m_rdr.c:1162; 0 = the `* 0.5` form (n <= 2)
   // ---- HRTF FIR renderer (render_fast_kernel<M, 2, true>): matrix = h[2][M][fir_taps] ----
   int32_t fir_taps;
   const float *fir_hist;    // device [n_streams][M][256] input history before this call

@@ -217,6 +217,11 @@ __global__ __launch_bounds__(kChunk) void render_kernel(const RenderParams p) {
 #pragma unroll
           for (int m = 0; m < M; ++m) acc = acc + row[m] * x[m];
           y = acc;
+        } else if (f == -2 && p.lfe && valid) {
+          // LFE slot (h2m_rdr.c:1154-1184): the generator's output `* 0.5` or `/ sqrt(n_size)` — double
+          // expressions narrowed by the store; slot lfe2 repeats slot lfe1
+          const float o = p.lfe[(int64_t)s * p.lfe_stride + k];
+          y = p.lfe_div == 0.0 ? (float)((double)o * 0.5) : (float)((double)o / p.lfe_div);
         }
       }
       if (p.elem_ramp) {

@@ -35,7 +35,8 @@ class BatchConfig(C.Structure):
     _fields_ = [("n_streams", C.c_int32), ("frame_size", C.c_int32), ("sample_rate", C.c_int32),
                 ("out_channels", C.c_int32), ("out_format", C.c_int32), ("matrix", Matrix),
                 ("limiter_enable", C.c_int32), ("limiter_threshold_db", C.c_float),
-                ("loudness_enable", C.c_int32), ("projection", C.c_int32), ("fir_taps", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("loudness_enable", C.c_int32), ("projection", C.c_int32), ("fir_taps", C.c_int32), ("lfe_hoa", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
 
 
 class DmxState(C.Structure):
@@ -191,7 +192,8 @@ class Batch:
     """Thin handle on iamf_hip_batch_*; pointers are raw device addresses (ints)."""
 
     def __init__(self, n_streams, matrix, out_channels, frame_size=1024, sample_rate=48000,
-                 out_format=FMT_S16, limiter=True, threshold_db=-1.0, loudness=False, projection=PROJ_AUTO, fir_taps=0):
+                 out_format=FMT_S16, limiter=True, threshold_db=-1.0, loudness=False, projection=PROJ_AUTO, fir_taps=0,
+                 lfe_hoa=False):
         cfg = BatchConfig()
         cfg.n_streams = n_streams
         cfg.frame_size = frame_size
@@ -204,6 +206,7 @@ class Batch:
         cfg.loudness_enable = 1 if loudness else 0
         cfg.projection = projection
         cfg.fir_taps = fir_taps
+        cfg.lfe_hoa = 1 if lfe_hoa else 0
         self.cfg = cfg
         self.bytes_per_sample = lib().iamf_hip_format_bytes(out_format)
         h = C.c_void_p()

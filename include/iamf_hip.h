@@ -109,7 +109,12 @@ typedef struct {
   int32_t loudness_enable; /* normalization_loudness != 0 (IAMF_decoder.c:3480) */
   int32_t projection;      /* IAMF_HIP_PROJ_*: how layouts with more than 2 channels are projected */
   int32_t fir_taps;        /* kind FIR: taps per HRIR (1..256) */
-  int32_t reserved[5];
+  int32_t lfe_hoa;         /* kind H2M into a layout with an LFE slot: 1 = the HOA LFE generator of
+                              h2m_rdr.c:1151-1239 fills it (2nd-order Butterworth low-pass at 120 Hz over
+                              ambisonics channel 0, scaled by 1/sqrt(n)), as a reference built with its
+                              switch -DDISABLE_LFE_HOA=0 does (call site IAMF_decoder.c:2625-2636);
+                              0 = the default build's silence (ae_rdr.h:63-65) */
+  int32_t reserved[4];
 } iamf_hip_batch_config;
 
 /* Creates device state for cfg->n_streams streams on the CURRENT HIP device.  Synchronous.
@@ -295,6 +300,15 @@ int iamf_hip_batch_reset(iamf_hip_batch *b);
 int iamf_hip_format_bytes(int out_format);
 /* library / build identification string (static storage) */
 const char *iamf_hip_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder facade extension.  The reference chooses at BUILD time whether scene-based elements feed
+ * the LFE of the output layout (-DDISABLE_LFE_HOA=0; default: compiled out, ae_rdr.h:63-65).  This
+ * library carries both builds: the switch is per decoder handle (an IAMF_DecoderHandle of this
+ * library's IAMF_decoder.h), to be set before IAMF_decoder_configure; its default is off, or on if
+ * the environment has IAMF_HIP_LFE_HOA=1 when the handle is opened.
+ * ---------------------------------------------------------------------------------------- */
+int iamf_hip_decoder_set_hoa_lfe(void *decoder_handle, int enable);
 
 #ifdef __cplusplus
 }

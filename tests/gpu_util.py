@@ -18,7 +18,7 @@ def to_frames(x, frame_size):
 
 def hip_render(matrix, out_ch, x, frame_size, fmt=A.FMT_S16, limiter=True, flush=True,
                frames_per_call=None, gains=None, loudness=False, threshold_db=-1.0,
-               sample_rate=48000, projection=0, fir_taps=0):
+               sample_rate=48000, projection=0, fir_taps=0, lfe_hoa=False):
     """x: numpy [S][m][total].  Returns a list (per stream) of arrays [n_out][out_ch] (S24:
     [n_out][out_ch][3] bytes) — everything the calls emitted, concatenated."""
     S, m, total = x.shape
@@ -27,7 +27,7 @@ def hip_render(matrix, out_ch, x, frame_size, fmt=A.FMT_S16, limiter=True, flush
     bps = {A.FMT_S16: 2, A.FMT_S24: 3, A.FMT_S32: 4, A.FMT_F32: 4}[fmt]
     b = A.Batch(S, matrix, out_ch, frame_size=frame_size, sample_rate=sample_rate, out_format=fmt,
                 limiter=limiter, threshold_db=threshold_db, loudness=loudness, projection=projection,
-                fir_taps=fir_taps)
+                fir_taps=fir_taps, lfe_hoa=lfe_hoa)
     if gains:
         b.set_gains(**gains)
     calls = frames_per_call or [F]

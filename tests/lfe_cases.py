@@ -57,6 +57,8 @@ E2E = {
     "soa_C_441_to_48k": dict(order=2, ss="C", bit_depth=16, frames=5, fs=1024, seed=205, rate=44100),
     "toa_B_decay_s32": dict(order=3, ss="B", bit_depth=32, frames=14, fs=1024, seed=206, silence_from=2500),
     "toa_A_s16": dict(order=3, ss="A", bit_depth=16, frames=3, fs=1024, seed=207),   # no LFE slot: unchanged path
+    # projection-mode ambisonics: W is channel 0 AFTER the de-mapping (IAMF_core_decoder.c:116-130)
+    "toa_projection_D_s16": dict(order=3, ss="D", bit_depth=16, frames=4, fs=1024, seed=208, projection=True),
 }
 
 
@@ -68,10 +70,25 @@ def build(name):
     xq = W.quantize(x, 16)
     pd = lambda pid: W.param_definition(pid, rate, mode=1)
     s = W.sequence_header(1) + W.codec_config_lpcm(0, fs, 16, rate)
-    s += W.audio_element_ambisonics_mono(1, 0, m, list(range(m)))
+    subs_n, coupled = 10, 6   # projection mode: 16 decoded channels in 10 sub-streams
+    if c.get("projection"):
+        rng = np.random.default_rng(c["seed"])
+        pq = rng.integers(-9000, 9000, size=(subs_n + coupled, m)).astype(np.int16)
+        pq[np.arange(m), np.arange(m)] = 29000
+        s += W.audio_element_ambisonics_projection(1, 0, m, list(range(subs_n)), coupled, pq)
+    else:
+        s += W.audio_element_ambisonics_mono(1, 0, m, list(range(m)))
     s += W.mix_presentation(1, [dict(eid=1, pdef=pd(100), default_q78=0)], dict(pdef=pd(101), default_q78=0),
                             [("ss", SS_ENUM[c["ss"]])])
     for f in range(F):
         s += W.temporal_delimiter()
-        s += W.audio_frames([(i, W.lpcm_bytes(xq[i:i + 1, f * fs:(f + 1) * fs], 16)) for i in range(m)])
+        if c.get("projection"):
+            subs, ch = [], 0
+            for i in range(subs_n):
+                w = 2 if i < coupled else 1
+                subs.append((i, W.lpcm_bytes(xq[ch:ch + w, f * fs:(f + 1) * fs], 16)))
+                ch += w
+            s += W.audio_frames(subs)
+        else:
+            s += W.audio_frames([(i, W.lpcm_bytes(xq[i:i + 1, f * fs:(f + 1) * fs], 16)) for i in range(m)])
     return s, xq

@@ -1,0 +1,129 @@
+"""-m gpu: the HOA LFE generator (reference h2m_rdr.c:1151-1239 under the reference's build
+switch -DDISABLE_LFE_HOA=0) on the HIP path, against goldens of the LFE-enabled reference
+(tests/golden/lfe.npz, oracle/gen_golden_lfe.py) and against the oracle.  Bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gpu_util as G
+import iac_amd as A
+import lfe_cases as LC
+import oracle_lib as O
+from decoder_driver import decode_stream
+
+pytestmark = pytest.mark.gpu
+
+
+def same_floats(a, b):
+    """bit-identical except for the sign of a zero (the mixer's 0 + y turns -0 into +0)"""
+    return a.shape == b.shape and bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))))
+
+
+@pytest.mark.parametrize("name", sorted(LC.STAGE))
+def test_stage_f32_bit_exact_vs_reference(golden, name):
+    """render_H2M + generator over ragged consecutive calls (filter state carried), float output,
+    limiter off: the reference's own floats.  frame_size 1 = sample-interleaved input."""
+    order, oid, rate, sizes, _ = LC.STAGE[name]
+    x = LC.stage_input(name)
+    ch = O.OUT_CH[oid]
+    got = G.hip_render(A.get_h2m_matrix(order, oid), ch, x[None], frame_size=1, fmt=A.FMT_F32, limiter=False,
+                       flush=False, frames_per_call=sizes, sample_rate=rate, lfe_hoa=True)[0]
+    want = np.ascontiguousarray(golden.npz("lfe")["stage_" + name].T)
+    assert same_floats(got, want), name
+
+
+def test_many_streams_lane_mapping_and_state_vs_oracle():
+    """150 streams (three 64-stream blocks of the recurrence kernel, the last one partial) in calls of
+    3 + 1 + 2 frames of 960 samples: every stream must get ITS filter state"""
+    S, fs, F = 150, 960, 6
+    x = np.stack([LC.programme(900 + s, 16, fs * F) * np.float32(0.5 + (s % 7) * 0.1) for s in range(S)])
+    mx, omx = A.get_h2m_matrix(3, A.SS["B"]), O.get_h2m(3, O.SS["B"])
+    got = G.hip_render(mx, 6, x, frame_size=fs, frames_per_call=[3, 1, 2], lfe_hoa=True)
+    for s in list(range(0, S, 13)) + [63, 64, 127, 128, 149]:
+        want = O.stream_run(omx, 6, x[s], fs, lfe_rate=48000)
+        assert np.array_equal(got[s], want), s
+    assert np.abs(got[5][:, 3].astype(np.int32)).max() > 1000   # the LFE slot carries a signal
+
+
+def test_denormal_decay_f32_vs_oracle():
+    """after the programme stops the recurrence decays through the f32 denormal range (a 120 Hz pole pair:
+    ~0.99 per sample); the CPU keeps gradual underflow, so must the kernel"""
+    fs, F = 1024, 24
+    x = LC.programme(77, 4, fs * F, silence_from=1500)
+    mx, omx = A.get_h2m_matrix(1, A.SS["B"]), O.get_h2m(1, O.SS["B"])
+    got = G.hip_render(mx, 6, x[None], frame_size=fs, fmt=A.FMT_F32, limiter=False, flush=False, lfe_hoa=True)[0]
+    want = np.ascontiguousarray(O.render_h2m_lfe(omx, x, 6, 48000, [fs] * F).T)
+    lfe = want[:, 3]
+    tiny = np.abs(lfe[np.nonzero(lfe)[0]]).min()
+    assert 0 < tiny < 1.2e-38, "the case must reach denormal outputs (got %g)" % tiny
+    assert same_floats(got, want)
+
+
+@pytest.mark.parametrize("fmt,bd", [(A.FMT_S16, 16), (A.FMT_S24, 24), (A.FMT_S32, 32)])
+def test_pipeline_formats_vs_oracle(fmt, bd):
+    fs, F = 1024, 4
+    x = np.stack([LC.programme(300 + s, 16, fs * F) for s in range(3)])
+    mx, omx = A.get_h2m_matrix(3, A.SS["J"]), O.get_h2m(3, O.SS["J"])
+    got = G.hip_render(mx, 12, x, frame_size=fs, fmt=fmt, lfe_hoa=True)
+    for s in range(3):
+        assert np.array_equal(got[s], O.stream_run(omx, 12, x[s], fs, bit_depth=bd, lfe_rate=48000)), s
+
+
+def test_switch_off_is_the_default_build():
+    """lfe_hoa = 0 -> the LFE slot stays silent, exactly the default reference build"""
+    fs, F = 1024, 2
+    x = LC.programme(55, 16, fs * F)[None]
+    mx, omx = A.get_h2m_matrix(3, A.SS["B"]), O.get_h2m(3, O.SS["B"])
+    got = G.hip_render(mx, 6, x, frame_size=fs)[0]
+    assert np.array_equal(got, O.stream_run(omx, 6, x[0], fs))
+    assert not got[:, 3].any()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import torch
+    assert torch.cuda.is_available()
+    L = C.CDLL(A.lib_path())
+    L.iamf_hip_decoder_set_hoa_lfe.argtypes = [C.c_void_p, C.c_int]
+    return L
+
+
+class _LfeOn:
+    """the decoder library with the generator switched on for every handle it opens"""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        f = getattr(self._lib, name)
+        if name != "IAMF_decoder_open":
+            return f
+        lib = self._lib
+
+        def open_():
+            lib.IAMF_decoder_open.restype = C.c_void_p
+            d = lib.IAMF_decoder_open()
+            assert lib.iamf_hip_decoder_set_hoa_lfe(d, 1) == 0
+            return d
+        return open_
+
+
+@pytest.mark.parametrize("name", sorted(LC.E2E))
+def test_facade_matches_lfe_enabled_reference_decoder(lib, golden, name):
+    c = LC.E2E[name]
+    stream, _ = LC.build(name)
+    pcm, rets = decode_stream(_LfeOn(lib), stream, ("ss", LC.SS_ENUM[c["ss"]]), bit_depth=c["bit_depth"])
+    want = golden.npz("lfe")["e2e_" + name]
+    assert list(rets) == list(golden.npz("lfe")["e2e_" + name + "_rets"]), name
+    assert pcm.shape == want.shape
+    assert np.array_equal(pcm, want), name
+
+
+def test_facade_switch_protocol(lib):
+    lib.IAMF_decoder_open.restype = C.c_void_p
+    lib.IAMF_decoder_close.argtypes = [C.c_void_p]
+    d = lib.IAMF_decoder_open()
+    assert lib.iamf_hip_decoder_set_hoa_lfe(d, 1) == 0
+    assert lib.iamf_hip_decoder_set_hoa_lfe(None, 1) == -1
+    lib.IAMF_decoder_close(d)

@@ -189,6 +189,8 @@ def test_lfe_e2e_through_the_oracle_stream(golden):
         mx = O.get_h2m(c["order"], oid)
         rate = c.get("rate", 48000)
         want = g["e2e_" + name]
+        if c.get("projection"):   # the de-mapping stage sits in front: checked on the facade (-m gpu)
+            continue
         if rate != 48000:   # resampled to the 48 kHz default: checked on the facade against this golden (-m gpu)
             continue
         y = O.stream_run(mx, O.OUT_CH[oid], xq, c["fs"], bit_depth=c["bit_depth"], lfe_rate=rate)
