@@ -40,6 +40,10 @@ WORKLOADS = {
     "toa_binaural_limiter_s16": ("h2m", 3, 0x1020, 16, 16 * 4 + 2 * 2),
     "toa_ssH_limiter_s16": ("h2m", 3, 0x9A3, 16, 16 * 4 + 24 * 2),
     "toa_ssB_limiter_s16": ("h2m", 3, 0x050, 16, 16 * 4 + 6 * 2),
+    # the same with the HOA LFE generator on (h2m_rdr.c:1151-1239, the reference built
+    # -DDISABLE_LFE_HOA=0): two pre-pass kernels (render_lfe.hpp: the serial biquad, one lane per stream)
+    # + the general render kernel; bytes = the render's own 76 + 16 of scratch traffic (u and y, written and read)
+    "toa_ssB_lfe_limiter_s16": ("h2m_lfe", 3, 0x050, 16, 16 * 4 + 6 * 2 + 16),
     "714_ssJ_limiter_s16": ("m2m", 0x714, 0x470, 12, 12 * 4 + 12 * 2),
     # binaural by HRTF FIR (256-tap synthetic HRIRs; the reference's own binauraliser is not in its
     # tree -> "parity unpinned"): compute-bound on the f32 MFMA, 2*16*2*256 flop per sample-frame
@@ -110,7 +114,7 @@ def cpu_baseline(workload, fs, seconds_target=12.0):
     import oracle_lib as O
     import synth
     kind, in_id, out_id, in_ch, _ = WORKLOADS[workload]
-    mx = O.get_h2m(in_id, out_id) if kind == "h2m" else O.get_m2m(in_id, out_id)
+    mx = O.get_h2m(in_id, out_id) if kind in ("h2m", "h2m_lfe") else O.get_m2m(in_id, out_id)
     out_ch = O.OUT_CH[out_id]
     frames = 256
     xf = np.ascontiguousarray(synth.hot(4242, in_ch, frames * fs).reshape(in_ch, frames, fs).transpose(1, 0, 2))
@@ -155,7 +159,7 @@ def reference_baseline(workload, fs, seconds_target=12.0):
         x = W.quantize(np.clip(synth.hot(4242, in_ch, frames * fs), -1, 1 - 2 ** -15).astype(np.float32), 16)
         pd = lambda pid: W.param_definition(pid, 48000, mode=1)
         stream = W.sequence_header(1) + W.codec_config_lpcm(0, fs, 16, 48000)
-        if kind in ("h2m", "h2m_proj", "h2m_in2"):
+        if kind in ("h2m", "h2m_proj", "h2m_in2", "h2m_lfe"):
             stream += W.audio_element_ambisonics_mono(1, 0, in_ch, list(range(in_ch)))
         else:
             stream += W.audio_element_channel(1, 0, 7, list(range(W.LAYOUT_SUBSTREAMS[7][0])))
@@ -169,7 +173,7 @@ def reference_baseline(workload, fs, seconds_target=12.0):
         desc_len = len(stream)
         for f in range(frames):
             stream += W.temporal_delimiter()
-            if kind in ("h2m", "h2m_proj", "h2m_in2"):
+            if kind in ("h2m", "h2m_proj", "h2m_in2", "h2m_lfe"):
                 stream += W.audio_frames([(i, W.lpcm_bytes(x[i:i + 1, f * fs:(f + 1) * fs], 16)) for i in range(in_ch)])
             else:
                 stream += W.audio_frames(W.channel_element_substreams(7, xal[:, f * fs:(f + 1) * fs], 0, 16))
@@ -223,6 +227,8 @@ def kernel_tag(kind, in_ch, out_ch):
         return "render_wide4_kernel<%d, %d, false, true" % (in_ch, out_ch)
     if kind == "fir":
         return "render_fast_kernel<%d, 2, 2" % in_ch
+    if kind == "h2m_lfe":
+        return "render_kernel<%d" % in_ch
     if out_ch <= 2:
         return "render_fast_kernel<%d, %d, 0, false, false" % (in_ch, out_ch)
     # whole 1024-sample chunks of s16: the 4-samples-per-lane kernel (else render_wide_kernel)
@@ -244,7 +250,7 @@ class Workload:
         elif kind == "dmx":
             mx = A.dmx_matrix(in_id, out_id)
         else:
-            mx = A.get_h2m_matrix(in_id, out_id) if kind in ("h2m", "h2m_proj", "h2m_in2") else A.get_m2m_matrix(in_id, out_id)
+            mx = A.get_h2m_matrix(in_id, out_id) if kind in ("h2m", "h2m_proj", "h2m_in2", "h2m_lfe") else A.get_m2m_matrix(in_id, out_id)
         out_ch = self.out_ch = mx.channels if kind == "dmx" else A.layout_channels(out_id)
         S, F, fs = args.streams, args.frames, args.frame_size
         self.S, self.F, self.fs = S, F, fs
@@ -260,7 +266,7 @@ class Workload:
             x = x.contiguous()
             del tt, ph
         batch = self.batch = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True,
-                                     fir_taps=FIR_TAPS if kind == "fir" else 0)
+                                     fir_taps=FIR_TAPS if kind == "fir" else 0, lfe_hoa=kind == "h2m_lfe")
         self.extra = None
         self.x2 = None
         if kind in ("h2m_in2", "m2m_in2"):
@@ -585,7 +591,7 @@ def main():
         kind = headline_kind
         if not args.no_cpu_baseline:
             wlname = {"fir": "toa_binaural_limiter_s16", "demix": "714_ssJ_limiter_s16"}.get(kind, args.workload)
-            wlname = wlname.replace("toa_projection_", "toa_")
+            wlname = wlname.replace("toa_projection_", "toa_").replace("_lfe_", "_")
             if kind in ("dmx", "m2m_in2"):
                 wlname = "714_ssJ_limiter_s16"
             if kind == "h2m_in2":
@@ -600,7 +606,8 @@ def main():
                      "dmx": " [the 7.1.4 -> J matrix stream: the reference's down-mixer needs a demixing-parameter stream]",
                      "h2m_in2": " [the one-element stream: without the stereo element]",
                      "m2m_in2": " [the one-element stream: without the stereo element]",
-                     "h2m_proj": " [the mono-mode stream: without the de-mapping stage]"}
+                     "h2m_proj": " [the mono-mode stream: without the de-mapping stage]",
+                     "h2m_lfe": " [the default reference build: LFE generator compiled out]"}
             out["cpu_baseline"]["sample"] += notes.get(kind, "")
         print(json.dumps(out), flush=True)
     if world > 1:
