@@ -234,6 +234,8 @@ struct IAMF_Decoder {
   hipStream_t stream;
   int flushed;
   uint32_t last_frame;
+  int pcm_stride, pcm_extra; /* channels per PCM sample-frame; surplus elements past the last frame (TV, > 12 ch) */
+  int tv;           /* behaves as the reference built -DSAMSUNG_TV (iamf_hip_decoder_set_variant) */
   int lfe_hoa;      /* HOA LFE generator on: the reference built -DDISABLE_LFE_HOA=0 (ae_rdr.h:63-65) */
   int started;      /* a configure call with data has been made: status left INIT */
   int need_reconf;  /* a new IA sequence header was met while decoding: status RECONFIGURE */
@@ -796,6 +798,8 @@ IAMF_DecoderHandle IAMF_decoder_open(void) { /* IAMF_decoder.c:3726-3744 */
      * here it is a run-time switch with the same default: the environment, or iamf_hip_decoder_set_hoa_lfe */
     const char *e = getenv("IAMF_HIP_LFE_HOA");
     d->lfe_hoa = e && e[0] == '1';
+    e = getenv("IAMF_HIP_SAMSUNG_TV");
+    d->tv = e && e[0] == '1';
   }
   d->out_rate = 48000; /* OUTPUT_SAMPLERATE, IAMF_decoder.c:56,3734: other stream rates are resampled to it */
   return d;
@@ -884,7 +888,8 @@ static int element_matrix(const struct IAMF_Decoder *d, const Element *e, iamf_h
     int order = e->channels == 1 ? 0 : e->channels == 4 ? 1 : e->channels == 9 ? 2 : 3; /* IAMF_decoder.c:2403-2413 */
     return iamf_hip_get_h2m_matrix(order, out_id, mx);
   }
-  return iamf_hip_get_m2m_matrix(e->channels == 1 ? IAMF_HIP_L_MONO : k_layer_rid[e->layout], out_id, mx);
+  return iamf_hip_get_m2m_matrix_variant(d->tv ? IAMF_HIP_VARIANT_SAMSUNG_TV : IAMF_HIP_VARIANT_DEFAULT,
+                                         e->channels == 1 ? IAMF_HIP_L_MONO : k_layer_rid[e->layout], out_id, mx);
 }
 
 /* channels per frame handed to the device: decoded channels for projection-mode ambisonics */
@@ -895,6 +900,7 @@ static int element_in_channels(const Element *e) {
 /* iamf_stream_set_output_layout, IAMF_decoder.c:1776-1822: which layer of a scalable element is decoded */
 static int select_layer(const struct IAMF_Decoder *d, const Element *e) {
   if (e->nlayers == 1) return 0;
+  if (d->tv) return e->nlayers - 1; /* -DSAMSUNG_TV: "default to use the highest layout" (:1782,1818-1820) */
   if (d->out_type == IAMF_LAYOUT_TYPE_BINAURAL) return e->nlayers - 1;
   for (int i = 0; i < e->nlayers; ++i)
     if (k_layout_ss[e->layer[i].layout] == (int)d->out_ss) return i;
@@ -952,6 +958,9 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   cfg.frame_size = (int32_t)d->frame_size;
   cfg.sample_rate = (int32_t)d->rate;
   cfg.out_channels = d->out_channels;
+  /* -DSAMSUNG_TV: every PCM frame is written with a 12-channel stride (IAMF_decoder.c:3492-3495) */
+  d->pcm_stride = d->tv ? 12 : d->out_channels;
+  d->pcm_extra = d->out_channels > d->pcm_stride ? d->out_channels - d->pcm_stride : 0;
   cfg.projection = IAMF_HIP_PROJ_EXACT; /* a single decoder handle is not throughput bound */
   /* IAMF_decoder.c:2625-2633: scene-based element, LFE generator compiled in, layout with an LFE.  The
    * reference keeps ONE filter per output layout, so two scene-based elements would run their W
@@ -1006,6 +1015,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
     cfg.limiter_enable = 0;
   } else {
     cfg.out_format = (int32_t)d->bit_depth;
+    cfg.pcm_stride_channels = d->pcm_stride;
     cfg.limiter_enable = d->limiter_on;
     cfg.limiter_threshold_db = d->limiter_db;
     cfg.loudness_enable = d->norm_loudness != 0.f;
@@ -1074,6 +1084,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
     c3.sample_rate = (int32_t)d->out_rate;
     c3.out_channels = d->out_channels;
     c3.out_format = (int32_t)d->bit_depth;
+    c3.pcm_stride_channels = d->pcm_stride;
     c3.matrix.kind = IAMF_HIP_KIND_M2M;
     c3.matrix.m = c3.matrix.n = c3.matrix.channels = d->out_channels;
     c3.matrix.lfe1 = c3.matrix.lfe2 = -1;
@@ -1103,7 +1114,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
         hipMalloc((void **)&d->d_ramp[i], sizeof(float) * d->frame_size) != hipSuccess)
       return IAMF_ERR_ALLOC_FAIL;
   if (hipMalloc((void **)&d->d_dmx, sizeof(iamf_hip_dmx_frame)) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
-  d->pcm_cap = (size_t)4 * d->info.max_frame_size * d->out_channels;
+  d->pcm_cap = (size_t)4 * ((size_t)d->info.max_frame_size * d->pcm_stride + d->pcm_extra);
   if (hipMalloc(&d->d_pcm, d->pcm_cap) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
   if (resample) {
     int cap = iamf_hip_resampler_out_capacity(d->rs, (int)d->frame_size) + 512;
@@ -1339,7 +1350,7 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     n = n2 ? iamf_hip_batch_render(d->batch3, d->d_res, 0, d->out_channels, n2, d->d_pcm, (int64_t)d->pcm_cap, d->stream) : 0;
   }
   if (n < 0) return IAMF_ERR_INTERNAL;
-  if (n > 0 && hipMemcpyAsync(pcm, d->d_pcm, (size_t)n * d->out_channels * bytes, hipMemcpyDeviceToHost, d->stream) != hipSuccess)
+  if (n > 0 && hipMemcpyAsync(pcm, d->d_pcm, ((size_t)n * d->pcm_stride + d->pcm_extra) * bytes, hipMemcpyDeviceToHost, d->stream) != hipSuccess)
     return IAMF_ERR_INTERNAL;
   if (hipStreamSynchronize(d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
   params_time_elapse(d, (uint64_t)keep); /* IAMF_decoder.c:3471: the mixed frame's length */
@@ -1366,7 +1377,7 @@ static int flush_tail(struct IAMF_Decoder *d, void *pcm) { /* iamf_delay_buffer_
     n = (n2 + extra) ? iamf_hip_batch_render(d->batch3, d->d_res, 0, d->out_channels, n2 + extra, d->d_pcm, (int64_t)d->pcm_cap, d->stream) : 0;
   }
   if (n < 0) return IAMF_ERR_INTERNAL;
-  if (n > 0 && hipMemcpyAsync(pcm, d->d_pcm, (size_t)n * d->out_channels * bytes, hipMemcpyDeviceToHost, d->stream) != hipSuccess)
+  if (n > 0 && hipMemcpyAsync(pcm, d->d_pcm, ((size_t)n * d->pcm_stride + d->pcm_extra) * bytes, hipMemcpyDeviceToHost, d->stream) != hipSuccess)
     return IAMF_ERR_INTERNAL;
   if (hipStreamSynchronize(d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
   return n;
@@ -1425,6 +1436,14 @@ int iamf_hip_decoder_set_hoa_lfe(void *handle, int enable) {
   if (!d) return IAMF_ERR_BAD_ARG;
   if (d->configured) return IAMF_ERR_INVALID_STATE; /* like the sampling rate: before configuration */
   d->lfe_hoa = enable ? 1 : 0;
+  return IAMF_OK;
+}
+
+int iamf_hip_decoder_set_variant(void *handle, int variant) {
+  struct IAMF_Decoder *d = (struct IAMF_Decoder *)handle;
+  if (!d || (variant != IAMF_HIP_VARIANT_DEFAULT && variant != IAMF_HIP_VARIANT_SAMSUNG_TV)) return IAMF_ERR_BAD_ARG;
+  if (d->configured) return IAMF_ERR_INVALID_STATE;
+  d->tv = variant == IAMF_HIP_VARIANT_SAMSUNG_TV;
   return IAMF_OK;
 }
 

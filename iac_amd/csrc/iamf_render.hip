@@ -59,6 +59,33 @@ namespace {
 #include "render_wide.hpp"
 #include "render_lfe.hpp"
 
+// PCM with a fixed channel stride (the -DSAMSUNG_TV build: iamf_decoder_plane2stride_out with
+// stride = SAMSUNG_SPECIFIC_CHANNELS = 12, IAMF_decoder.c:121-167,3492-3495).  The reference zeroes
+// n * stride elements and then writes, channel by channel, element i * stride + c for every sample i:
+// with more channels than the stride those land in the NEXT sample-frames' slots and the last writer
+// wins (the highest channel), the last sample's surplus channels past the zeroed area.  One thread per
+// output element reproduces exactly that.  src: natural interleaving [n][ch].
+__global__ __launch_bounds__(256) void restride_kernel(const uint8_t *src, int64_t src_stream_stride, uint8_t *dst,
+                                                       int64_t dst_stream_stride, int n, int ch, int sc, int bps) {
+  const int s = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n_out = (int64_t)n * sc + (ch > sc ? ch - sc : 0);
+  if (p >= n_out) return;
+  const int c0 = (int)(p % sc);
+  const int64_t i = p / sc;
+  const uint8_t *from = nullptr;
+  for (int k = (ch - 1 - c0) / sc; k >= 0 && ch > c0; --k) {   // the highest channel that maps here
+    const int64_t ii = i - k;
+    if (ii >= 0 && ii < n) {
+      from = src + (int64_t)s * src_stream_stride + (ii * ch + c0 + (int64_t)sc * k) * bps;
+      break;
+    }
+  }
+  if (!from && p >= (int64_t)n * sc) return;   // past the zeroed area and nobody writes it
+  uint8_t *to = dst + (int64_t)s * dst_stream_stride + p * bps;
+  for (int b = 0; b < bps; ++b) to[b] = from ? from[b] : 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -81,15 +108,18 @@ struct TableEntry {
 
 extern "C" const uint8_t _binary_rdr_tables_bin_start[];
 extern "C" const uint8_t _binary_rdr_tables_bin_end[];
+extern "C" const uint8_t _binary_rdr_tables_tv_bin_start[];   // the -DSAMSUNG_TV build's tables (m2m_rdr.c:36-830)
+extern "C" const uint8_t _binary_rdr_tables_tv_bin_end[];
 
 struct Tables {
   int n = 0;
   const TableEntry *ents = nullptr;
   const float *data = nullptr;
   bool ok = false;
-  Tables() {
-    const uint8_t *b = _binary_rdr_tables_bin_start;
-    const size_t sz = (size_t)(_binary_rdr_tables_bin_end - _binary_rdr_tables_bin_start);
+  explicit Tables(bool tv) {
+    const uint8_t *b = tv ? _binary_rdr_tables_tv_bin_start : _binary_rdr_tables_bin_start;
+    const size_t sz = tv ? (size_t)(_binary_rdr_tables_tv_bin_end - _binary_rdr_tables_tv_bin_start)
+                         : (size_t)(_binary_rdr_tables_bin_end - _binary_rdr_tables_bin_start);
     if (sz < 12 || memcmp(b, "IARDRTB1", 8) != 0) return;
     uint32_t cnt;
     memcpy(&cnt, b + 8, 4);
@@ -100,13 +130,13 @@ struct Tables {
   }
 };
 
-const Tables &tables() {
-  static Tables t;
-  return t;
+const Tables &tables(bool tv) {
+  static Tables t(false), t_tv(true);
+  return tv ? t_tv : t;
 }
 
-int find_matrix(int kind, int in_id, int out_id, iamf_hip_matrix *out) {
-  const Tables &t = tables();
+int find_matrix(int kind, int in_id, int out_id, iamf_hip_matrix *out, bool tv = false) {
+  const Tables &t = tables(tv);
   if (!t.ok || !out) return -1;
   for (int i = 0; i < t.n; ++i) {  // first match in table order, as the reference searches
     const TableEntry &e = t.ents[i];
@@ -179,6 +209,9 @@ struct iamf_hip_batch {
   double lfe_div = 0.0;
   float *d_lfe_state = nullptr, *d_lfe_next = nullptr, *d_lfe_u = nullptr, *d_lfe_y = nullptr;
   size_t lfe_u_floats = 0, lfe_y_floats = 0;
+  // fixed PCM channel stride (cfg.pcm_stride_channels): the kernels pack into d_nat, restride_kernel re-lays
+  uint8_t *d_nat = nullptr;
+  size_t nat_bytes = 0;
 };
 
 namespace {
@@ -569,13 +602,38 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
   }
   const size_t lds = sizeof(float) * ((size_t)(p.out_ch + 2) * kRing + 3 * kChunk + kHead + 4 +
                                       ((b->dmx || b->demix) ? (size_t)kChCount * kChunk : 0));
+  const int sc = b->cfg.pcm_stride_channels;
+  const bool restride = sc > 0 && sc != p.out_ch;
+  const int bps = iamf_hip_format_bytes(p.out_format);
+  if (restride) {  // pack naturally into scratch, then re-lay with the fixed channel stride
+    const size_t per_stream = (size_t)(total > kDelay ? total : kDelay) * p.out_ch * bps;
+    const size_t need = per_stream * (size_t)p.n_streams;
+    if (need > b->nat_bytes) {
+      HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(a.stream)));
+      (void)hipFree(b->d_nat);
+      b->d_nat = nullptr;
+      b->nat_bytes = 0;
+      HIPCHK(hipMalloc(&b->d_nat, need));
+      b->nat_bytes = need;
+    }
+    p.pcm = b->d_nat;
+    p.pcm_stream_stride = (int64_t)per_stream;
+  }
   const int r = launch(p, m_eff, lds, static_cast<hipStream_t>(a.stream));
   if (r != IAMF_HIP_OK) return r;
   if (b->fir && p.in) b->fir_cur ^= 1;
   const int64_t before = p.limiter_on ? (b->pos > kDelay ? b->pos - kDelay : 0) : b->pos;
   b->pos += total;
   const int64_t after = p.limiter_on ? (b->pos > kDelay ? b->pos - kDelay : 0) : b->pos;
-  return (int)(after - before);
+  const int n_emit = (int)(after - before);
+  if (restride && n_emit > 0) {
+    const int64_t n_out = (int64_t)n_emit * sc + (p.out_ch > sc ? p.out_ch - sc : 0);
+    hipLaunchKernelGGL(restride_kernel, dim3((unsigned)((n_out + 255) / 256), (unsigned)p.n_streams), dim3(256), 0,
+                       static_cast<hipStream_t>(a.stream), b->d_nat, p.pcm_stream_stride,
+                       static_cast<uint8_t *>(a.d_pcm), a.pcm_stream_stride_bytes, n_emit, p.out_ch, sc, bps);
+    HIPCHK(hipGetLastError());
+  }
+  return n_emit;
 }
 
 // feed-major copy of a renderer matrix and its output-slot map (h2m_rdr.c:1114-1150 keeps the
@@ -611,6 +669,11 @@ int iamf_hip_get_h2m_matrix(int order, int out_id, iamf_hip_matrix *out) {
 
 int iamf_hip_get_m2m_matrix(int in_id, int out_id, iamf_hip_matrix *out) {
   return find_matrix(IAMF_HIP_KIND_M2M, in_id, out_id, out);
+}
+
+int iamf_hip_get_m2m_matrix_variant(int variant, int in_id, int out_id, iamf_hip_matrix *out) {
+  if (variant != IAMF_HIP_VARIANT_DEFAULT && variant != IAMF_HIP_VARIANT_SAMSUNG_TV) return -1;
+  return find_matrix(IAMF_HIP_KIND_M2M, in_id, out_id, out, variant == IAMF_HIP_VARIANT_SAMSUNG_TV);
 }
 
 int iamf_hip_layout_channels(int out_id) {
@@ -662,7 +725,8 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
   if (cfg->n_streams <= 0 || cfg->frame_size <= 0 || cfg->sample_rate <= 0 || (!dmx && !mx.mat) ||
       mx.m <= 0 || mx.m > kMaxIn || mx.n <= 0 || mx.n > kMaxOut || cfg->out_channels <= 0 ||
       cfg->out_channels > kMaxOut || !iamf_hip_format_bytes(cfg->out_format) || cfg->projection < 0 ||
-      cfg->projection > IAMF_HIP_PROJ_MFMA || (dmx && cfg->out_channels != mx.n))
+      cfg->projection > IAMF_HIP_PROJ_MFMA || (dmx && cfg->out_channels != mx.n) || cfg->pcm_stride_channels < 0 ||
+      cfg->pcm_stride_channels > 64)
     return IAMF_HIP_ERR_BAD_ARG;
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
@@ -832,6 +896,7 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_lfe_next);
   (void)hipFree(b->d_lfe_u);
   (void)hipFree(b->d_lfe_y);
+  (void)hipFree(b->d_nat);
   (void)hipFree(b->d_matrix2);
   (void)hipFree(b->d_gains2);
   (void)hipFree(b->d_src_feed2);
@@ -866,7 +931,9 @@ int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *a) {
     total = a->n_samples;
   }
   if (total > INT32_MAX) return IAMF_HIP_ERR_BAD_ARG;
-  const int64_t need = total * b->cfg.out_channels * iamf_hip_format_bytes(b->cfg.out_format);
+  const int sc = b->cfg.pcm_stride_channels > 0 ? b->cfg.pcm_stride_channels : b->cfg.out_channels;
+  const int64_t need = (total * sc + (b->cfg.out_channels > sc ? b->cfg.out_channels - sc : 0)) *
+                       iamf_hip_format_bytes(b->cfg.out_format);
   if (b->cfg.n_streams > 1 && a->pcm_stream_stride_bytes < need) return IAMF_HIP_ERR_BUFFER_TOO_SMALL;
   return render_call(b, *a, (int)total);
 }

@@ -36,7 +36,7 @@ class BatchConfig(C.Structure):
                 ("out_channels", C.c_int32), ("out_format", C.c_int32), ("matrix", Matrix),
                 ("limiter_enable", C.c_int32), ("limiter_threshold_db", C.c_float),
                 ("loudness_enable", C.c_int32), ("projection", C.c_int32), ("fir_taps", C.c_int32), ("lfe_hoa", C.c_int32),
-                ("reserved", C.c_int32 * 4)]
+                ("pcm_stride_channels", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class DmxState(C.Structure):
@@ -101,6 +101,7 @@ def lib():
         L = C.CDLL(path)
         L.iamf_hip_get_h2m_matrix.argtypes = [C.c_int, C.c_int, C.POINTER(Matrix)]
         L.iamf_hip_get_m2m_matrix.argtypes = [C.c_int, C.c_int, C.POINTER(Matrix)]
+        L.iamf_hip_get_m2m_matrix_variant.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Matrix)]
         L.iamf_hip_layout_channels.argtypes = [C.c_int]
         L.iamf_hip_batch_create.argtypes = [C.POINTER(BatchConfig), C.POINTER(C.c_void_p)]
         L.iamf_hip_batch_destroy.argtypes = [C.c_void_p]
@@ -148,9 +149,10 @@ def get_h2m_matrix(order, out_id):
     return m
 
 
-def get_m2m_matrix(in_id, out_id):
+def get_m2m_matrix(in_id, out_id, variant=0):
+    """variant 1 = the tables of the reference's -DSAMSUNG_TV build"""
     m = Matrix()
-    if lib().iamf_hip_get_m2m_matrix(in_id, out_id, C.byref(m)) != 0:
+    if lib().iamf_hip_get_m2m_matrix_variant(variant, in_id, out_id, C.byref(m)) != 0:
         raise KeyError((hex(in_id), hex(out_id)))
     return m
 
@@ -193,7 +195,7 @@ class Batch:
 
     def __init__(self, n_streams, matrix, out_channels, frame_size=1024, sample_rate=48000,
                  out_format=FMT_S16, limiter=True, threshold_db=-1.0, loudness=False, projection=PROJ_AUTO, fir_taps=0,
-                 lfe_hoa=False):
+                 lfe_hoa=False, pcm_stride_channels=0):
         cfg = BatchConfig()
         cfg.n_streams = n_streams
         cfg.frame_size = frame_size
@@ -207,6 +209,7 @@ class Batch:
         cfg.projection = projection
         cfg.fir_taps = fir_taps
         cfg.lfe_hoa = 1 if lfe_hoa else 0
+        cfg.pcm_stride_channels = pcm_stride_channels
         self.cfg = cfg
         self.bytes_per_sample = lib().iamf_hip_format_bytes(out_format)
         h = C.c_void_p()

@@ -86,6 +86,12 @@ typedef struct {
 int iamf_hip_get_h2m_matrix(int order, int out_id, iamf_hip_matrix *out);
 /* replaces IAMF_element_renderer_get_M2M_matrix, src/iamf_dec/m2m_rdr.c:1786 (0 or -1) */
 int iamf_hip_get_m2m_matrix(int in_id, int out_id, iamf_hip_matrix *out);
+/* The reference has two sets of layout->layout tables, chosen at build time: m2m_rdr.c:36-830 under
+ * -DSAMSUNG_TV (the upstream default, CMakeLists.txt:14-19) and :831-1628 otherwise; 47 of the 140
+ * matrices differ.  This library carries both; iamf_hip_get_m2m_matrix is VARIANT_DEFAULT (= the
+ * -DSAMSUNG_TV=OFF build).  The HOA tables are the same in both builds. */
+enum { IAMF_HIP_VARIANT_DEFAULT = 0, IAMF_HIP_VARIANT_SAMSUNG_TV = 1 };
+int iamf_hip_get_m2m_matrix_variant(int variant, int in_id, int out_id, iamf_hip_matrix *out);
 /* channels of an output layout by rendering id (IAMF_decoder.c:3998-4008); 0 if unknown */
 int iamf_hip_layout_channels(int out_id);
 
@@ -114,7 +120,15 @@ typedef struct {
                               ambisonics channel 0, scaled by 1/sqrt(n)), as a reference built with its
                               switch -DDISABLE_LFE_HOA=0 does (call site IAMF_decoder.c:2625-2636);
                               0 = the default build's silence (ae_rdr.h:63-65) */
-  int32_t reserved[4];
+  int32_t pcm_stride_channels; /* 0 = out_channels.  Otherwise the PCM is laid out as
+                              iamf_decoder_plane2stride_out does with that `stride` (IAMF_decoder.c:121-167): the
+                              -DSAMSUNG_TV build always passes SAMSUNG_SPECIFIC_CHANNELS = 12 (:3492-3495,
+                              IAMF_defines.h:211-213) — sample-frame i starts at element 12 i, slots beyond
+                              out_channels are zero, and for layouts of more than 12 channels the surplus
+                              channels overwrite the following sample-frame exactly as the reference's loop
+                              does.  A stream then needs (n * stride + max(0, out_channels - stride)) samples
+                              of room per call. */
+  int32_t reserved[3];
 } iamf_hip_batch_config;
 
 /* Creates device state for cfg->n_streams streams on the CURRENT HIP device.  Synchronous.
@@ -309,6 +323,11 @@ const char *iamf_hip_version(void);
  * the environment has IAMF_HIP_LFE_HOA=1 when the handle is opened.
  * ---------------------------------------------------------------------------------------- */
 int iamf_hip_decoder_set_hoa_lfe(void *decoder_handle, int enable);
+/* Which build of the reference the handle behaves as: IAMF_HIP_VARIANT_SAMSUNG_TV = its tables
+ * (m2m_rdr.c:36-830), 12-channel PCM stride (IAMF_decoder.c:3492-3495,3510-3512), always the top layer of a
+ * scalable element (:1782-1822).  Before IAMF_decoder_configure; default VARIANT_DEFAULT, or SAMSUNG_TV if
+ * the environment has IAMF_HIP_SAMSUNG_TV=1 when the handle is opened. */
+int iamf_hip_decoder_set_variant(void *decoder_handle, int variant);
 
 #ifdef __cplusplus
 }

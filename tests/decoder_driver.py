@@ -6,7 +6,8 @@ import numpy as np
 
 
 def decode_stream(ref, stream_bytes, layout, bit_depth=16, out_rate=0, loudness=0.0, limiter=True,
-               threshold=-1.0):
+               threshold=-1.0, pcm_channels=None):
+    # pcm_channels: channel stride of the PCM the decoder writes (a -DSAMSUNG_TV build: always 12)
     """layout: ('ss', IAMF_SoundSystem enum value) or ('binaural',). Returns (pcm ndarray
     [n][ch] (24-bit: [n][ch][3] bytes), list of per-call return values)."""
     ref.IAMF_decoder_open.restype = C.c_void_p
@@ -38,13 +39,16 @@ def decode_stream(ref, stream_bytes, layout, bit_depth=16, out_rate=0, loudness=
     else:
         ref.IAMF_decoder_output_layout_set_binaural(d)
         ch = 2
+    ch_layout = ch
+    if pcm_channels:
+        ch = pcm_channels
     ref.IAMF_decoder_set_pts(d, 0, 90000)
     rsize = C.c_uint32(0)
     r = ref.IAMF_decoder_configure(d, stream_bytes, len(stream_bytes), C.byref(rsize))
     assert r == 0, "configure failed: %d" % r
     used = rsize.value
     bps = bit_depth // 8
-    pcm = C.create_string_buffer(bps * 6144 * 6 * ch)
+    pcm = C.create_string_buffer(bps * 6144 * 6 * max(ch, ch_layout))
     chunks, rets = [], []
     while used < len(stream_bytes):
         rsize.value = 0

@@ -61,6 +61,10 @@ int iamf_hip_get_h2m_matrix(int order, int out_id, iamf_hip_matrix *mx) {
 int iamf_hip_get_m2m_matrix(int in_id, int out_id, iamf_hip_matrix *mx) {
   return fill_matrix(IAMF_HIP_KIND_M2M, iamf_hip_layout_channels(in_id), out_id, mx);
 }
+int iamf_hip_get_m2m_matrix_variant(int v, int in_id, int out_id, iamf_hip_matrix *mx) {
+  (void)v;
+  return iamf_hip_get_m2m_matrix(in_id, out_id, mx);
+}
 int iamf_hip_format_bytes(int f) { return f == 16 ? 2 : f == 24 ? 3 : (f == 32 || f == -32) ? 4 : 0; }
 
 int iamf_hip_batch_create(const iamf_hip_batch_config *c, iamf_hip_batch **out) {
@@ -83,7 +87,9 @@ static int emit(iamf_hip_batch *b, void *pcm, int64_t cap, int n) {
   int skip = n < b->pad_left ? n : b->pad_left;
   b->pad_left -= skip;
   n -= skip;
-  int64_t need = (int64_t)n * b->cfg.out_channels * iamf_hip_format_bytes(b->cfg.out_format);
+  const int sc = b->cfg.pcm_stride_channels > 0 ? b->cfg.pcm_stride_channels : b->cfg.out_channels;
+  int64_t need = ((int64_t)n * sc + (n > 0 && b->cfg.out_channels > sc ? b->cfg.out_channels - sc : 0)) *
+                 iamf_hip_format_bytes(b->cfg.out_format);
   if (need > cap) return IAMF_HIP_ERR_BAD_ARG;
   memset(pcm, 0, (size_t)need); /* a real write: ASan checks the "device" buffer the facade sized */
   return n;

@@ -196,3 +196,32 @@ def test_lfe_e2e_through_the_oracle_stream(golden):
         y = O.stream_run(mx, O.OUT_CH[oid], xq, c["fs"], bit_depth=c["bit_depth"], lfe_rate=rate)
         assert y.shape == want.shape, (name, y.shape, want.shape)
         assert np.array_equal(y, want), name
+
+
+def test_tv_table_blob_is_what_the_tv_reference_returns():
+    """iac_amd/data/rdr_tables_tv.bin = oracle/dump_tables.c linked against the reference built -DSAMSUNG_TV
+    (checked where that build exists: the authoring container); everywhere: same index as the default blob,
+    HOA tables identical, 47 layout->layout matrices different"""
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(p):
+        b = open(p, "rb").read()
+        assert b[:8] == b"IARDRTB1"
+        n = struct.unpack("<I", b[8:12])[0]
+        ents = [struct.unpack("<3I5iI", b[12 + 36 * i:12 + 36 * (i + 1)]) for i in range(n)]
+        data = np.frombuffer(b[12 + 36 * n:], dtype=np.float32)
+        return {(e[0], e[1], e[2]): (e[3:8], data[e[8]:e[8] + e[6] * e[7]]) for e in ents}
+
+    dflt = load(os.path.join(root, "iac_amd", "data", "rdr_tables.bin"))
+    tv = load(os.path.join(root, "iac_amd", "data", "rdr_tables_tv.bin"))
+    assert set(dflt) == set(tv) and len(tv) == 196
+    diff = [k for k in dflt if dflt[k][0] != tv[k][0] or not np.array_equal(dflt[k][1], tv[k][1])]
+    assert all(k[0] == 1 for k in diff) and len(diff) == 47
+    tool = os.path.join(root, "oracle", "_ref_tv", "dump_tables_tv")
+    if os.path.exists(tool) and os.path.isdir("/root/reference"):
+        out = os.path.join("/tmp", "rdr_tables_tv_check.bin")
+        subprocess.check_call([tool, out], stderr=subprocess.DEVNULL)
+        assert open(out, "rb").read() == open(os.path.join(root, "iac_amd", "data", "rdr_tables_tv.bin"), "rb").read()
