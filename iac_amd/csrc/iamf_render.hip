@@ -41,6 +41,8 @@
 
 #include "../../include/iamf_hip.h"
 
+extern "C" int iamf_hip_fir_m2b_has(int m);                                           // iamf_render_fir_m2b.hip
+extern "C" int iamf_hip_fir_m2b_launch(const void *params, int m, hipStream_t st);    // iamf_render_fir_m2b.hip
 extern "C" int iamf_hip_wide4_has_mix(int m, int c);                                  // iamf_render_wide4_mix.hip
 extern "C" int iamf_hip_wide4_mix_launch(const void *params, int m, hipStream_t st);  // iamf_render_wide4_mix.hip
 extern "C" int iamf_hip_wide4_has_downmixer(int m, int c);                            // iamf_render_wide4.hip
@@ -411,7 +413,8 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
       case 4: launch_fir_m<4>(p, grid, st); break;
       case 9: launch_fir_m<9>(p, grid, st); break;
       case 16: launch_fir_m<16>(p, grid, st); break;
-      default: return IAMF_HIP_ERR_UNIMPLEMENTED;
+      default:  // channel-based elements (M2B): the loudspeaker layouts' channel counts
+        if (!iamf_hip_fir_m2b_launch(&p, m, st)) return IAMF_HIP_ERR_UNIMPLEMENTED;
     }
     HIPCHK(hipGetLastError());
     return IAMF_HIP_OK;
@@ -715,7 +718,8 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
   const bool dmx = mx.kind == IAMF_HIP_KIND_DMX;
   const bool fir = mx.kind == IAMF_HIP_KIND_FIR;
   if (fir && (cfg->fir_taps < 1 || cfg->fir_taps > 256 || mx.n != 2 || cfg->out_channels != 2 ||
-              !cfg->limiter_enable || (mx.m != 1 && mx.m != 4 && mx.m != 9 && mx.m != 16)))
+              !cfg->limiter_enable ||
+              (mx.m != 1 && mx.m != 4 && mx.m != 9 && mx.m != 16 && !iamf_hip_fir_m2b_has(mx.m))))
     return IAMF_HIP_ERR_BAD_ARG;
   if (dmx) {
     if (!iamf_hip_dmx_valid(mx.in_id, mx.out_id)) return IAMF_HIP_ERR_BAD_ARG;

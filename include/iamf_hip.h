@@ -48,10 +48,14 @@ enum {
 /* element renderer kinds.  DMX = the parametric down-mixer (downmix_renderer.c): matrix.in_id /
  * out_id are IAChannelLayoutType values (IAMF_defines.h:196-209), matrix.mat is unused. */
 enum { IAMF_HIP_KIND_H2M = 0, IAMF_HIP_KIND_M2M = 1, IAMF_HIP_KIND_DMX = 2, IAMF_HIP_KIND_FIR = 3 };
-/* FIR = binaural HRTF convolution of a scene-based element (the role of
- * IAMF_element_renderer_render_H2B, h2b_rdr.c:109-130): matrix.m = ambisonics channels, matrix.n = 2,
- * matrix.mat = HRIRs h[ear][channel][fir_taps] (host), out_channels = 2, limiter on.
- *   y[ear][t] = sum_c sum_k h[ear][c][k] * x[c][t-k]     (f32 MFMA; fir_taps <= 256)
+/* FIR = binaural HRTF convolution: of a scene-based element (the role of
+ * IAMF_element_renderer_render_H2B, h2b_rdr.c:109-130; matrix.m = ambisonics channels 1 / 4 / 9 / 16) or of
+ * a channel-based element (the role of IAMF_element_renderer_render_M2B, m2b_rdr.c:103-121, taken by the
+ * reference when headphones_rendering_mode == 1, IAMF_decoder.c:2562-2570; matrix.m = channels of the
+ * element's loudspeaker layout 2 / 6 / 8 / 10 / 12, playback order, one HRIR pair per loudspeaker — a
+ * zero pair mutes a channel, e.g. the LFE).  matrix.n = 2, matrix.mat = HRIRs h[ear][channel][fir_taps]
+ * (host), out_channels = 2, limiter on.
+ *   y[ear][t] = sum_c sum_k h[ear][c][k] * x[c][t-k]     (MFMA; fir_taps <= 256)
  * PARITY UNPINNED: the reference's binauraliser arithmetic lives in Resonance Audio / BEAR, which
  * are not in the reference tree; this formula is this library's specification. */
 
