@@ -169,6 +169,9 @@ float ease(float x) {
 
 struct iamf_hip_batch {
   iamf_hip_batch_config cfg;
+  int device = 0;                    // the HIP device the batch was created on; every later call must run on it
+  hipStream_t last_stream = nullptr; // stream of the last render / flush: the synchronous setters wait for it
+  bool rendered = false;
   int m = 0, n_feeds = 0;
   int32_t src_feed[kMaxOut];
   uint32_t nz_mask[6] = {0, 0, 0, 0, 0, 0};
@@ -218,6 +221,19 @@ struct iamf_hip_batch {
 
 namespace {
 
+// every entry point that touches device state: the caller's current device must be the batch's
+bool on_batch_device(const iamf_hip_batch *b) {
+  int dev = -1;
+  return hipGetDevice(&dev) == hipSuccess && dev == b->device;
+}
+
+// the setters copy into buffers a queued render may still be reading (renders are asynchronous on the
+// caller's stream, which may be non-blocking with respect to the null stream): wait for that stream first
+int quiesce(iamf_hip_batch *b) {
+  if (b->rendered) HIPCHK(hipStreamSynchronize(b->last_stream));
+  return IAMF_HIP_OK;
+}
+
 int reset_state(iamf_hip_batch *b) {
   const int ns = b->cfg.n_streams;
   std::vector<LimState> init((size_t)ns);
@@ -252,13 +268,11 @@ void launch_m(const RenderParams &p, dim3 grid, size_t lds_bytes, hipStream_t st
 
 template <int M>
 void launch_fir_m(const RenderParams &p, dim3 grid, hipStream_t st) {
-  static bool opted = false;
-  if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-    opted = true;
+  static OptIn opted;
+  if (opted.begin()) {
+    opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 1>), 120 * 1024);
+    opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 2>), 120 * 1024);
+    opted.end();
   }
   // 8 waves either way: render_fir.hpp / render_fir16.hpp
   if (p.fir_h16 && !getenv("IAMF_HIP_FIR_F32")) {
@@ -273,22 +287,18 @@ template <int M>
 void launch_fast_m(const RenderParams &p, dim3 grid, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)fast_lds_floats(p.out_ch, M);
   // more than 64 KiB of dynamic LDS has to be opted into per kernel (gfx950 has 160 KiB per CU)
-  static bool opted = false;
-  if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    opted = true;
+  static OptIn opted;
+  if (opted.begin()) {
+    opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 1>), 80 * 1024);
+    opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 2>), 80 * 1024);
+    opted.end();
   }
   if (p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp) {  // the mixing variant
-    static bool opted2 = false;
-    if (!opted2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 1, 0, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 0, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      opted2 = true;
+    static OptIn opted2;
+    if (opted2.begin()) {
+      opted2.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 1, 0, false, true>), 80 * 1024);
+      opted2.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 0, false, true>), 80 * 1024);
+      opted2.end();
     }
     if (p.out_ch == 1)
       hipLaunchKernelGGL((render_fast_kernel<M, 1, 0, false, true>), grid, dim3(256), lds, st, p);
@@ -306,11 +316,10 @@ void launch_fast_m(const RenderParams &p, dim3 grid, hipStream_t st) {
 template <int M, int OC>
 void launch_fast_down_mc(const RenderParams &p, dim3 grid, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)fast_lds_floats(OC, M);
-  static bool opted = false;
-  if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, OC, 0, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    opted = true;
+  static OptIn opted;
+  if (opted.begin()) {
+    opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, OC, 0, true>), 80 * 1024);
+    opted.end();
   }
   hipLaunchKernelGGL((render_fast_kernel<M, OC, 0, true>), grid, dim3(256), lds, st, p);
 }
@@ -327,13 +336,11 @@ bool launch_fast_down(const RenderParams &p, int m, dim3 grid, hipStream_t st) {
 template <int M>
 void launch_wide_m(const RenderParams &p, dim3 grid, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)wide_lds_floats(p.out_ch, M);
-  static bool opted = false;
-  if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide_kernel<M, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide_kernel<M, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    opted = true;
+  static OptIn opted;
+  if (opted.begin()) {
+    opted.set(reinterpret_cast<const void *>(&render_wide_kernel<M, false>), 80 * 1024);
+    opted.set(reinterpret_cast<const void *>(&render_wide_kernel<M, true>), 80 * 1024);
+    opted.end();
   }
   if (p.use_mfma)
     hipLaunchKernelGGL((render_wide_kernel<M, true>), grid, dim3(256), lds, st, p);
@@ -467,6 +474,9 @@ const int kLayoutSurround[9] = {1, 2, 5, 5, 5, 7, 7, 7, 3};
 const int kLayoutTop[9] = {0, 0, 0, 2, 4, 0, 2, 4, 2};
 
 int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
+  if (!on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
+  b->last_stream = static_cast<hipStream_t>(a.stream);
+  b->rendered = true;
   RenderParams p;
   memset(&p, 0, sizeof(p));
   p.in = a.d_in;
@@ -739,6 +749,10 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
   iamf_hip_batch *b = new (std::nothrow) iamf_hip_batch();
   if (!b) return IAMF_HIP_ERR_ALLOC_FAIL;
   b->cfg = *cfg;
+  if (hipGetDevice(&b->device) != hipSuccess) {
+    delete b;
+    return IAMF_HIP_ERR_DEVICE;
+  }
   b->m = mx.m;
   b->n_feeds = mx.n;
   b->dmx = dmx;
@@ -881,6 +895,16 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
 
 void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   if (!b) return;
+  int cur = -1;   // free on the batch's own device whatever is current, and restore
+  const bool sw = hipGetDevice(&cur) == hipSuccess && cur != b->device && hipSetDevice(b->device) == hipSuccess;
+  struct Restore {
+    bool on;
+    int dev;
+    ~Restore() {
+      if (on) (void)hipSetDevice(dev);
+    }
+  } restore{sw, cur};
+  if (b->rendered) (void)hipStreamSynchronize(b->last_stream);
   (void)hipFree(b->d_matrix_pre);
   (void)hipFree(b->d_matrix);
   (void)hipFree(b->d_gains);
@@ -909,6 +933,11 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
 
 int iamf_hip_batch_set_gains(iamf_hip_batch *b, const float *eg, const float *og, const float *lg) {
   if (!b) return IAMF_HIP_ERR_BAD_ARG;
+  if (!on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
+  {  // a render queued earlier may still be reading d_gains
+    const int q = quiesce(b);
+    if (q != IAMF_HIP_OK) return q;
+  }
   const int ns = b->cfg.n_streams;
   if (eg) memcpy(&b->h_gains[0], eg, sizeof(float) * ns);
   if (og) memcpy(&b->h_gains[(size_t)ns], og, sizeof(float) * ns);
@@ -973,6 +1002,7 @@ int iamf_hip_batch_flush(iamf_hip_batch *b, void *d_pcm, int64_t pcm_stream_stri
 }
 
 int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *mx, const float *g2) {
+  if (b && !on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
   if (!b || !mx || !mx->mat || mx->m <= 0 || mx->m > kMaxIn || mx->n <= 0 || mx->n > kMaxOut ||
       mx->kind == IAMF_HIP_KIND_DMX || b->pos != 0)
     return IAMF_HIP_ERR_BAD_ARG;
@@ -1000,6 +1030,7 @@ int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *
 }
 
 int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *matrix, int l_in) {
+  if (b && !on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
   if (!b || !matrix || l_in <= 0 || l_in > kMaxIn || b->pos != 0 || b->dmx || b->fir) return IAMF_HIP_ERR_BAD_ARG;
   (void)hipFree(b->d_pre);
   b->d_pre = nullptr;
@@ -1044,6 +1075,7 @@ int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *matrix, int l_
 /* ---- demixer of scalable channel audio (reference src/iamf_dec/demixer.c) ---- */
 
 int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *c) {
+  if (b && !on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
   if (!b || !c || b->pos != 0 || b->fir || b->d_pre) return IAMF_HIP_ERR_BAD_ARG;
   if (c->layout < 0 || c->layout > 8 || c->n_in != kLayoutCount[c->layout] || c->n_in != b->m ||
       c->n_gain < 0 || c->n_gain > 12)
@@ -1263,6 +1295,7 @@ void iamf_hip_dmx_coefficients(const iamf_hip_dmx_state *st, float out[5]) {
 
 int iamf_hip_batch_reset(iamf_hip_batch *b) {
   if (!b) return IAMF_HIP_ERR_BAD_ARG;
+  if (!on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
   HIPCHK(hipDeviceSynchronize());
   return reset_state(b);
 }

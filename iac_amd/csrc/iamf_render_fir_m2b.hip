@@ -25,13 +25,11 @@ namespace {
 
 template <int M>
 void launch_fir_m(const RenderParams &p, hipStream_t st) {
-  static bool opted = false;
-  if (!opted) {
-    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 1>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 2>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-    opted = e1 == hipSuccess && e2 == hipSuccess;
+  static OptIn opted;
+  if (opted.begin()) {
+    opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 1>), 120 * 1024);
+    opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 2>), 120 * 1024);
+    opted.end();
   }
   const dim3 grid((unsigned)p.n_streams);
   if (p.fir_h16 && !getenv("IAMF_HIP_FIR_F32")) {

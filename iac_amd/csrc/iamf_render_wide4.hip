@@ -20,13 +20,11 @@ namespace {
 template <int M, int C>
 void launch_mc(const RenderParams &p, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M, 0);
-  static bool opted = false;
-  if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, true, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    opted = true;
+  static OptIn opted;
+  if (opted.begin()) {
+    opted.set(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, false>), 80 * 1024);
+    opted.set(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, true, false>), 80 * 1024);
+    opted.end();
   }
   if (p.use_mfma)
     hipLaunchKernelGGL((render_wide4_kernel<M, C, true, false>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
@@ -39,11 +37,10 @@ template <int M, int C>
 void launch_mc_demixer(const RenderParams &p, hipStream_t st) {
   static_assert(wide4_lds_floats(C, M, kW4DmxFloats) <= 20480, "two workgroups per CU");
   const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M, kW4DmxFloats);
-  static bool opted = false;
-  if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    opted = true;
+  static OptIn opted;
+  if (opted.begin()) {
+    opted.set(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, true>), 80 * 1024);
+    opted.end();
   }
   hipLaunchKernelGGL((render_wide4_kernel<M, C, false, true>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
 }
@@ -52,11 +49,10 @@ void launch_mc_demixer(const RenderParams &p, hipStream_t st) {
 template <int M, int C>
 void launch_mc_downmixer(const RenderParams &p, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M, 0);
-  static bool opted = false;
-  if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    opted = true;
+  static OptIn opted;
+  if (opted.begin()) {
+    opted.set(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, false, true>), 80 * 1024);
+    opted.end();
   }
   hipLaunchKernelGGL((render_wide4_kernel<M, C, false, false, true>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
 }

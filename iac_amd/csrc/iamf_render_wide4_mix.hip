@@ -22,13 +22,11 @@ template <int M, int C>
 void launch_mc(const RenderParams &p, hipStream_t st) {
   static_assert(wide4_lds_floats(C, M, kW4MixFloats) <= 20480, "two workgroups per CU");
   const size_t lds = sizeof(float) * (size_t)wide4_lds_floats(C, M, kW4MixFloats);
-  static bool opted = false;
-  if (!opted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, false, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, true, false, false, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    opted = true;
+  static OptIn opted;
+  if (opted.begin()) {
+    opted.set(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, false, false, true>), 80 * 1024);
+    opted.set(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, true, false, false, true>), 80 * 1024);
+    opted.end();
   }
   if (p.use_mfma)
     hipLaunchKernelGGL((render_wide4_kernel<M, C, true, false, false, true>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);

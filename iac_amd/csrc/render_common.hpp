@@ -10,6 +10,25 @@ constexpr int kHead = 256;       // coefficient-table head kept in LDS
 constexpr int kMaxOut = 24;      // reference MAX_OUTPUT_CHANNELS
 constexpr int kMaxIn = 24;
 
+// Opting a kernel into more than 64 KiB of dynamic LDS is a PER-DEVICE attribute: one flag per device
+// ordinal, set only when every hipFuncSetAttribute of the group succeeded (a failed opt-in is retried
+// and surfaces as a launch error instead of being remembered as done).
+constexpr int kMaxDevices = 64;
+struct OptIn {
+  bool done[kMaxDevices] = {};
+  bool ok = true;
+  int dev = 0;
+  bool begin() {  // true if this device still has to opt in
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    ok = true;
+    return !done[dev];
+  }
+  void set(const void *fn, int bytes) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) ok = false;
+  }
+  void end() { done[dev] = ok; }
+};
+
 struct LimState {  // per stream, persisted in HBM between calls
   float g;   // currentGain
   float gs;  // targetStartGain

@@ -61,7 +61,8 @@ enum { IAMF_HIP_KIND_H2M = 0, IAMF_HIP_KIND_M2M = 1, IAMF_HIP_KIND_DMX = 2, IAMF
 
 /* Projection arithmetic for output layouts wider than stereo.
  *   EXACT: VALU, separate f32 multiply and add in the reference's order -> bit-identical PCM.
- *   MFMA : v_mfma_f32_32x32x2_f32 (exact f32 products, fused k-ordered accumulation) -> PCM within
+ *   MFMA : v_mfma_f32_16x16x4_f32 (render_wide4.hpp; v_mfma_f32_32x32x2_f32 in the fallback render_wide.hpp):
+ *          exact f32 products, fused k-ordered accumulation -> PCM within
  *          +-1 LSB of the reference (rounding ties only).
  *   AUTO : MFMA for the HOA projection (h2m_rdr.c:1103-1112, a dense contraction), EXACT for
  *          channel-layout matrices (m2m_rdr.c:1826-1837) and always for mono/stereo/binaural. */
@@ -136,6 +137,8 @@ typedef struct {
 } iamf_hip_batch_config;
 
 /* Creates device state for cfg->n_streams streams on the CURRENT HIP device.  Synchronous.
+ * The batch remembers that device: every later call on it (setters, render, flush, reset) returns
+ * IAMF_HIP_ERR_INVALID_STATE unless the same device is current; destroy switches to it and back.
  * Replaces, per stream: iamf_stream_renderer_open (IAMF_decoder.c:2480),
  * audio_effect_peak_limiter_create/_init (audio_effect_peak_limiter.c:50,73). */
 int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out);
@@ -144,7 +147,8 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b);
 /* Per-stream linear gains (host arrays of n_streams floats, NULL = leave unchanged):
  * element mix gain and output mix gain as iamf_frame_gain applies a constant gain
  * (IAMF_decoder.c:1392-1397: only if != 1 and > 0), and the loudness gain
- * db2lin(target - loudness) of iamf_loudness_process (IAMF_decoder.c:3206-3221).  Synchronous. */
+ * db2lin(target - loudness) of iamf_loudness_process (IAMF_decoder.c:3206-3221).  Synchronous, and ordered after the renders already queued: it
+ * first waits for the stream of the batch's last render / flush call. */
 int iamf_hip_batch_set_gains(iamf_hip_batch *b, const float *element_gain,
                              const float *output_gain, const float *loudness_gain);
 
