@@ -75,7 +75,8 @@ class DemixFrame(C.Structure):
 
 
 def lib_path():
-    return os.path.join(ROOT, "iac_amd", "lib", "libiamf_hip.so")
+    # IAMF_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one box)
+    return os.environ.get("IAMF_HIP_LIB") or os.path.join(ROOT, "iac_amd", "lib", "libiamf_hip.so")
 
 
 def build(force=False):
