@@ -148,171 +148,6 @@ __device__ __forceinline__ int limiter_wave(const float *arr_p, float *arr_g,
   return b;
 }
 
-// ---- the same recurrence with FOUR consecutive samples per lane (256-sample blocks) ----
-// What bounds a programme that keeps the limiter busy is the trigger-run chain: g[k] = g[k-1] -
-// a1 * (g[k-1] - e[k-1]), three dependent f32 operations per sample that only a lane shift can
-// parallelise (Jacobi sweeps, limiter_wave above).  A DPP read of a register the previous VALU
-// instruction wrote needs two wait states, and with one sample per lane every sweep pays them:
-// 20.6 cycles per sample against 13.0 for the three operations alone (tools/sweep_probe.hip).  Here a
-// lane owns samples 4l..4l+3 of a 256-sample block: a sweep is twelve dependent operations, ONE lane
-// crossing (the first sample takes lane l-1's last) and one pair of wait states = 58.3 cycles per four
-// samples, 14.6 per sample.  Everything else is limiter_wave: ballot-driven speculation "no trigger
-// from position l0 on", the run assumption, fixed points for what is already settled (a settled
-// position keeps G = gs and takes e' = gs, so G - a1 * (G - e') == G exactly), and every accepted gain
-// is produced by the reference's own f32 operations.  arr_p / arr_g: the chunk's window maxima and
-// gains, cnt = valid samples of the chunk (a multiple of 64; positions past it never trigger).
-// Returns the first 256-block NOT processed (stop_clean: the walk ends behind the first block after b0
-// in which nothing triggered).
-__device__ __forceinline__ float sel4(float a, float b, float c, float d, int j) {  // j wave-uniform
-  return j == 0 ? a : (j == 1 ? b : (j == 2 ? c : d));
-}
-template <typename Lookup>
-__device__ __forceinline__ int limiter_wave4(const float *arr_p, float *arr_g, Lookup ctab, int b0, int cnt, int &n,
-                                             float &gs, float &ge, float &g_last, float thr, int n_atk, int n_end,
-                                             bool stop_clean = false) {
-  const int lane = threadIdx.x & 63;
-  const int nblk = (cnt + 255) >> 8;
-  __builtin_amdgcn_s_setprio(3);
-  const float a1 = ctab(1);  // attack-curve value one step after a trigger
-  float ga[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-  int b = b0;
-  int last_lim = 256;
-  for (; b < nblk; ++b) {
-    const int lim = cnt - 256 * b < 256 ? cnt - 256 * b : 256;  // valid positions of this block (multiple of 64)
-    last_lim = lim;
-    float pk[4], e[4];
-    {
-      const float4 pv = *reinterpret_cast<const float4 *>(&arr_p[256 * b + 4 * lane]);
-      const bool in = 4 * lane < lim;
-      pk[0] = in ? pv.x : 0.f;
-      pk[1] = in ? pv.y : 0.f;
-      pk[2] = in ? pv.z : 0.f;
-      pk[3] = in ? pv.w : 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) e[j] = thr / pk[j];  // targetEndGain if this sample triggers (IEEE division)
-    }
-    const float e3s = dpp_wave_shr1(e[3]);  // e of the sample in front of the lane's first one
-    int l0 = 0;
-    bool clean = true;
-    while (true) {
-      // speculate: no trigger at positions l0..255 given the state before position l0
-      float g[4];
-      int fj = 4;
-#pragma unroll
-      for (int j = 3; j >= 0; --j) {
-        const int pos = 4 * lane + j;
-        int n_pre = n + (pos - l0);
-        n_pre = n_pre < n_end ? n_pre : n_end;
-        n_pre = n_pre < 0 ? 0 : n_pre;
-        const int ci = n_pre + 1 < n_end ? n_pre + 1 : n_end;
-        g[j] = gain_at(n_pre, gs, ge, ctab(ci), n_atk, n_end);
-        if (pos >= l0 && pk[j] * g[j] > thr) fj = j;
-      }
-      const unsigned long long mask = __ballot(fj < 4);
-      if (mask == 0ull) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (4 * lane + j >= l0) ga[j] = g[j];
-        n = n + (lim - l0) < n_end ? n + (lim - l0) : n_end;
-        break;
-      }
-      clean = false;
-      const int fl = __builtin_ctzll(mask);
-      const int fjv = __builtin_amdgcn_readlane(fj, fl);
-      const int f = 4 * fl + fjv;  // first trigger: positions l0..f are settled
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * lane + j >= l0 && 4 * lane + j <= f) ga[j] = g[j];
-      gs = sel4(readlane_f(g[0], fl), readlane_f(g[1], fl), readlane_f(g[2], fl), readlane_f(g[3], fl), fjv);
-      ge = sel4(readlane_f(e[0], fl), readlane_f(e[1], fl), readlane_f(e[2], fl), readlane_f(e[3], fl), fjv);
-      n = 0;
-      l0 = f + 1;
-      if (l0 >= lim) break;
-
-      // the run: assume every later position's predecessor triggered
-      float G0 = gs, G1 = gs, G2 = gs, G3 = gs;
-      const float E0 = 4 * lane + 0 <= f ? gs : e3s;
-      const float E1 = 4 * lane + 1 <= f ? gs : e[0];
-      const float E2 = 4 * lane + 2 <= f ? gs : e[1];
-      const float E3 = 4 * lane + 3 <= f ? gs : e[2];
-      // One sweep: G0 <- shr(G3) - a1 * (shr(G3) - E0), then G1..G3 from their own lane.  Lane fl is final
-      // after the first sweep, lane fl + s after sweep s + 1; sweeps beyond that change nothing.  Lane 0 has no
-      // source lane: its DPP instructions are skipped and G0 keeps gs (position 0 is never inside a run
-      // that started in this block, f >= 0).
-      for (int it = fl; it < 64; it += 4) {
-        float tmp;
-#define IAMF_SWEEP4                                                               \
-  "s_nop 1\n\t"                                                                   \
-  "v_sub_f32_dpp %[t], %[g3], %[e0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"    \
-  "v_mul_f32_e32 %[t], %[a1], %[t]\n\t"                                           \
-  "v_sub_f32_dpp %[g0], %[g3], %[t] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"    \
-  "v_sub_f32_e32 %[t], %[g0], %[e1]\n\t"                                          \
-  "v_mul_f32_e32 %[t], %[a1], %[t]\n\t"                                           \
-  "v_sub_f32_e32 %[g1], %[g0], %[t]\n\t"                                          \
-  "v_sub_f32_e32 %[t], %[g1], %[e2]\n\t"                                          \
-  "v_mul_f32_e32 %[t], %[a1], %[t]\n\t"                                           \
-  "v_sub_f32_e32 %[g2], %[g1], %[t]\n\t"                                          \
-  "v_sub_f32_e32 %[t], %[g2], %[e3]\n\t"                                          \
-  "v_mul_f32_e32 %[t], %[a1], %[t]\n\t"                                           \
-  "v_sub_f32_e32 %[g3], %[g2], %[t]\n\t"
-        asm volatile(IAMF_SWEEP4 IAMF_SWEEP4 IAMF_SWEEP4 IAMF_SWEEP4
-                     : [g0] "+v"(G0), [g1] "+v"(G1), [g2] "+v"(G2), [g3] "+v"(G3), [t] "=&v"(tmp)
-                     : [e0] "v"(E0), [e1] "v"(E1), [e2] "v"(E2), [e3] "v"(E3), [a1] "v"(a1));
-#undef IAMF_SWEEP4
-        // Early exit.  Lanes fl .. it + 3 are final now.  A run ends where the window maximum drops (the
-        // peak leaves the look-ahead), and from there on the positions computed under the run assumption
-        // keep failing the trigger test, so testing each final lane's LAST sample finds the end within a
-        // lane or two.  Only an optimisation: which positions are accepted is decided by the exact test of
-        // every position below; stopping early (or late) changes the number of sweeps, not a single value.
-        const int done = it + 4 < 64 ? it + 4 : 64;  // lanes fl .. done - 1 are final
-        const unsigned long long settled = (done >= 64 ? ~0ull : ((1ull << done) - 1ull)) & ~((1ull << fl) - 1ull);
-        if (__ballot(!(pk[3] * G3 > thr)) & settled) break;
-      }
-      const float Gv[4] = {G0, G1, G2, G3};
-      int mj = 4;  // first position of the run in this lane that does NOT trigger (positions past lim never do)
-#pragma unroll
-      for (int j = 3; j >= 0; --j)
-        if (4 * lane + j > f && !(pk[j] * Gv[j] > thr)) mj = j;
-      const unsigned long long stop = __ballot(mj < 4);
-      int m = 256;
-      if (stop != 0ull) {
-        const int ml = __builtin_ctzll(stop);
-        m = 4 * ml + __builtin_amdgcn_readlane(mj, ml);
-      }
-      if (m >= lim) {  // the run reaches the end of the block
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (4 * lane + j > f) ga[j] = Gv[j];
-        const int ll = (lim - 1) >> 2;  // lim is a multiple of 4: the last valid position is sample 3 of lane ll
-        gs = readlane_f(G3, ll);
-        ge = readlane_f(e[3], ll);
-        n = 0;
-        l0 = lim;
-        break;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * lane + j > f && 4 * lane + j <= m) ga[j] = Gv[j];
-      {
-        const int pl = (m - 1) >> 2, pj = (m - 1) & 3;  // position m - 1 (>= f: settled or inside the run)
-        gs = sel4(readlane_f(G0, pl), readlane_f(G1, pl), readlane_f(G2, pl), readlane_f(G3, pl), pj);
-        ge = sel4(readlane_f(e[0], pl), readlane_f(e[1], pl), readlane_f(e[2], pl), readlane_f(e[3], pl), pj);
-      }
-      n = 1;  // position m stepped once from the trigger at m - 1 and did not re-trigger
-      l0 = m + 1;
-      if (l0 >= lim) break;
-    }
-    *reinterpret_cast<float4 *>(&arr_g[256 * b + 4 * lane]) = make_float4(ga[0], ga[1], ga[2], ga[3]);
-    if (stop_clean && clean && b > b0) {
-      ++b;
-      break;
-    }
-  }
-  g_last = readlane_f(ga[3], (last_lim - 1) >> 2);
-  __builtin_amdgcn_s_setprio(0);
-  return b;
-}
-
 // Which of the workgroup's 4 waves runs the serial limiter recurrence.  Workgroups that share a CU
 // tend to reach that phase together; if both ran it on "wave 0" the two dependent chains would
 // sit on the same SIMD and each would get half its issue slots.  Every wave publishes its SIMD
@@ -366,7 +201,7 @@ constexpr int kFIn2 = 4;
 // FIR:  0 = gain matrix; 1 = HRTF stage on the f32 MFMA (render_fir.hpp); 2 = HRTF stage on the f16
 //       MFMA with split operands (render_fir16.hpp)
 template <int M, int OC, int FIR = 0, bool DOWN = false, bool IN2 = false>
-__global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 2) void render_fast_kernel(const RenderParams p) {
+__global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2) void render_fast_kernel(const RenderParams p) {
   static_assert(!(FIR && DOWN), "one renderer");
   static_assert(!(IN2 && (FIR || DOWN)), "the second element joins a matrix-rendered first one");
   extern __shared__ float lds[];
@@ -697,16 +532,16 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 2) void render_fast_kern
         return (d >= 0 && d < kFWin) ? win[d] : head[ci < kFWin ? ci : kFWin - 1];
       }
     };
-    const int nblk = (cnt + 255) >> 8;  // 256-sample blocks of the chain wave (limiter_wave4)
+    const int nblk = cnt >> 6;
     int bs = 0;
     while (true) {
       if (act) {
         int kfirst = kBig;
-        if (4 * t >= 256 * bs) {
+        if (4 * t >= 64 * bs) {
           float gh[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            int np = n_st + (4 * t + j - 256 * bs);
+            int np = n_st + (4 * t + j - 64 * bs);
             np = np < n_end ? np : n_end;
             const int ci = np + 1 < n_end ? np + 1 : n_end;
             gh[j] = gain_at(np, gs, ge, look(ci), n_atk, n_end);
@@ -730,14 +565,14 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 2) void render_fast_kern
       kf = min(kf, __float_as_int(misc[3]));
       if (kf == kBig) {  // the hypothesis holds for the rest of the chunk
         g_cur = misc[8];
-        n_st = n_st + (cnt - 256 * bs) < n_end ? n_st + (cnt - 256 * bs) : n_end;
+        n_st = n_st + (cnt - 64 * bs) < n_end ? n_st + (cnt - 64 * bs) : n_end;
         break;
       }
-      const int b0 = kf >> 8;
+      const int b0 = kf >> 6;
       if (act && wave == cw) {
-        int ln = n_st + 256 * (b0 - bs) < n_end ? n_st + 256 * (b0 - bs) : n_end;
+        int ln = n_st + 64 * (b0 - bs) < n_end ? n_st + 64 * (b0 - bs) : n_end;
         float lgs = gs, lge = ge, lgl = g_cur;
-        const int be = limiter_wave4(arr_p, arr_g, look, b0, cnt, ln, lgs, lge, lgl, thr, n_atk, n_end, true);
+        const int be = limiter_wave(arr_p, arr_g, look, b0, nblk, ln, lgs, lge, lgl, thr, n_atk, n_end, true);
         if (lane == 0) {
           misc[4] = lgl;
           misc[5] = lgs;
@@ -748,7 +583,7 @@ __global__ __launch_bounds__(FIR ? 512 : 256, FIR ? 4 : 2) void render_fast_kern
       }
       __syncthreads();
       const int be = __float_as_int(misc[9]);
-      if (4 * t >= 256 * b0 && 4 * t < 256 * be) g = *reinterpret_cast<const float4 *>(&arr_g[4 * t]);
+      if (4 * t >= 64 * b0 && 4 * t < 64 * be) g = *reinterpret_cast<const float4 *>(&arr_g[4 * t]);
       g_cur = misc[4];
       gs = misc[5];
       ge = misc[6];

@@ -715,15 +715,15 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
         const int d = ci - n_chunk;
         return (d >= 0 && d < kW4Win) ? win[d] : head[ci < kW4Win ? ci : kW4Win - 1];
       };
-      const int nblk = (cnt + 255) >> 8;  // 256-sample blocks of the chain wave (limiter_wave4)
+      const int nblk = cnt >> 6;
       int bs = 0;
       while (true) {
         int kfirst = kBig;
-        if (4 * tv >= 256 * bs) {
+        if (4 * tv >= 64 * bs) {
           float gh[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            int np = n_st + (4 * tv + j - 256 * bs);
+            int np = n_st + (4 * tv + j - 64 * bs);
             np = np < n_end ? np : n_end;
             const int ci = np + 1 < n_end ? np + 1 : n_end;
             gh[j] = gain_at(np, gs, ge, look(ci), n_atk, n_end);
@@ -750,14 +750,14 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
         kf = min(kf, __float_as_int(misc[3]));
         if (kf == kBig) {
           g_cur = misc[8];
-          n_st = n_st + (cnt - 256 * bs) < n_end ? n_st + (cnt - 256 * bs) : n_end;
+          n_st = n_st + (cnt - 64 * bs) < n_end ? n_st + (cnt - 64 * bs) : n_end;
           break;
         }
-        const int b0 = kf >> 8;
+        const int b0 = kf >> 6;
         if (wave == cw) {
-          int ln = n_st + 256 * (b0 - bs) < n_end ? n_st + 256 * (b0 - bs) : n_end;
+          int ln = n_st + 64 * (b0 - bs) < n_end ? n_st + 64 * (b0 - bs) : n_end;
           float lgs = gs, lge = ge, lgl = g_cur;
-          const int be = limiter_wave4(arr_p, arr_g, look, b0, cnt, ln, lgs, lge, lgl, thr, n_atk, n_end, true);
+          const int be = limiter_wave(arr_p, arr_g, look, b0, nblk, ln, lgs, lge, lgl, thr, n_atk, n_end, true);
           if (lane == 0) {
             misc[4] = lgl;
             misc[5] = lgs;
