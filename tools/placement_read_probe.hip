@@ -1,0 +1,57 @@
+// placement_read_probe.hip — is the slow / fast mode of an allocation (tools/placement_probe*.py) visible to a
+// plain streaming read that saturates HBM (grid-stride float4 loads, 2048 workgroups, nothing else)?
+// A large early arena, then fresh 2.1 GB allocations; GB/s of reading 2.1 GB from each.
+//   hipcc --offload-arch=gfx950 -O3 tools/placement_read_probe.hip -o tools/bin/placement_read_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+using v4f = __attribute__((ext_vector_type(4))) float;
+__global__ __launch_bounds__(256) void rd(const v4f *in, float *out, long n4) {
+  float a = 0.f;
+  const long step = (long)gridDim.x * 256 * 4;
+  for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < n4; i += step) {
+    const v4f v0 = __builtin_nontemporal_load(in + i), v1 = __builtin_nontemporal_load(in + i + 256);
+    const v4f v2 = __builtin_nontemporal_load(in + i + 512), v3 = __builtin_nontemporal_load(in + i + 768);
+    a += v0.x + v1.y + v2.z + v3.w;
+  }
+  if (a == 123.456f) out[0] = a;
+}
+
+static double gbs(const v4f *p, float *out, size_t bytes) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int rep = 0; rep < 8; ++rep) {
+    hipEventRecord(e0);
+    rd<<<2048, 256>>>(p, out, (long)(bytes / 16));
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 1 && ms < best) best = ms;
+  }
+  return bytes / best / 1e6;
+}
+
+int main() {
+  const size_t one = (size_t)512 * (64 * 16 * 1024 + 1024) * 4;  // the bench's padded input: 2.15 GB
+  float *out;
+  hipMalloc(&out, 4096);
+  char *arena;
+  hipMalloc(&arena, 12 * one);
+  hipMemset(arena, 0, 12 * one);
+  printf("arena %p:", (void *)arena);
+  for (int k = 0; k < 12; k += 3) printf("  slice %d %.0f GB/s", k, gbs((const v4f *)(arena + k * one), out, one));
+  printf("\n");
+  char *keep[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 12; ++i) {
+    char *p;
+    hipMalloc(&p, one);
+    hipMemset(p, 0, one);
+    printf("fresh %p  %.0f GB/s\n", (void *)p, gbs((const v4f *)p, out, one));
+    hipFree(keep[i & 3]);
+    keep[i & 3] = p;
+  }
+  return 0;
+}
