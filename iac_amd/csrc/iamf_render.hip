@@ -217,6 +217,7 @@ struct iamf_hip_batch {
   // fixed PCM channel stride (cfg.pcm_stride_channels): the kernels pack into d_nat, restride_kernel re-lays
   uint8_t *d_nat = nullptr;
   size_t nat_bytes = 0;
+  uint8_t *d_dump = nullptr;   // RenderParams::dump
 };
 
 namespace {
@@ -513,6 +514,7 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
   p.n_end = b->n_end;
   p.thr = b->thr;
   p.src_feed = b->d_src_feed;
+  p.dump = b->d_dump;
   for (int g = 0; g < 6; ++g) p.nz_mask[g] = b->nz_mask[g];
   p.sparse = getenv("IAMF_HIP_DENSE") ? 0 : b->sparse;
   if (b->has2 && a.d_in2) {
@@ -841,6 +843,7 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
     CREATE_CHK(hipMalloc(&b->d_lfe_state, sizeof(float) * 4 * (size_t)ns));
     CREATE_CHK(hipMalloc(&b->d_lfe_next, sizeof(float) * 2 * (size_t)ns));
   }
+  CREATE_CHK(hipMalloc(&b->d_dump, (size_t)ns * 256 * 16));
   CREATE_CHK(hipMalloc(&b->d_src_feed, sizeof(int32_t) * kMaxOut));
   CREATE_CHK(hipMemcpy(b->d_src_feed, b->src_feed, sizeof(int32_t) * kMaxOut, hipMemcpyHostToDevice));
   if (fir) {
@@ -925,6 +928,7 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_lfe_u);
   (void)hipFree(b->d_lfe_y);
   (void)hipFree(b->d_nat);
+  (void)hipFree(b->d_dump);
   (void)hipFree(b->d_matrix2);
   (void)hipFree(b->d_gains2);
   (void)hipFree(b->d_src_feed2);

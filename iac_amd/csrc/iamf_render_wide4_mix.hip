@@ -7,6 +7,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "../../include/iamf_hip.h"
 
 namespace {

@@ -96,6 +96,10 @@ struct RenderParams {
   int32_t demix_layout;     // IAChannelLayoutType of the target layout (render_wide4_kernel<.., DMX>)
   int32_t demix_gmask;      // bit m: decoded channel m takes the output gain demix_ftab[12 + 2*frame_size + m]
   int32_t demix_w4;         // 1 if the in-register demixer of render_wide4.hpp covers this configuration
+  // ---- render_wide4.hpp: where lanes that have nothing to emit send their 16-byte store, so that every
+  //      chunk issues the same vector-memory instructions and the compiler can COUNT them (s_waitcnt vmcnt(N)
+  //      instead of vmcnt(0) at the top of the chunk loop); device [n_streams][256 lanes][16 B] ----
+  uint8_t *dump;
   // ---- HOA LFE generator (render_lfe.hpp): raw low-pass output of this call or nullptr ----
   const float *lfe;         // device [n_streams][lfe_stride]
   int64_t lfe_stride;

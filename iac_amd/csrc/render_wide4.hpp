@@ -21,6 +21,12 @@
 //   * two workgroup barriers per chunk on the no-trigger path.
 #pragma once
 
+// IAMF_W4_EXP: timing-only elimination builds (WRONG results; never the product, which is 0):
+//   1 = no global PCM stores   2 = no pack / staging / stores   3 = no limiter gain rounds (gain 1)
+//   4 = no projection (y = inputs)   6 = every PCM store redirected to the dump slot (no HBM writes)
+#ifndef IAMF_W4_EXP
+#define IAMF_W4_EXP 0
+#endif
 constexpr int kW4Win = kFWin;       // staged table window / head length (render_fast.hpp)
 constexpr int kW4TailLanes = 60;    // lanes holding the chunk's last 240 samples
 constexpr int kW4FirstTail = 256 - kW4TailLanes;
@@ -438,15 +444,18 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       const int j = tt & 15, kg = (tt >> 4) & 3, wv_ = tt >> 6;
 #pragma unroll
       for (int cg = 0; cg < 4; ++cg) {
-        const int k = cbase + 256 * wv_ + 4 * (16 * cg + j);
+        // every lane loads on every call: the same vector-memory instructions in every chunk, see the note at
+        // the PCM stores.  Lanes past the end of the call read the call's first samples instead; nothing such
+        // a lane computes is ever stored (ring, PCM and state writes are all guarded by `valid` / `emit`)
+        const int k0 = cbase + 256 * wv_ + 4 * (16 * cg + j);
+        const int k = k0 < p.total ? k0 : 4 * (16 * cg + j);
         const int f = k / fs;
         const int i = k - f * fs;
         const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int m = 4 * ks + kg;
-          x[4 * ks + cg] = ((M % 4 == 0 || m < M) && k < p.total) ? ld_stream4(src + (int64_t)m * fs)
-                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+          x[4 * ks + cg] = (M % 4 == 0 || m < M) ? ld_stream4(src + (int64_t)m * fs) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
     } else if constexpr (DMX) {
@@ -460,29 +469,16 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
 #pragma unroll
       for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
     } else {
-      const int k = cbase + 4 * tt;
+      const int k0 = cbase + 4 * tt;
+      const int k = k0 < p.total ? k0 : 4 * tt;   // unconditional loads, as in the MFMA variant
       const int f = k / fs;
       const int i = k - f * fs;
       const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
 #pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = k < p.total ? ld_stream4(src + (int64_t)m * fs) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
     }
   };
   load_x(0, t);
-  // MFMA A operand: lane (i = lane & 15, kg = lane >> 4) holds W[slot 16*rt + i][input 4*ks + kg]
-  float aw[MFMA ? RT * KS : 1];
-  if constexpr (MFMA) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const int slot = 16 * rt + (lane & 15);
-      const int f = slot < C ? p.src_feed[slot] : -1;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int m = 4 * ks + (lane >> 4);
-        aw[rt * KS + ks] = (f >= 0 && m < M) ? p.matrix[f * M + m] : 0.f;
-      }
-    }
-  }
   __syncthreads();
   const int cw = chain_wave_pick(misc + 12);
 
@@ -492,14 +488,16 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
   float wv[5];
   auto fetch_window = [&](int n0, int tt) {
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
+    for (int r = 0; r < 5; ++r) {  // five loads, always (ctab[n_end] is 1: the idle limiter)
       const int i = n0 + tt + 256 * r;
-      wv[r] = 1.0f;
-      if (n0 < n_end && tt + 256 * r < kW4Win) wv[r] = p.ctab[i < n_end ? i : n_end];
+      wv[r] = p.ctab[i < n_end ? i : n_end];
     }
   };
   fetch_window(n_st, t);
 
+  // One drain before the loop (once per call): with nothing pending on entry, the waits inside the loop are
+  // the ones the loop body itself implies.
+  if constexpr (!(DMX || DOWN || MIX)) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   float4 y[C];
   for (int c0 = 0; c0 < p.total; c0 += kFChunk) {
     // opaque per-chunk copy of the thread index: address arithmetic derived from it is recomputed
@@ -555,6 +553,19 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       // transpose hands every lane all channels of its own sample.  Exact f32 products in a
       // k-ordered fma chain: <= 1 ulp per term away from the reference's separately rounded
       // multiply and add (tests/test_gpu_mfma.py: +-1 LSB of the PCM).
+      // MFMA A operand: lane (i = lane & 15, kg = lane >> 4) holds W[slot 16*rt + i][input 4*ks + kg], read
+      // per chunk from the LDS copy of the matrix (mat[input][slot], zero for silent slots): eight registers
+      // that are not live through the limiter and pack phases
+      float aw[RT * KS];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int slot = 16 * rt + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int m = 4 * ks + (lane >> 4);
+          aw[rt * KS + ks] = (slot < C4 && m < M) ? mat[m * C4 + slot] : 0.f;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         w4_f32x4 acc[4][RT];
@@ -665,15 +676,23 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       }
     }
 
+#if IAMF_W4_EXP == 4
+#pragma unroll
+    for (int c = 0; c < C; ++c) y[c] = X[c % NX];
+#endif
     // ---- table window -> LDS, THEN the prefetch of the next chunk's input.  Vector-memory operations
     //      retire in order: waiting for the window values (fetched before the previous chunk's stores)
     //      after the prefetch had been issued would drain the prefetch on the spot ----
 #pragma unroll
     for (int r = 0; r < 5; ++r)
       if (tv + 256 * r < kW4Win) win[tv + 256 * r] = wv[r];
-    if (c0 + kFChunk < p.total) {
-      put_rec(tv, ((c0 >> 10) + 1) & 1);  // the next chunk's frame records
-      load_x(c0 + kFChunk, tv);
+    if constexpr (DMX || DOWN || MIX) {
+      if (c0 + kFChunk < p.total) {
+        put_rec(tv, ((c0 >> 10) + 1) & 1);  // the next chunk's frame records
+        load_x(c0 + kFChunk, tv);
+      }
+    } else {
+      load_x(c0 + kFChunk, tv);  // past the end of the call: loaded from its start and dropped (see load_x)
     }
 
     // ---- per-16 prefix / suffix / block maxima: 4 lanes x 4 samples = one aligned block ----
@@ -717,7 +736,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       };
       const int nblk = cnt >> 6;
       int bs = 0;
-      while (true) {
+      while (IAMF_W4_EXP != 3 && IAMF_W4_EXP != 5) {
         int kfirst = kBig;
         if (4 * tv >= 64 * bs) {
           float gh[4];
@@ -778,17 +797,30 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
 
     // ---- emit 4 sample-frames per lane: lanes < 196 their own (gains at +240 in this chunk),
     //      tail lanes the previous chunk's (gains at 4t - 784), leaving their own in the slot ----
-    if (c0 + kFChunk < p.total) fetch_window(n_st, tv);  // for the next chunk, ahead of the stores
+    if constexpr (DMX || DOWN || MIX) {
+      if (c0 + kFChunk < p.total) fetch_window(n_st, tv);  // for the next chunk, ahead of the stores
+    } else {
+      fetch_window(n_st, tv);
+    }
     if (c0 + 2 * kFChunk < p.total) fetch_rec(c0 + 2 * kFChunk, tv);  // written to LDS in the next chunk
     if constexpr (DMX) __builtin_amdgcn_sched_barrier(0);  // keep both fetches ahead of the stores
     float4 gq = *reinterpret_cast<const float4 *>(&arr_g[is_tail ? 4 * tv - (kFChunk - kDelay) : 4 * tv + kDelay]);
+#if IAMF_W4_EXP == 3 || IAMF_W4_EXP == 5
+    gq = make_float4(1.f, 1.f, 1.f, 1.f);
+#endif
     const float gs4[4] = {gq.x * 32768.f, gq.y * 32768.f, gq.z * 32768.f, gq.w * 32768.f};  // exact scaling
-    if (c0 + kFChunk >= p.total && valid && 4 * tv >= cnt - kSave) {
-      // last chunk of the call: its last 256 rendered samples are the stream state the next call
-      // (any kernel) starts from.  Written here so that y is dead once it has been packed below.
-      float *sy = p.ring_y + (int64_t)s * C * kSave;
+    if (c0 + kFChunk >= p.total) {  // wave-uniform
+      if (valid && 4 * tv >= cnt - kSave) {
+        // last chunk of the call: its last 256 rendered samples are the stream state the next call
+        // (any kernel) starts from.  Written here so that y is dead once it has been packed below.
+        float *sy = p.ring_y + (int64_t)s * C * kSave;
 #pragma unroll
-      for (int c = 0; c < C; ++c) *reinterpret_cast<float4 *>(&sy[c * kSave + 4 * tv - (cnt - kSave)]) = y[c];
+        for (int c = 0; c < C; ++c) *reinterpret_cast<float4 *>(&sy[c * kSave + 4 * tv - (cnt - kSave)]) = y[c];
+      }
+      // These stores sit in a conditional block; left pending they would make the loop-top wait for the
+      // prefetched input a vmcnt(0) on EVERY chunk (see the note at the PCM stores).  Drained here, once per
+      // call, this path reaches the loop header with nothing in flight and the steady path keeps its count.
+      if constexpr (!(DMX || DOWN || MIX)) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
     if (is_tail) {  // swap in place: y <- previous tail, slot <- this chunk's samples
 #pragma unroll
@@ -799,6 +831,14 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
         y[c] = old;
       }
     }
+#if IAMF_W4_EXP == 2
+    {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc += y[c].x * gs4[0] + y[c].y * gs4[1] + y[c].z * gs4[2] + y[c].w * gs4[3];
+      if (acc == 123.456f && p.total < 0) pcm[tv] = 1;
+    }
+#else
     {
       // Pack to s16 (rint then saturate == the reference's clamp then lrintf: the bounds are
       // integers).  Piece k of a lane = dwords 4k..4k+3 of its 8*C bytes; dword d = sample
@@ -842,11 +882,37 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
             // persisted state)
             const bool ts = t2 >= kW4FirstTail;
             const int rel = c0 + 4 * t2 - (ts ? kFChunk : 0);  // sample, relative to pos0
-            if (ts ? rel + pos_small >= 0 : 4 * t2 < cnt - kDelay)
-            {  // written once, never read back by this GPU: streaming store
-              using u4 = __attribute__((ext_vector_type(4))) unsigned;
-              __builtin_nontemporal_store(u4{v.x, v.y, v.z, v.w},
-                                          reinterpret_cast<u4 *>(pcm + (uint32_t)((rel + lead) * (C * 2) + k * 16)));
+#if IAMF_W4_EXP == 6
+            const bool emit = false;  // every store goes to the lane's dump slot: instruction issue without HBM writes
+#else
+            const bool emit = ts ? rel + pos_small >= 0 : 4 * t2 < cnt - kDelay;
+#endif
+            using u4 = __attribute__((ext_vector_type(4))) unsigned;
+            if constexpr (DMX || DOWN || MIX) {
+              if (emit)  // written once, never read back by this GPU: streaming store
+                __builtin_nontemporal_store(u4{v.x, v.y, v.z, v.w},
+                                            reinterpret_cast<u4 *>(pcm + (uint32_t)((rel + lead) * (C * 2) + k * 16)));
+            } else {
+              // EVERY lane stores in EVERY chunk: a lane with nothing to emit (no previous tail yet at the start
+              // of a stream, the end of a short last chunk) sends its 16 bytes to its slot of the dump buffer.
+              // With the loads above that makes the chunk's vector-memory instructions the same on every path,
+              // which is what lets the compiler wait for the prefetched input with a COUNTED s_waitcnt
+              // vmcnt(5 + stores) at the top of the loop instead of vmcnt(0): vector-memory operations retire in
+              // order, and vmcnt(0) there drained this chunk's PCM stores — a store round trip (~2 us) exposed
+              // on every chunk, 25-35 % of cfg2 / cfg3 (tools/w4_exp.sh).
+              // (the dump address is rebuilt from the per-chunk thread index: two registers that do not stay live)
+              uint8_t *to = emit ? pcm + (uint32_t)((rel + lead) * (C * 2) + k * 16)
+                                 : p.dump + (uint32_t)((s * 256 + tv) * 16);
+#if IAMF_W4_EXP == 1
+              if (v.x == 0x12345678u && p.total < 0)
+#endif
+#if IAMF_W4_EXP == 7
+              *reinterpret_cast<u4 *>(to) = u4{v.x, v.y, v.z, v.w};   // plain instead of non-temporal
+#else
+              __builtin_nontemporal_store(u4{v.x, v.y, v.z, v.w}, reinterpret_cast<u4 *>(to));
+#endif
+              __builtin_amdgcn_sched_barrier(0);  // piece by piece: without the branches the scheduler would
+                                                  // hoist a round's LDS reads above its stores (24 registers)
             }
           }
         }
@@ -854,6 +920,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
         __builtin_amdgcn_wave_barrier();
       }
     }
+#endif
     base = base + cnt >= R ? base + cnt - R : base + cnt;
     // no barrier here: the next chunk writes ring_* / win before its barrier (1), whose readers
     // all finished before barrier (2)/(3) of this chunk; arr_* / misc are written after (1)
