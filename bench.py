@@ -474,7 +474,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="N=1, default workload: do not also measure BASELINE configs 2, 3 and the HRTF form of 4")
-    ap.add_argument("--placement-tries", type=int, default=6,
+    ap.add_argument("--placement-tries", type=int, default=10,
                     help="setup: allocate up to this many candidate buffers for the element PCM, measure a few "
                          "launches on each and keep the fastest (the rate is bimodal per allocation, ~13 %% apart; "
                          "1 = take the first allocation as it comes)")

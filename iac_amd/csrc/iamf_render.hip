@@ -212,8 +212,8 @@ struct iamf_hip_batch {
   bool lfe = false;
   float lfe_a1 = 0.f, lfe_a2 = 0.f, lfe_a3 = 0.f, lfe_b1 = 0.f, lfe_b2 = 0.f;
   double lfe_div = 0.0;
-  float *d_lfe_state = nullptr, *d_lfe_next = nullptr, *d_lfe_u = nullptr, *d_lfe_y = nullptr;
-  size_t lfe_u_floats = 0, lfe_y_floats = 0;
+  float *d_lfe_state = nullptr, *d_lfe_next = nullptr, *d_lfe_u = nullptr;
+  size_t lfe_u_floats = 0;
   // fixed PCM channel stride (cfg.pcm_stride_channels): the kernels pack into d_nat, restride_kernel re-lays
   uint8_t *d_nat = nullptr;
   size_t nat_bytes = 0;
@@ -578,17 +578,14 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     // caller's stream ahead of the render kernel (render_lfe.hpp)
     hipStream_t st = static_cast<hipStream_t>(a.stream);
     const int ns = b->cfg.n_streams, nb = (ns + 63) / 64, t4 = (total + 3) / 4;
-    const size_t need_u = (size_t)nb * t4 * 64 * 4, need_y = (size_t)ns * t4 * 4;
-    if (need_u > b->lfe_u_floats || need_y > b->lfe_y_floats) {  // grows with the largest call seen
+    const size_t need_u = (size_t)nb * t4 * 64 * 4;
+    if (need_u > b->lfe_u_floats) {  // grows with the largest call seen
       HIPCHK(hipStreamSynchronize(st));
       (void)hipFree(b->d_lfe_u);
-      (void)hipFree(b->d_lfe_y);
-      b->d_lfe_u = b->d_lfe_y = nullptr;
-      b->lfe_u_floats = b->lfe_y_floats = 0;
+      b->d_lfe_u = nullptr;
+      b->lfe_u_floats = 0;
       HIPCHK(hipMalloc(&b->d_lfe_u, sizeof(float) * need_u));
-      HIPCHK(hipMalloc(&b->d_lfe_y, sizeof(float) * need_y));
       b->lfe_u_floats = need_u;
-      b->lfe_y_floats = need_y;
     }
     LfeParams lp;
     memset(&lp, 0, sizeof(lp));
@@ -606,13 +603,11 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     lp.state = b->d_lfe_state;
     lp.state_next = b->d_lfe_next;
     lp.u_t = reinterpret_cast<float4 *>(b->d_lfe_u);
-    lp.y = b->d_lfe_y;
-    lp.y_stride = (int64_t)t4 * 4;
     hipLaunchKernelGGL(lfe_ff_kernel, dim3((unsigned)((t4 + kLfeTileQ - 1) / kLfeTileQ), (unsigned)nb), dim3(256), 0, st, lp);
     hipLaunchKernelGGL(lfe_chain_kernel, dim3((unsigned)nb), dim3(64), 0, st, lp);
     HIPCHK(hipGetLastError());
-    p.lfe = b->d_lfe_y;
-    p.lfe_stride = lp.y_stride;
+    p.lfe = b->d_lfe_u;
+    p.lfe_t4 = t4;
     p.lfe_div = b->lfe_div;
   }
   const size_t lds = sizeof(float) * ((size_t)(p.out_ch + 2) * kRing + 3 * kChunk + kHead + 4 +
@@ -926,7 +921,6 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_lfe_state);
   (void)hipFree(b->d_lfe_next);
   (void)hipFree(b->d_lfe_u);
-  (void)hipFree(b->d_lfe_y);
   (void)hipFree(b->d_nat);
   (void)hipFree(b->d_dump);
   (void)hipFree(b->d_matrix2);

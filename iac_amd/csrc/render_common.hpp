@@ -101,8 +101,8 @@ struct RenderParams {
   //      instead of vmcnt(0) at the top of the chunk loop); device [n_streams][256 lanes][16 B] ----
   uint8_t *dump;
   // ---- HOA LFE generator (render_lfe.hpp): raw low-pass output of this call or nullptr ----
-  const float *lfe;         // device [n_streams][lfe_stride]
-  int64_t lfe_stride;
+  const float *lfe;         // device, transposed by blocks of 64 streams: element lfe_index(s, k, lfe_t4) (render_lfe.hpp)
+  int32_t lfe_t4;           // quads per stream in that buffer
   double lfe_div;           // sqrt(n) of h2m_rdr.c:1162; 0 = the `* 0.5` form (n <= 2)
   // ---- HRTF FIR renderer (render_fast_kernel<M, 2, true>): matrix = h[2][M][fir_taps] ----
   int32_t fir_taps;

@@ -87,7 +87,11 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       xr[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (xoff[r] >= 0) xr[r] = *reinterpret_cast<const float4 *>(in_s + (int64_t)ch * p.frame_size + xoff[r]);
+      if (xoff[r] >= 0) {  // streamed once: non-temporal, so that it does not push the shared filter tables out of L2
+        using v4 = __attribute__((ext_vector_type(4))) float;
+        const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(in_s + (int64_t)ch * p.frame_size + xoff[r]));
+        xr[r] = make_float4(v.x, v.y, v.z, v.w);
+      }
       else if (xoff[r] <= -2 && xoff[r] != kNoQuad) xr[r] = *reinterpret_cast<const float4 *>(hist + ch * kFirHist + (-2 - xoff[r]));
     }
     const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const unsigned char *>(p.fir_h16) + (size_t)ch * kF16HBytes);

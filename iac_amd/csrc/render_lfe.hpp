@@ -10,7 +10,10 @@
 //   lfe_ff_kernel     u[j] = (a1*w[j] + a2*w[j-1]) + a3*w[j-2], one lane per 4 samples, written through
 //                     an LDS transpose into [block of 64 streams][quad][stream] order;
 //   lfe_chain_kernel  lane = stream, 64 streams per wave: y = (u - b1*y1) - b2*y2 over the whole call,
-//                     u read as coalesced 1 KiB rows prefetched two blocks ahead, y stored per stream;
+//                     u read as coalesced 1 KiB rows prefetched two blocks ahead, y written IN PLACE over u
+//                     (first version: y stored per stream, 64 scattered 16-byte transactions per store
+//                     instruction in front of the prefetch loads in the in-order memory pipe — 53 cycles per
+//                     step, 1.44 ms per 64-frame call; in place: see DESIGN.md 4.6);
 //   the scaling (y * 0.5 or y / sqrt(n), both double expressions in the reference, h2m_rdr.c:1157-1163)
 //   is done by the render kernel where it reads the slot.
 // State per stream between calls: w[-1], w[-2], y[-1], y[-2] (lfe_filter_t's two histories).
@@ -28,10 +31,13 @@ struct LfeParams {
   float a1, a2, a3, b1, b2;
   float *state;               // [n_streams][4]: w1, w2, y1, y2
   float *state_next;          // [n_streams][2]: w1, w2 after this call (adopted by the chain kernel)
-  float4 *u_t;                // [n_blocks64][t4][64] quads
-  float *y;                   // [n_streams][y_stride]
-  int64_t y_stride;           // floats, multiple of 4
+  float4 *u_t;                // [n_blocks64][t4][64] quads: u from the ff kernel, y after the chain kernel
 };
+
+// where the render kernel finds the generator's output for sample k of stream s (floats into u_t)
+__device__ __forceinline__ int64_t lfe_index(int s, int k, int t4) {
+  return ((((int64_t)(s >> 6) * t4 + (k >> 2)) * 64 + (s & 63)) << 2) + (k & 3);
+}
 
 __device__ __forceinline__ float lfe_w_at(const LfeParams &p, int s, int k) {
   const int f = k / p.frame_size, i = k - f * p.frame_size;
@@ -86,49 +92,57 @@ __global__ __launch_bounds__(64) void lfe_chain_kernel(const LfeParams p) {
   const int sc = active ? s : p.n_streams - 1;
   float y1 = p.state[4 * sc + 2], y2 = p.state[4 * sc + 3];
   const float b1 = p.b1, b2 = p.b2;
-  const float4 *src = p.u_t + (int64_t)sb * p.t4 * 64 + lane;
-  float *dst = p.y + (int64_t)sc * p.y_stride;
-  const int t4 = p.t4;
+  float4 *row = p.u_t + (int64_t)sb * p.t4 * 64 + lane;   // this lane's quad q sits at row[64 q]
+  const int nfull = p.total >> 2;                          // quads whose four samples all belong to the call
+  // One step: y = (u - b1*y1) - b2*y2, three dependent f32 operations.  The hot loop has nothing else in it:
+  // whole blocks of kLfeBlk quads, no per-quad conditions (the first version carried the short-last-quad
+  // selects and a bounds branch per quad: 35 instructions per quad, 53 cycles per step).
+  auto step4 = [&](const float4 u) {
+    float4 o;
+    o.x = (u.x - b1 * y1) - b2 * y2;
+    o.y = (u.y - b1 * o.x) - b2 * y1;
+    o.z = (u.z - b1 * o.y) - b2 * o.x;
+    o.w = (u.w - b1 * o.z) - b2 * o.y;
+    y2 = o.z;
+    y1 = o.w;
+    return o;
+  };
   float4 bufa[kLfeBlk], bufb[kLfeBlk];
-  auto load = [&](float4(&buf)[kLfeBlk], int q0) {
+  const int nblk = nfull / kLfeBlk;  // whole blocks
+  auto load = [&](float4(&buf)[kLfeBlk], int blk) {  // blk < nblk, or a clamped re-read whose values are not used
+    const float4 *src = row + (int64_t)(blk < nblk ? blk : (nblk > 0 ? nblk - 1 : 0)) * kLfeBlk * 64;
 #pragma unroll
-    for (int i = 0; i < kLfeBlk; ++i) {
-      const int q = q0 + i < t4 ? q0 + i : t4 - 1;   // clamped: past the end the values are not used
-      buf[i] = src[(int64_t)q * 64];
-    }
+    for (int i = 0; i < kLfeBlk; ++i) buf[i] = src[i * 64];
   };
-  auto run = [&](const float4(&buf)[kLfeBlk], int q0) {
+  auto run = [&](const float4(&buf)[kLfeBlk], int blk) {
+    float4 *dst = row + (int64_t)blk * kLfeBlk * 64;
 #pragma unroll
-    for (int i = 0; i < kLfeBlk; ++i) {
-      if (q0 + i < t4) {  // wave-uniform
-        const float4 u = buf[i];
-        float4 o;
-        o.x = (u.x - b1 * y1) - b2 * y2;
-        o.y = (u.y - b1 * o.x) - b2 * y1;
-        o.z = (u.z - b1 * o.y) - b2 * o.x;
-        o.w = (u.w - b1 * o.z) - b2 * o.y;
-        // a short last quad computes on u = a1*0 + ... of samples past the call; their y is never read
-        // and the state below is taken from the last REAL sample
-        const int left = p.total - 4 * (q0 + i);
-        if (left >= 4) {
-          y2 = o.z;
-          y1 = o.w;
-        } else {
-          const float r1 = left == 3 ? o.z : (left == 2 ? o.y : o.x);
-          const float r2 = left == 3 ? o.y : (left == 2 ? o.x : y1);
-          y2 = r2;
-          y1 = r1;
-        }
-        if (active) *reinterpret_cast<float4 *>(dst + 4 * (q0 + i)) = o;
-      }
-    }
+    for (int i = 0; i < kLfeBlk; ++i) dst[i * 64] = step4(buf[i]);  // in place: the wave writes one contiguous 1 KiB row
   };
-  load(bufa, 0);
-  for (int q0 = 0; q0 < t4; q0 += 2 * kLfeBlk) {
-    load(bufb, q0 + kLfeBlk);
-    run(bufa, q0);
-    load(bufa, q0 + 2 * kLfeBlk);
-    run(bufb, q0 + kLfeBlk);
+  if (nblk > 0) load(bufa, 0);
+  int blk = 0;
+  for (; blk + 1 < nblk; blk += 2) {
+    load(bufb, blk + 1);
+    run(bufa, blk);
+    load(bufa, blk + 2);
+    run(bufb, blk + 1);
+  }
+  if (blk < nblk) run(bufa, blk);
+  // what is left: fewer than kLfeBlk whole quads, then at most one quad that the call ends inside
+  for (int q = nblk * kLfeBlk; q < nfull; ++q) row[(int64_t)q * 64] = step4(row[(int64_t)q * 64]);
+  const int left = p.total - 4 * nfull;  // 0..3 samples in the last quad
+  if (left > 0) {
+    const float4 u = row[(int64_t)nfull * 64];
+    float4 o;
+    o.x = (u.x - b1 * y1) - b2 * y2;
+    o.y = (u.y - b1 * o.x) - b2 * y1;
+    o.z = (u.z - b1 * o.y) - b2 * o.x;
+    o.w = 0.f;
+    row[(int64_t)nfull * 64] = o;
+    const float r1 = left == 3 ? o.z : (left == 2 ? o.y : o.x);
+    const float r2 = left == 3 ? o.y : (left == 2 ? o.x : y1);
+    y2 = r2;
+    y1 = r1;
   }
   if (active) {
     p.state[4 * s + 0] = p.state_next[2 * s + 0];
