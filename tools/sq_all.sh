@@ -12,4 +12,5 @@ for W in toa_binaural_limiter_s16 714_ssJ_limiter_s16 toa_ssH_limiter_s16 toa_hr
       -d "$R/gpurun_out/sq/$W" -o t --output-format csv -- python3 $ARGS > "$R/gpurun_out/sq_$W.log" 2>&1 || echo "rocprof failed for $W"
   echo "done $W"
 done
+mkdir -p "$R/gpurun_out/profiles"
 python3 "$R/tools/sq_summary.py" "$R/gpurun_out/sq" "$R/gpurun_out/profiles/${ROUND}_sq_counters.json" > /dev/null
