@@ -240,7 +240,7 @@ def test_projection_tolerance_mode_within_1lsb(hip, order, l_in, out):
         want = O.pack(z, 16)
         d = np.abs(got[s].astype(np.int32) - want.astype(np.int32))
         assert d.max() <= 1, (s, int(d.max()))
-        assert (d != 0).mean() < 0.2, (s, float((d != 0).mean()))
+        assert (d != 0).mean() < 0.02, (s, float((d != 0).mean()))
 
 
 def test_mix_gain_ramps_vs_oracle(hip):

@@ -35,7 +35,8 @@ def test_mfma_projection_pcm_within_1lsb(hip, order, out):
     assert got.shape == want.shape
     d = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert d.max() <= 1, (order, out, int(d.max()))
-    assert (d != 0).mean() < 0.02  # only rounding ties may move
+    # measured on the bench programme (tools/flip_rates.py): 0.013-0.018 % of PCM words, always 1 LSB
+    assert (d != 0).mean() < 0.005  # only rounding ties may move
 
 
 def test_mfma_projection_float_tap(hip):
