@@ -392,6 +392,30 @@ class Workload:
             ev_pair[1].record()
         return n
 
+    def same_traffic_no_compute(self, reps=8):
+        """What the memory system delivers for THIS workload's traffic shape on THESE buffers with no compute:
+        the library's diagnostic kernel (iamf_probe.hip: one workgroup per stream, in_ch x 16 B read and
+        out_ch / 2 x 16 B written per lane and chunk), timed like the render kernel.  Runs after the timed
+        regions (it overwrites the PCM buffer).  None where the shape has no probe (odd channel counts)."""
+        A = self.A
+        if self.fs != 1024 or self.out_ch % 2 and self.out_ch != 1:
+            return None
+        rows, pieces = self.in_ch, max(1, self.out_ch // 2)
+        in_stride_b = self.stream_stride * 4
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record()
+            r = A.lib().iamf_hip_probe_traffic(self.S, self.F, rows, pieces, self.x.data_ptr(), in_stride_b,
+                                               self.pcm[1].data_ptr(), self.stride_bytes, self.stream)
+            b.record()
+            if r != 0:
+                return None
+        torch.cuda.synchronize()
+        ms = float(np.median([a.elapsed_time(b) for a, b in ev[2:]]))
+        bytes_ = self.S * self.F * (rows + pieces) * 4096
+        return {"msamples_s": round(self.sf_per_step / (ms * 1e-3) / 1e6, 1), "gbs": round(bytes_ / (ms * 1e-3) / 1e9, 1),
+                "kernel_ms": round(ms, 4), "note": "same loads and stores per lane and chunk, same buffers, no compute"}
+
     def close(self):
         self.batch.close()
         self.x = self.x2 = self.extra = self.pcm = None
@@ -573,6 +597,13 @@ def main():
         total_sf = wl.sf_per_step * args.steps * world
         value = total_sf / elapsed / 1e6
         roof, dtype = wl.roofline(kernel_ms)
+        if wl.kind in ("h2m", "m2m", "h2m_proj"):
+            probe = wl.same_traffic_no_compute()
+            if probe:
+                roof["same_traffic_no_compute"] = probe
+                # kernel time against kernel time (this GPU's launch): how much of what the memory system
+                # gives this traffic shape the render kernel gets
+                roof["frac_of_same_traffic"] = round(wl.sf_per_step / (kernel_ms * 1e-3) / 1e6 / probe["msamples_s"], 4)
         out = {
             "metric": "Msamples/s rendered (3rd-order HOA->binaural, 48 kHz)",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -617,6 +648,11 @@ def main():
             assert em >= args.steps * F * fs - 240
             v2 = w2.sf_per_step * args.steps / el / 1e6
             r2, dt2 = w2.roofline(kms)
+            if w2.kind in ("h2m", "m2m"):
+                pr2 = w2.same_traffic_no_compute()
+                if pr2:
+                    r2["same_traffic_no_compute"] = pr2
+                    r2["frac_of_same_traffic"] = round(w2.sf_per_step / (kms * 1e-3) / 1e6 / pr2["msamples_s"], 4)
             out["configs"][name] = {"value": round(v2, 2), "unit": "Msamples/s", "steps": args.steps,
                                     "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": dt2,
                                     "in_channels": w2.in_ch, "out_channels": w2.out_ch,

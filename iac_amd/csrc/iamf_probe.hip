@@ -1,0 +1,66 @@
+// iamf_probe.hip — diagnostic entry point: the render kernels' HBM traffic SHAPE with no compute, so that a
+// measured rate can be put next to what the memory system delivers for that shape (bench.py:
+// roofline.same_traffic_no_compute).  One 256-thread workgroup per stream; per 1024-sample chunk every lane
+// reads `rows` x 16 B (rows 4 KiB apart inside a frame of rows x 4 KiB, prefetched one chunk ahead, non-temporal)
+// and writes `pieces` x 16 B, each store instruction covering 1 KiB contiguous per wave — the geometry of
+// render_fast.hpp (rows 16, pieces 1) and render_wide4.hpp (cfg2: 12 / 6, cfg3: 16 / 12).
+// Round-2 finding (tools/rw_mix_probe.hip, profiles/r02_rw_mix.txt): read-only this pattern runs at 7.1 TB/s;
+// ANY share of writes puts it in a 5.2-6.0 TB/s regime (headline shape 5.5-5.85, cfg2 5.2-5.3, cfg3 5.8-6.05),
+// whichever wave issues the stores.  Nothing here is used by the render path.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "../../include/iamf_hip.h"
+
+namespace {
+
+using v4 = __attribute__((ext_vector_type(4))) float;
+using u4 = __attribute__((ext_vector_type(4))) unsigned;
+
+template <int ROWS>
+__global__ __launch_bounds__(256, 2) void traffic_probe_kernel(const v4 *in, int64_t in_stream_stride4, u4 *out,
+                                                               int64_t out_stream_stride4, int chunks, int pieces) {
+  const int s = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const v4 *src = in + (int64_t)s * in_stream_stride4;
+  u4 *dst = out + (int64_t)s * out_stream_stride4;
+  v4 x[ROWS];
+#pragma unroll
+  for (int m = 0; m < ROWS; ++m) x[m] = __builtin_nontemporal_load(src + m * 256 + t);
+  for (int c = 0; c < chunks; ++c) {
+    float a = 0.f;
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) a += x[m].x + x[m].y + x[m].z + x[m].w;
+    const int cn = c + 1 < chunks ? c + 1 : c;  // unconditional prefetch (the last one re-reads)
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) x[m] = __builtin_nontemporal_load(src + ((int64_t)cn * ROWS + m) * 256 + t);
+    __syncthreads();
+    const u4 w = {__float_as_uint(a), (unsigned)c, (unsigned)t, 0u};
+    for (int k = 0; k < pieces; ++k)
+      __builtin_nontemporal_store(w, dst + ((int64_t)c * pieces * 4 + wave * pieces + k) * 64 + lane);
+  }
+}
+
+}  // namespace
+
+extern "C" int iamf_hip_probe_traffic(int n_streams, int chunks, int rows, int pieces, const void *d_in,
+                                      int64_t in_stream_stride_bytes, void *d_out, int64_t out_stream_stride_bytes,
+                                      void *stream) {
+  if (n_streams <= 0 || chunks <= 0 || pieces < 0 || pieces > 64 || !d_in || !d_out ||
+      in_stream_stride_bytes < (int64_t)chunks * rows * 4096 || out_stream_stride_bytes < (int64_t)chunks * pieces * 4096 ||
+      (in_stream_stride_bytes & 15) || (out_stream_stride_bytes & 15))
+    return IAMF_HIP_ERR_BAD_ARG;
+  const v4 *in = static_cast<const v4 *>(d_in);
+  u4 *out = static_cast<u4 *>(d_out);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)n_streams), block(256);
+  const int64_t is4 = in_stream_stride_bytes / 16, os4 = out_stream_stride_bytes / 16;
+  switch (rows) {
+#define CASE_R(R) \
+  case R: hipLaunchKernelGGL(traffic_probe_kernel<R>, grid, block, 0, st, in, is4, out, os4, chunks, pieces); break;
+    CASE_R(1) CASE_R(2) CASE_R(4) CASE_R(6) CASE_R(8) CASE_R(9) CASE_R(10) CASE_R(12) CASE_R(16)
+#undef CASE_R
+    default: return IAMF_HIP_ERR_UNIMPLEMENTED;
+  }
+  return hipGetLastError() == hipSuccess ? IAMF_HIP_OK : IAMF_HIP_ERR_DEVICE;
+}

@@ -102,6 +102,8 @@ def lib():
         L = C.CDLL(path)
         L.iamf_hip_get_h2m_matrix.argtypes = [C.c_int, C.c_int, C.POINTER(Matrix)]
         L.iamf_hip_get_m2m_matrix.argtypes = [C.c_int, C.c_int, C.POINTER(Matrix)]
+        L.iamf_hip_probe_traffic.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                             C.c_int64, C.c_void_p]
         L.iamf_hip_get_m2m_matrix_variant.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Matrix)]
         L.iamf_hip_layout_channels.argtypes = [C.c_int]
         L.iamf_hip_batch_create.argtypes = [C.POINTER(BatchConfig), C.POINTER(C.c_void_p)]

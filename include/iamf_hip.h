@@ -324,6 +324,18 @@ int iamf_hip_format_bytes(int out_format);
 const char *iamf_hip_version(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Diagnostics (not part of the render path).  Launches a kernel with the render kernels' HBM traffic
+ * SHAPE and no compute: one 256-thread workgroup per stream, per 1024-sample chunk every lane reads
+ * `rows` x 16 B (a frame of rows x 4 KiB per chunk, prefetched one chunk ahead) and writes `pieces` x 16 B
+ * (1 KiB contiguous per wave and store instruction).  rows = input channels, pieces = out_channels / 2 for
+ * s16.  Time it on the caller's stream to know what the memory system delivers for that shape on THOSE
+ * buffers (bench.py: roofline.same_traffic_no_compute).  The buffers' contents are read / overwritten.
+ * ---------------------------------------------------------------------------------------- */
+int iamf_hip_probe_traffic(int n_streams, int chunks, int rows, int pieces, const void *d_in,
+                           int64_t in_stream_stride_bytes, void *d_out, int64_t out_stream_stride_bytes,
+                           void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Decoder facade extension.  The reference chooses at BUILD time whether scene-based elements feed
  * the LFE of the output layout (-DDISABLE_LFE_HOA=0; default: compiled out, ae_rdr.h:63-65).  This
  * library carries both builds: the switch is per decoder handle (an IAMF_DecoderHandle of this
