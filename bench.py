@@ -254,6 +254,24 @@ class Workload:
         out_ch = self.out_ch = mx.channels if kind == "dmx" else A.layout_channels(out_id)
         S, F, fs = args.streams, args.frames, args.frame_size
         self.S, self.F, self.fs = S, F, fs
+        batch = self.batch = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True,
+                                     fir_taps=FIR_TAPS if kind == "fir" else 0, lfe_hoa=kind == "h2m_lfe")
+        self.stride_bytes = F * fs * out_ch * 2
+        self.pcm = [torch.zeros((S, self.stride_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.stream_stride, self.frame_stride = F * in_ch * fs + args.pad_kb * 256, in_ch * fs
+        self.sf_per_step = S * F * fs     # sample-frames one launch processes on this GPU
+        # The element PCM's buffer FIRST, before any other large allocation of this process: which region of
+        # memory it lands in decides between two modes of the same kernel (pick_placement).
+        if kind == "h2m_proj":   # a well-conditioned Q15 de-mapping matrix (identity/2 + noise)
+            rngp = np.random.default_rng(5)
+            Pm = rngp.integers(-6000, 6000, size=(in_ch, in_ch)).astype(np.float32) * np.float32(2.0 ** -15)
+            Pm[np.arange(in_ch), np.arange(in_ch)] += np.float32(0.5)
+            batch.set_projection(Pm.astype(np.float32))
+        self.placement = None
+        self.x = None
+        if args.placement_tries > 1 and kind in ("h2m", "m2m", "fir", "h2m_lfe", "h2m_proj"):
+            self.pick_placement(args.placement_tries, dev)
 
         x = synth_hot_device(S, in_ch, F, fs, 1000 + rank, dev)
         if args.signal == "quiet":
@@ -265,8 +283,6 @@ class Workload:
             x += (((tt - ph) % 1531) < 8) * torch.where(tt % 2 == 0, 1.0, -1.0) * 1.5
             x = x.contiguous()
             del tt, ph
-        batch = self.batch = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True,
-                                     fir_taps=FIR_TAPS if kind == "fir" else 0, lfe_hoa=kind == "h2m_lfe")
         self.extra = None
         self.x2 = None
         if kind in ("h2m_in2", "m2m_in2"):
@@ -286,11 +302,6 @@ class Workload:
                     A.lib().iamf_hip_dmx_set_mode_weight(C.byref(st_), (0, 1, 2, 4, 5, 6)[(s_ + f_) % 6], -1)
                     A.lib().iamf_hip_dmx_coefficients(C.byref(st_), fr_[s_ * F + f_].cur)
             self.extra = torch.from_numpy(np.frombuffer(bytes(fr_), dtype=np.uint8).copy()).to(dev)
-        if kind == "h2m_proj":   # a well-conditioned Q15 de-mapping matrix (identity/2 + noise)
-            rngp = np.random.default_rng(5)
-            Pm = rngp.integers(-6000, 6000, size=(in_ch, in_ch)).astype(np.float32) * np.float32(2.0 ** -15)
-            Pm[np.arange(in_ch), np.arange(in_ch)] += np.float32(0.5)
-            batch.set_projection(Pm.astype(np.float32))
         if kind == "demix":
             import ctypes as C
             import demix_cases as D
@@ -322,49 +333,41 @@ class Workload:
             x = torch.stack([L2 / 0.7079458, R2 / 0.7079458, L7, R7, HL / 1.4125376, HR / 1.4125376, Cc, LFE,
                              SL7, SR7, HFL, HFR], dim=2).contiguous()
             del L7, R7, Cc, LFE, SL7, SR7, BL7, BR7, HFL, HFR, HBL, HBR, SL5, SR5, L2, R2, HL, HR
-        self.stride_bytes = F * fs * out_ch * 2
-        self.pcm = [torch.zeros((S, self.stride_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
-        self.stream = torch.cuda.current_stream().cuda_stream
-        self.stream_stride, self.frame_stride = F * in_ch * fs, in_ch * fs
-        if args.pad_kb:
-            xp = torch.zeros((S, self.stream_stride + args.pad_kb * 256), dtype=torch.float32, device=dev)
-            xp[:, :self.stream_stride] = x.reshape(S, -1)
-            x = xp
-            self.stream_stride += args.pad_kb * 256
-        self.x = x
-        self.sf_per_step = S * F * fs     # sample-frames one launch processes on this GPU
+        n = F * in_ch * fs
+        if self.x is None:
+            self.x = torch.zeros((S, self.stream_stride), dtype=torch.float32, device=dev)
+        self.x[:, :n] = x.reshape(S, -1)   # into the chosen buffer
+        del x
         self.ktag = kernel_tag(kind, in_ch, out_ch)
-        self.placement = None
-        if args.placement_tries > 1:
-            self.pick_placement(args.placement_tries)
 
-    def pick_placement(self, tries):
+    def pick_placement(self, tries, dev):
         """Setup, untimed.  The same kernel on the same bytes runs in one of two modes depending on WHICH
         allocation holds the element PCM (tools/placement_probe*.py: e.g. 79 or 91 Gsamples/s quiet, 73 or 86
         hot; not the stride, not the base offset inside the allocation, not the PCM / state buffers; a plain
         streaming read gets 7.0 TB/s from either).  A long-lived serving buffer is allocated once, so the
         harness does what a deployment would: it allocates up to `tries` candidates, measures a few launches
         on each, keeps the fastest and frees the rest.  Every candidate's rate goes into the JSON line."""
-        cands, rates = [self.x], []
+        cands, rates = [], []
         for i in range(tries):
-            if i > 0:
-                c = torch.empty_like(self.x)   # the earlier candidates are still alive: another address
-                c.copy_(self.x)
-                cands.append(c)
+            cands.append(torch.zeros((self.S, self.stream_stride), dtype=torch.float32, device=dev))  # earlier ones stay alive
             self.x = cands[i]
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
-            for e in ev:
-                self.render_into(self.pcm[0], e)
+            for a, b in ev:   # on silence: the modes differ by the same ~13 % on any programme
+                a.record()
+                self.batch.render(self.x.data_ptr(), self.stream_stride, self.frame_stride, self.F,
+                                  self.pcm[0].data_ptr(), self.stride_bytes, self.stream)
+                b.record()
             torch.cuda.synchronize()
             self.batch.reset()
             ms = float(np.median([a.elapsed_time(b) for a, b in ev[1:]]))
             rates.append(round(self.sf_per_step / (ms * 1e-3) / 1e6, 1))
-            if i >= 1 and max(rates) > 1.07 * min(rates) and rates[-1] >= 0.97 * max(rates):
-                break   # both modes seen and the current candidate is in the fast one
+            if i >= 2 and rates[-1] >= 0.97 * max(rates) and (max(rates) > 1.07 * min(rates) or i >= 3):
+                break   # the current candidate is as fast as any seen, and either both modes showed or four agree
         best = int(np.argmax(rates))
         self.x = cands[best]
         self.placement = {"candidates_msamples_s": rates, "picked": best,
-                          "note": "same kernel, same bytes, different allocations of the input (setup, untimed)"}
+                          "note": "same kernel on silence, different allocations of the input buffer, tried before "
+                                  "anything else is allocated (setup, untimed)"}
         del cands
         torch.cuda.empty_cache()
 
