@@ -666,7 +666,7 @@ def main():
 
     if rank == 0:
         kind = headline_kind
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks would wait for it
             wlname = {"fir": "toa_binaural_limiter_s16", "demix": "714_ssJ_limiter_s16"}.get(kind, args.workload)
             wlname = wlname.replace("toa_projection_", "toa_").replace("_lfe_", "_")
             if kind in ("dmx", "m2m_in2"):
