@@ -212,7 +212,11 @@ SIGNALS = {"hot": "hot (sigma 0.25 + 1.5 bursts)", "quiet": "quiet (sigma 0.05)"
            "sparse": "sparse (sigma 0.05 + an 8-sample 1.5 peak every 1531 samples)"}
 # BASELINE.json configs that fit one GPU besides the headline (configs[3] matrix form): measured in
 # the same process and reported under "configs" of the one JSON line (N=1 only)
-EXTRA_CONFIGS = ["714_ssJ_limiter_s16", "toa_ssH_limiter_s16", "toa_hrtf256_limiter_s16"]
+# (workload, streams per GPU, placement tries).  BASELINE fixes 512 streams per GPU only for the headline (config 5:
+# 4096 over 8 GPUs); configs 2 and 3 name no batch size, and the wide-layout kernels are bound by chunk latency x
+# workgroups per CU, so they run on a larger shard (2048 streams: +4-8 % over 512, profiles/r02_streams_sweep.txt).
+# Their input's placement does not matter (candidates within 2 %): one try.
+EXTRA_CONFIGS = [("714_ssJ_limiter_s16", 2048, 1), ("toa_ssH_limiter_s16", 2048, 1), ("toa_hrtf256_limiter_s16", 512, 4)]
 
 
 def kernel_tag(kind, in_ch, out_ch):
@@ -642,13 +646,16 @@ def main():
     if rank == 0 and world == 1 and args.workload == "toa_binaural_limiter_s16" and not args.no_extra_configs:
         # BASELINE configs 2, 3 and the HRTF form of 4 in the same process, same harness, one region each
         out["configs"] = {}
-        for name in EXTRA_CONFIGS:
-            w2 = Workload(A, name, args, rank, dev)
+        import copy
+        for name, streams2, tries2 in EXTRA_CONFIGS:
+            a2 = copy.copy(args)
+            a2.streams, a2.placement_tries = streams2, tries2
+            w2 = Workload(A, name, a2, rank, dev)
             p2 = GatherPipeline(w2.pcm, 1, 0, enabled=False)
             for i in range(args.warmup):
                 p2.step(w2.render_into)
             el, kms, em = timed_region(w2, p2, args.steps, 1, dist)
-            assert em >= args.steps * F * fs - 240
+            assert em >= args.steps * w2.F * w2.fs - 240
             v2 = w2.sf_per_step * args.steps / el / 1e6
             r2, dt2 = w2.roofline(kms)
             if w2.kind in ("h2m", "m2m"):
@@ -657,6 +664,7 @@ def main():
                     r2["same_traffic_no_compute"] = pr2
                     r2["frac_of_same_traffic"] = round(w2.sf_per_step / (kms * 1e-3) / 1e6 / pr2["msamples_s"], 4)
             out["configs"][name] = {"value": round(v2, 2), "unit": "Msamples/s", "steps": args.steps,
+                                    "streams_per_gpu": streams2, "frames_per_step": w2.F,
                                     "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": dt2,
                                     "in_channels": w2.in_ch, "out_channels": w2.out_ch,
                                     "input_placement": w2.placement, "roofline": r2}
