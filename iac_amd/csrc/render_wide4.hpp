@@ -24,6 +24,7 @@
 // IAMF_W4_EXP: timing-only elimination builds (WRONG results; never the product, which is 0):
 //   1 = no global PCM stores   2 = no pack / staging / stores   3 = no limiter gain rounds (gain 1)
 //   4 = no projection (y = inputs)   6 = every PCM store redirected to the dump slot (no HBM writes)
+//   7 = plain instead of non-temporal stores   8 = NO staging: each lane stores its own 8*C bytes (results stay RIGHT)
 #ifndef IAMF_W4_EXP
 #define IAMF_W4_EXP 0
 #endif
@@ -857,6 +858,22 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
       // Through the wave's staging area so that every store instruction writes one contiguous run:
       // in output order the chunk is [tail lanes 196..255 | lanes 0..195], so the lanes of a round
       // cover at most two contiguous stretches of the PCM stream.
+#if IAMF_W4_EXP == 8
+      // experiment: no staging — every lane stores its own 8*C contiguous bytes, piece by piece (each store
+      // instruction then writes 64 pieces 8*C bytes apart, left to the L2 to merge)
+      if constexpr (!(DMX || DOWN || MIX)) {
+        const bool ts8 = tv >= kW4FirstTail;
+        const int rel8 = c0 + 4 * tv - (ts8 ? kFChunk : 0);
+        const bool emit8 = ts8 ? rel8 + pos_small >= 0 : 4 * tv < cnt - kDelay;
+        using u4 = __attribute__((ext_vector_type(4))) unsigned;
+#pragma unroll
+        for (int k = 0; k < H2; ++k) {
+          uint8_t *to = emit8 ? pcm + (uint32_t)((rel8 + lead) * (C * 2) + k * 16) : p.dump + (uint32_t)((s * 256 + tv) * 16);
+          __builtin_nontemporal_store(u4{od[4 * k], od[4 * k + 1], od[4 * k + 2], od[4 * k + 3]}, reinterpret_cast<u4 *>(to));
+        }
+      } else
+#endif
+      {
       uint4 *stg = stage + wave * (LR * S);
       const int lane_e = lane;
 #pragma unroll
@@ -918,6 +935,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next round overwrites the staging area
         __builtin_amdgcn_wave_barrier();
+      }
       }
     }
 #endif
