@@ -42,14 +42,28 @@ __host__ __device__ constexpr int wide4_base_floats(int c, int m, int extra) {
   return 4 * kW4TailLanes * c + 2 * kFRing + 2 * (kFRing / 16) + 2 * kFChunk + 2 * kW4Win + ((c + 3) & ~3) * m + 16 +
          extra;  // 0, kW4DmxFloats or kW4MixFloats
 }
+// Workgroups per CU the kernel is sized for.  The kernels are bound by (chunk latency) x (workgroups resident per
+// CU) — DESIGN.md 4.3 — so the light variants (no demixer / mixer, at most 12 output channels) are kept within a third
+// of the CU: <= 52 KiB of LDS here, <= 168 VGPRs by themselves or (M, C <= 12: the 7.1.4 -> 7.1.4 VALU variant sits at
+// 171) by __launch_bounds__; asking the same of the 16-input and down-mixer variants makes them spill.
+__host__ __device__ constexpr int wide4_wgs(int c, int extra) { return (extra == 0 && c <= 12) ? 3 : 2; }
+__host__ __device__ constexpr int wide4_budget_floats(int c, int extra) { return wide4_wgs(c, extra) == 3 ? 13312 : 20480; }
 // PCM staging (per wave): a lane's 8*C output bytes = C/2 16-byte pieces, lane stride padded to an
-// odd number of pieces (conflict-free).  All 64 lanes at once if that fits 80 KB, else 32 per round.
+// odd number of pieces (conflict-free).  All 64 lanes at once if that fits the budget, else 32 per round.
+// The staging area starts ON arr_p (the chunk's 1024 window maxima, the last array of the base block): arr_p is
+// written after barrier (1) and last read before the last barrier of the gain rounds, the staging area (and the
+// demixer's scatter rows, which use it too) only between that barrier and the next chunk's barrier (1).
 __host__ __device__ constexpr int wide4_stage_stride(int c) { return ((c / 2) & 1) ? c / 2 : c / 2 + 1; }
+__host__ __device__ constexpr int wide4_stage_floats(int c, int lanes) { return 4 * lanes * wide4_stage_stride(c) * 4; }
+__host__ __device__ constexpr int wide4_total_floats(int c, int m, int extra, int lanes) {
+  return wide4_base_floats(c, m, extra) +
+         (wide4_stage_floats(c, lanes) > kFChunk ? wide4_stage_floats(c, lanes) - kFChunk : 0);
+}
 __host__ __device__ constexpr int wide4_stage_lanes(int c, int m, int extra) {
-  return wide4_base_floats(c, m, extra) + 4 * 64 * wide4_stage_stride(c) * 4 <= 20480 ? 64 : 32;
+  return wide4_total_floats(c, m, extra, 64) <= wide4_budget_floats(c, extra) ? 64 : 32;
 }
 __host__ __device__ constexpr int wide4_lds_floats(int c, int m, int extra) {
-  return wide4_base_floats(c, m, extra) + 4 * wide4_stage_lanes(c, m, extra) * wide4_stage_stride(c) * 4;
+  return wide4_total_floats(c, m, extra, wide4_stage_lanes(c, m, extra));
 }
 
 using w4_f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -192,7 +206,7 @@ __device__ __forceinline__ void w4_demix(const RenderParams &p, float4 (&x)[M],
 // MIX:  the mixing variant, as in render_fast.hpp: a second element of at most kFIn2 channels rendered
 //       by its own matrix and mixed in, and / or per-sample element / output gain ramps.
 template <int M, int C, bool MFMA, bool DMX, bool DOWN = false, bool MIX = false>
-__global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams p) {
+__global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) ? 3 : 2) void render_wide4_kernel(const RenderParams p) {
   static_assert((C & 1) == 0 && C >= 4 && C <= 24, "even channel counts");
   static_assert(!(DMX && MFMA), "the demixer variant projects on the VALU");
   static_assert(!(DOWN && (MFMA || DMX)), "one renderer");
@@ -207,8 +221,7 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
   float *ring_suf = ring_pm + R;                    // [R]     suffix maxima inside aligned 16-blocks
   float *ring_bm = ring_suf + R;                    // [2][R/16] maxima of aligned 16-blocks, stored twice so
                                                     //           that 'block b - j' needs no wrap
-  float *arr_p = ring_bm + 2 * NB;                     // [1024]  window maxima of the chunk
-  float *arr_g = arr_p + kFChunk;                   // [1024]  limiter gains of the chunk
+  float *arr_g = ring_bm + 2 * NB;                  // [1024]  limiter gains of the chunk
   float *win = arr_g + kFChunk;                     // [kW4Win] ctab[min(n_st + i, n_end)]
   float *head = win + kW4Win;                       // [kW4Win] ctab[i]
   float *mat = head + kW4Win;                       // [M][C4] weights, input-major
@@ -217,7 +230,9 @@ __global__ __launch_bounds__(256, 2) void render_wide4_kernel(const RenderParams
   float *dmx_ws = dmx_rec + 2 * kW4DmxRecs * kW4DmxRec;  // DMX: [192] start window, [192] stop window
   int *dmx_pos = reinterpret_cast<int *>(dmx_ws + 2 * kW4DmxWin);  // DMX: [24] playback position of an IAChannel
   float *mat2 = misc + 16;                           // MIX: [C][4] second element's matrix rows (aliases dmx_rec)
-  uint4 *stage = reinterpret_cast<uint4 *>(misc + 16 + kExtra);  // [4 waves][LR][S] packed PCM
+  float *arr_p = misc + 16 + kExtra;                // [1024]  window maxima of the chunk
+  uint4 *stage = reinterpret_cast<uint4 *>(arr_p);  // [4 waves][LR][S] packed PCM, over arr_p (see wide4_stage_lanes)
+  static_assert(wide4_lds_floats(C, M, kExtra) <= wide4_budget_floats(C, kExtra), "LDS per workgroup");
 
   const int s = blockIdx.x;
   const int t = threadIdx.x;
