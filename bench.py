@@ -216,7 +216,9 @@ SIGNALS = {"hot": "hot (sigma 0.25 + 1.5 bursts)", "quiet": "quiet (sigma 0.05)"
 # 4096 over 8 GPUs); configs 2 and 3 name no batch size, and the wide-layout kernels are bound by chunk latency x
 # workgroups per CU, so they run on a larger shard (2048 streams: +4-8 % over 512, profiles/r02_streams_sweep.txt).
 # Their input's placement does not matter (candidates within 2 %): one try.
-EXTRA_CONFIGS = [("714_ssJ_limiter_s16", 2048, 1), ("toa_ssH_limiter_s16", 2048, 1), ("toa_hrtf256_limiter_s16", 512, 4)]
+# streams per GPU = a whole number of rounds of the workgroups a CU holds (256 CUs x 3 for the 12-channel kernel,
+# x 2 for the 24-channel and HRTF kernels)
+EXTRA_CONFIGS = [("714_ssJ_limiter_s16", 3072, 1), ("toa_ssH_limiter_s16", 2048, 1), ("toa_hrtf256_limiter_s16", 1024, 4)]
 
 
 def kernel_tag(kind, in_ch, out_ch):
@@ -458,7 +460,8 @@ class Workload:
                 dtype = "f32 via split f16 (hi/lo halves, three f16 MFMAs, f32 accumulate)"
                 r.update({"issued_tflops": round(issued, 1), "frac_issued": round(issued / peak, 4),
                           "effective_peak": round(eff_peak, 1), "frac_of_effective_peak": round(tf / eff_peak, 4),
-                          "note": "effective_peak = 2.5 PF / 3 MFMAs per product block x 256/288 useful taps "
+                          "note": "power-limited: the same instruction stream on all-zero data runs 1.5x faster at 2.1 instead "
+                                  "of 1.4 GHz (profiles/r02_fir16/); effective_peak = 2.5 PF / 3 MFMAs per product block x 256/288 useful taps "
                                   "(DESIGN.md 4.2); IAMF_HIP_FIR_F32=1 runs the f32-MFMA stage"})
         return r, dtype
 

@@ -278,7 +278,7 @@ void launch_fir_m(const RenderParams &p, dim3 grid, hipStream_t st) {
   // 8 waves either way: render_fir.hpp / render_fir16.hpp
   if (p.fir_h16 && !getenv("IAMF_HIP_FIR_F32")) {
     static_assert(fast_lds_floats(2, M, 2) * 4 <= 80 * 1024, "two workgroups per CU");
-    hipLaunchKernelGGL((render_fast_kernel<M, 2, 2>), grid, dim3(512), sizeof(float) * (size_t)fast_lds_floats(2, M, 2), st, p);
+    hipLaunchKernelGGL((render_fast_kernel<M, 2, 2>), grid, dim3(256), sizeof(float) * (size_t)fast_lds_floats(2, M, 2), st, p);
   } else {
     hipLaunchKernelGGL((render_fast_kernel<M, 2, 1>), grid, dim3(512), sizeof(float) * (size_t)fast_lds_floats(2, M, 1), st, p);
   }

@@ -34,7 +34,7 @@ void launch_fir_m(const RenderParams &p, hipStream_t st) {
   const dim3 grid((unsigned)p.n_streams);
   if (p.fir_h16 && !getenv("IAMF_HIP_FIR_F32")) {
     static_assert(fast_lds_floats(2, M, 2) * 4 <= 80 * 1024, "two workgroups per CU");
-    hipLaunchKernelGGL((render_fast_kernel<M, 2, 2>), grid, dim3(512), sizeof(float) * (size_t)fast_lds_floats(2, M, 2), st, p);
+    hipLaunchKernelGGL((render_fast_kernel<M, 2, 2>), grid, dim3(256), sizeof(float) * (size_t)fast_lds_floats(2, M, 2), st, p);
   } else {
     hipLaunchKernelGGL((render_fast_kernel<M, 2, 1>), grid, dim3(512), sizeof(float) * (size_t)fast_lds_floats(2, M, 1), st, p);
   }

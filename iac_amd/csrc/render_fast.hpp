@@ -189,8 +189,9 @@ __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
   return i >= kFRing ? i - kFRing : i;
 }
 
-// The HRTF variant runs 512 threads: all eight waves work in fir_stage (ear x quarter of the
-// channels), waves 0..3 alone (`act`) run the stages around it.
+// The f32-MFMA HRTF variant (FIR == 1) runs 512 threads: all eight waves work in fir_stage (ear x quarter of
+// the channels), waves 0..3 alone (`act`) run the stages around it.  The split-f16 variant (FIR == 2) runs 256
+// threads at two waves per SIMD: its stage wants the registers (render_fir16.hpp).
 // DOWN: the element is rendered by the parametric down-mixer (render_downmix.hpp) instead of a matrix.
 // IN2: the mixing variant.  A second element of at most kFIn2 channels (mono, stereo, first-order
 //      ambisonics: a dialogue or commentary track next to the bed) is rendered by its own matrix and
@@ -201,7 +202,7 @@ constexpr int kFIn2 = 4;
 // FIR:  0 = gain matrix; 1 = HRTF stage on the f32 MFMA (render_fir.hpp); 2 = HRTF stage on the f16
 //       MFMA with split operands (render_fir16.hpp)
 template <int M, int OC, int FIR = 0, bool DOWN = false, bool IN2 = false>
-__global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2) void render_fast_kernel(const RenderParams p) {
+__global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR == 2 ? 2 : ((FIR || (M <= 16 && !IN2)) ? 4 : 2)) void render_fast_kernel(const RenderParams p) {
   static_assert(!(FIR && DOWN), "one renderer");
   static_assert(!(IN2 && (FIR || DOWN)), "the second element joins a matrix-rendered first one");
   extern __shared__ float lds[];
@@ -222,8 +223,8 @@ __global__ __launch_bounds__(FIR ? 512 : 256, (FIR || (M <= 16 && !IN2)) ? 4 : 2
   float *fir = misc + 16;               // [kFirLdsFloats]  HRTF staging (FIR variant only)
 
   const int s = blockIdx.x;
-  const bool act = !FIR || threadIdx.x < 256;
-  const int t = FIR ? (int)(threadIdx.x & 255) : (int)threadIdx.x;  // helper waves keep indices in range
+  const bool act = FIR != 1 || threadIdx.x < 256;
+  const int t = FIR == 1 ? (int)(threadIdx.x & 255) : (int)threadIdx.x;  // helper waves keep indices in range
   const int wave = t >> 6;
   const int lane = t & 63;
   const int q = t & 3;
