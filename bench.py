@@ -233,8 +233,8 @@ def kernel_tag(kind, in_ch, out_ch):
         return "render_wide4_kernel<%d, %d, false, true" % (in_ch, out_ch)
     if kind == "fir":
         return "render_fast_kernel<%d, 2, 2" % in_ch
-    if kind == "h2m_lfe":
-        return "render_kernel<%d" % in_ch
+    if kind == "h2m_lfe":   # render_wide4_kernel<.., LFE>, behind the generator's two kernels (render_lfe.hpp)
+        return "render_wide4_kernel<%d, %d, true, false, false, false, true" % (in_ch, out_ch)
     if out_ch <= 2:
         return "render_fast_kernel<%d, %d, 0, false, false" % (in_ch, out_ch)
     # whole 1024-sample chunks of s16: the 4-samples-per-lane kernel (else render_wide_kernel)

@@ -45,6 +45,8 @@ extern "C" int iamf_hip_fir_m2b_has(int m);                                     
 extern "C" int iamf_hip_fir_m2b_launch(const void *params, int m, hipStream_t st);    // iamf_render_fir_m2b.hip
 extern "C" int iamf_hip_wide4_has_mix(int m, int c);                                  // iamf_render_wide4_mix.hip
 extern "C" int iamf_hip_wide4_mix_launch(const void *params, int m, hipStream_t st);  // iamf_render_wide4_mix.hip
+extern "C" int iamf_hip_wide4_has_lfe(int m, int c);                                  // iamf_render_wide4_lfe.hip
+extern "C" int iamf_hip_wide4_lfe_launch(const void *params, int m, hipStream_t st);  // iamf_render_wide4_lfe.hip
 extern "C" int iamf_hip_wide4_has_downmixer(int m, int c);                            // iamf_render_wide4.hip
 extern "C" int iamf_hip_wide4_has_demixer(int m, int c);                              // iamf_render_wide4.hip
 extern "C" int iamf_hip_wide4_has(int m, int c);                                      // iamf_render_wide4.hip
@@ -431,7 +433,14 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return IAMF_HIP_OK;
   }
-  const bool fast = !p.lfe && fast_path_ok(p);   // an LFE slot is filled by the generic kernel only
+  // an LFE slot is filled by render_wide4_kernel<.., LFE> where that exists, else by the generic kernel
+  if (p.lfe && !p.demix_on && !p.dmx_on && !p.in2 && !p.elem_ramp && !p.elem2_ramp && !p.out_ramp && !p.pre_matrix &&
+      wide_path_ok(p, m) && wide4_path_ok(p, m) && iamf_hip_wide4_has_lfe(m, p.out_ch) &&
+      iamf_hip_wide4_lfe_launch(&p, m, st)) {
+    HIPCHK(hipGetLastError());
+    return IAMF_HIP_OK;
+  }
+  const bool fast = !p.lfe && fast_path_ok(p);
   const bool wide = !p.lfe && !fast && wide_path_ok(p, m);
   const bool mixing = p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp;
   if (!p.lfe && (wide || ((p.demix_on || p.dmx_on || mixing) && wide_path_ok(p, m, true))) && wide4_path_ok(p, m) &&
@@ -609,6 +618,8 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     p.lfe = b->d_lfe_u;
     p.lfe_t4 = t4;
     p.lfe_div = b->lfe_div;
+    for (int c = 0; c < b->cfg.out_channels && c < 32; ++c)
+      if (b->src_feed[c] == -2) p.lfe_mask |= 1 << c;
   }
   const size_t lds = sizeof(float) * ((size_t)(p.out_ch + 2) * kRing + 3 * kChunk + kHead + 4 +
                                       ((b->dmx || b->demix) ? (size_t)kChCount * kChunk : 0));

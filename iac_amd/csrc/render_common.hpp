@@ -61,7 +61,7 @@ struct RenderParams {
   int32_t n_atk, n_end;     // limiter table split points
   float thr;
   const int32_t *src_feed;  // device [out_ch]: output slot -> feed index, -1 = silent slot, -2 = LFE slot
-                            // fed by the HOA LFE generator (render_lfe.hpp; generic kernel only)
+                            // fed by the HOA LFE generator (render_lfe.hpp; generic and wide4 kernels)
   // wide4 VALU projection: bit m of nz_mask[g] = some output slot 4g..4g+3 has a non-zero weight for
   // input m; sparse = less than half of those bits are set (then all-zero weight batches are skipped)
   uint32_t nz_mask[6];
@@ -104,6 +104,7 @@ struct RenderParams {
   const float *lfe;         // device, transposed by blocks of 64 streams: element lfe_index(s, k, lfe_t4) (render_lfe.hpp)
   int32_t lfe_t4;           // quads per stream in that buffer
   double lfe_div;           // sqrt(n) of h2m_rdr.c:1162; 0 = the `* 0.5` form (n <= 2)
+  int32_t lfe_mask;         // bit c: output slot c is an LFE slot (src_feed[c] == -2), for render_wide4.hpp
   // ---- HRTF FIR renderer (render_fast_kernel<M, 2, true>): matrix = h[2][M][fir_taps] ----
   int32_t fir_taps;
   const float *fir_hist;    // device [n_streams][M][256] input history before this call

@@ -205,8 +205,11 @@ __device__ __forceinline__ void w4_demix(const RenderParams &p, float4 (&x)[M],
 // DOWN: the element is rendered by the parametric down-mixer (render_downmix.hpp) instead of a matrix.
 // MIX:  the mixing variant, as in render_fast.hpp: a second element of at most kFIn2 channels rendered
 //       by its own matrix and mixed in, and / or per-sample element / output gain ramps.
-template <int M, int C, bool MFMA, bool DMX, bool DOWN = false, bool MIX = false>
+// LFE:  output slots marked in p.lfe_mask carry the HOA LFE generator's output (render_lfe.hpp, p.lfe) instead of a
+//       matrix row (h2m_rdr.c:1154-1184), as in the generic kernel.
+template <int M, int C, bool MFMA, bool DMX, bool DOWN = false, bool MIX = false, bool LFE = false>
 __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) ? 3 : 2) void render_wide4_kernel(const RenderParams p) {
+  static_assert(!(LFE && (DMX || DOWN || MIX)), "the LFE generator belongs to a matrix-rendered ambisonics element");
   static_assert((C & 1) == 0 && C >= 4 && C <= 24, "even channel counts");
   static_assert(!(DMX && MFMA), "the demixer variant projects on the VALU");
   static_assert(!(DOWN && (MFMA || DMX)), "one renderer");
@@ -430,9 +433,15 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
   constexpr int KS = (M + 3) / 4, RT = (C + 15) / 16;
   constexpr int NX = MFMA ? 4 * KS : M;
   float4 x[NX];
+  float4 lq = make_float4(0.f, 0.f, 0.f, 0.f);  // LFE: the generator's output for the lane's 4 samples, fetched with them
   float drec[DOWN ? 11 : 1];  // DOWN: the frame record (iamf_hip_dmx_frame) of the lane's samples, fetched with them
   const int down_nfr = DOWN ? (p.total + fs - 1) / fs : 0;
   auto load_x = [&](int cbase, int tt) {
+    if constexpr (LFE) {  // transposed by blocks of 64 streams (lfe_index, render_lfe.hpp); unconditional like the rest
+      const int k0 = cbase + 4 * tt;
+      const int k = k0 < p.total ? k0 : 4 * tt;
+      lq = ld_stream4(p.lfe + (((((int64_t)(s >> 6) * p.lfe_t4 + (k >> 2)) * 64 + (s & 63)) << 2)));
+    }
     if constexpr (MIX) {
       // the lane's own 4 samples (lanes past the end of a short last chunk re-read the call's last quad)
       int k = cbase + 4 * tt;
@@ -549,6 +558,18 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
 
     // ---- element renderer + gains (reference operation order), 4 slots x 4 samples at a time ----
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 lv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (LFE) {  // `* 0.5` or `/ sqrt(n)`: double expressions narrowed by the store (h2m_rdr.c:1162)
+      const double dv = p.lfe_div;
+      if (dv == 0.0)
+        lv = make_float4((float)((double)lq.x * 0.5), (float)((double)lq.y * 0.5), (float)((double)lq.z * 0.5), (float)((double)lq.w * 0.5));
+      else
+        lv = make_float4((float)((double)lq.x / dv), (float)((double)lq.y / dv), (float)((double)lq.z / dv), (float)((double)lq.w / dv));
+    }
+    auto slot_value = [&](int c, const float4 v) -> float4 {  // what slot c carries before the gains
+      if constexpr (LFE) return ((p.lfe_mask >> c) & 1) ? lv : v;
+      return v;
+    };
     if constexpr (DOWN) {
       float4 cf[5];
       const int kk = c0 + 4 * tv;
@@ -610,7 +631,7 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
       }
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        const float4 v = gains4(c, y[c]);
+        const float4 v = gains4(c, slot_value(c, y[c]));
         y[c] = v;
         pm.x = fmaxf(pm.x, fabsf(v.x));
         pm.y = fmaxf(pm.y, fabsf(v.y));
@@ -633,7 +654,7 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (4 * g + i < C) {
-            const float4 v = gains4(4 * g + i, acc[i]);
+            const float4 v = gains4(4 * g + i, slot_value(4 * g + i, acc[i]));
             y[4 * g + i] = v;
             pm.x = fmaxf(pm.x, fabsf(v.x));
             pm.y = fmaxf(pm.y, fabsf(v.y));

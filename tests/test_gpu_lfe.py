@@ -39,7 +39,7 @@ def test_many_streams_lane_mapping_and_state_vs_oracle():
     S, fs, F = 150, 960, 6
     x = np.stack([LC.programme(900 + s, 16, fs * F) * np.float32(0.5 + (s % 7) * 0.1) for s in range(S)])
     mx, omx = A.get_h2m_matrix(3, A.SS["B"]), O.get_h2m(3, O.SS["B"])
-    got = G.hip_render(mx, 6, x, frame_size=fs, frames_per_call=[3, 1, 2], lfe_hoa=True)
+    got = G.hip_render(mx, 6, x, frame_size=fs, frames_per_call=[3, 1, 2], lfe_hoa=True, projection=A.PROJ_EXACT)
     for s in list(range(0, S, 13)) + [63, 64, 127, 128, 149]:
         want = O.stream_run(omx, 6, x[s], fs, lfe_rate=48000)
         assert np.array_equal(got[s], want), s
@@ -65,9 +65,45 @@ def test_pipeline_formats_vs_oracle(fmt, bd):
     fs, F = 1024, 4
     x = np.stack([LC.programme(300 + s, 16, fs * F) for s in range(3)])
     mx, omx = A.get_h2m_matrix(3, A.SS["J"]), O.get_h2m(3, O.SS["J"])
-    got = G.hip_render(mx, 12, x, frame_size=fs, fmt=fmt, lfe_hoa=True)
+    got = G.hip_render(mx, 12, x, frame_size=fs, fmt=fmt, lfe_hoa=True, projection=A.PROJ_EXACT)
     for s in range(3):
         assert np.array_equal(got[s], O.stream_run(omx, 12, x[s], fs, bit_depth=bd, lfe_rate=48000)), s
+
+
+W4 = [(1, "B", 6), (2, "C", 8), (3, "D", 10), (3, "J", 12), (1, "H", 24), (3, "H", 24), (2, "L312", 6), (3, "L712", 10)]
+
+
+@pytest.mark.parametrize("order,lay,ch", W4, ids=["o%d_%s" % (o, l) for o, l, _ in W4])
+def test_wide4_lfe_variant_bit_exact_vs_oracle_and_generic(order, lay, ch, monkeypatch):
+    """16-bit PCM, limiter on, whole 1024-sample chunks: render_wide4_kernel<.., LFE> fills the LFE slot.  A hot programme (the limiter works), three calls with the filter and limiter state carried, the last one
+    ending in a short chunk.  Exact projection: bit-equal to the oracle, and to the generic kernel's output."""
+    fs, calls = 1024, [3, 2, 1]
+    m, F = (order + 1) ** 2, 6
+    x = np.stack([LC.programme(500 + 7 * s + order, m, fs * F) * np.float32(2.5) for s in range(3)])
+    mx, omx = A.get_h2m_matrix(order, A.SS[lay]), O.get_h2m(order, O.SS[lay])
+    got = G.hip_render(mx, ch, x, frame_size=fs, frames_per_call=calls, lfe_hoa=True, projection=A.PROJ_EXACT)
+    monkeypatch.setenv("IAMF_HIP_NO_WIDE4", "1")
+    gen = G.hip_render(mx, ch, x, frame_size=fs, frames_per_call=calls, lfe_hoa=True, projection=A.PROJ_EXACT)
+    monkeypatch.delenv("IAMF_HIP_NO_WIDE4")
+    for s in range(3):
+        want = O.stream_run(omx, ch, x[s], fs, lfe_rate=48000)
+        assert np.array_equal(got[s], want), s
+        assert np.array_equal(gen[s], want), s
+    lfe_slots = [c for c in range(ch) if got[0][:, c].any() and not G.hip_render(
+        mx, ch, x[:1], frame_size=fs, projection=A.PROJ_EXACT)[0][:, c].any()]
+    assert lfe_slots == [mx.lfe1], lfe_slots   # silent without the generator, alive with it
+
+
+def test_wide4_lfe_variant_on_the_mfma_projection_within_one_lsb():
+    """the default projection of an ambisonics element (f32 MFMA, +-1 LSB)"""
+    fs, F = 1024, 4
+    x = np.stack([LC.programme(640 + s, 16, fs * F) for s in range(2)])
+    mx, omx = A.get_h2m_matrix(3, A.SS["J"]), O.get_h2m(3, O.SS["J"])
+    got = G.hip_render(mx, 12, x, frame_size=fs, lfe_hoa=True)
+    for s in range(2):
+        want = O.stream_run(omx, 12, x[s], fs, lfe_rate=48000)
+        assert np.abs(got[s].astype(np.int32) - want.astype(np.int32)).max() <= 1
+        assert np.abs(got[s][:, mx.lfe1].astype(np.int32)).max() > 1000
 
 
 def test_switch_off_is_the_default_build():
