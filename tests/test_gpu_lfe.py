@@ -94,6 +94,17 @@ def test_wide4_lfe_variant_bit_exact_vs_oracle_and_generic(order, lay, ch, monke
     assert lfe_slots == [mx.lfe1], lfe_slots   # silent without the generator, alive with it
 
 
+@pytest.mark.parametrize("fs,calls", [(1024, [40]), (960, [37, 3])], ids=["1024x40", "960x37+3"])
+def test_long_calls_vs_oracle(fs, calls):
+    """calls of tens of frames (what a batch deployment issues): 70 streams = two blocks of the recurrence kernel"""
+    S, F = 70, sum(calls)
+    x = np.stack([LC.programme(1200 + s, 16, fs * F) * np.float32(1.0 + (s % 5) * 0.4) for s in range(S)])
+    mx, omx = A.get_h2m_matrix(3, A.SS["J"]), O.get_h2m(3, O.SS["J"])
+    got = G.hip_render(mx, 12, x, frame_size=fs, frames_per_call=calls, lfe_hoa=True, projection=A.PROJ_EXACT)
+    for s in (0, 33, 63, 64, 69):
+        assert np.array_equal(got[s], O.stream_run(omx, 12, x[s], fs, lfe_rate=48000)), s
+
+
 def test_wide4_lfe_variant_on_the_mfma_projection_within_one_lsb():
     """the default projection of an ambisonics element (f32 MFMA, +-1 LSB)"""
     fs, F = 1024, 4
