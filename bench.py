@@ -262,7 +262,7 @@ class Workload:
         self.S, self.F, self.fs = S, F, fs
         batch = self.batch = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True,
                                      fir_taps=FIR_TAPS if kind == "fir" else 0, lfe_hoa=kind == "h2m_lfe")
-        self.stride_bytes = F * fs * out_ch * 2
+        self.stride_bytes = F * fs * out_ch * 2 + args.pcm_pad_kb * 1024
         self.pcm = [torch.zeros((S, self.stride_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
         self.stream = torch.cuda.current_stream().cuda_stream
         self.stream_stride, self.frame_stride = F * in_ch * fs + args.pad_kb * 256, in_ch * fs
@@ -512,6 +512,8 @@ def parse_args(argv=None):
                     help="setup: allocate up to this many candidate buffers for the element PCM, measure a few "
                          "launches on each and keep the fastest (the rate is bimodal per allocation, ~13 %% apart; "
                          "1 = take the first allocation as it comes)")
+    ap.add_argument("--pcm-pad-kb", type=int, default=0,
+                    help="the same stagger for the streams' PCM output regions (stream stride = the call's bytes + this)")
     ap.add_argument("--pad-kb", type=int, default=4,
                     help="stagger the streams' input regions: stream stride = frames * channels * frame size "
                          "+ this many KiB, so that the workgroups, which advance in step, are not all on the "
