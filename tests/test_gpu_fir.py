@@ -42,7 +42,11 @@ def fir64(h, x):
 
 
 @pytest.mark.parametrize("m,taps,fs,calls", [(16, 256, 1024, [2, 1, 3]), (4, 100, 1024, [3]), (9, 33, 960, [1, 1, 2]),
-                                             (1, 256, 1024, [2]), (16, 64, 2048, [1, 1])])
+                                             (1, 256, 1024, [2]), (16, 64, 2048, [1, 1]),
+                                             # calls longer than one 4096-sample pass of the stage (the last pass partial),
+                                             # and the shortest filters (one and two K steps of 32 taps)
+                                             (16, 256, 1024, [9, 5]), (9, 200, 960, [11]), (4, 1, 1024, [5]),
+                                             (9, 17, 1024, [5, 1]), (4, 18, 1024, [6])])
 def test_fir_stage_matches_float64_convolution(hip, m, taps, fs, calls):
     A, G = hip
     F = sum(calls)
@@ -60,7 +64,7 @@ def test_fir_stage_matches_float64_convolution(hip, m, taps, fs, calls):
 
 
 @pytest.mark.parametrize("m,taps,fs,calls", [(2, 256, 1024, [2, 1]), (6, 128, 1024, [3]), (8, 256, 960, [1, 2]),
-                                             (10, 200, 1024, [2]), (12, 256, 1024, [1, 1, 2])])
+                                             (10, 200, 1024, [2]), (12, 256, 1024, [1, 1, 2]), (12, 256, 1024, [10, 3])])
 def test_m2b_channel_based_element_matches_float64_convolution(hip, m, taps, fs, calls):
     """M2B (the role of m2b_rdr.c:103-121): a channel-based element of 2 / 6 / 8 / 10 / 12 loudspeaker
     channels through one HRIR pair per loudspeaker; the LFE's pair is zero where the layout has one"""
