@@ -28,6 +28,8 @@
 // ds_read_b128 that is not 16-byte aligned is served one lane per cycle (tools/lds_unaligned_probe.hip:
 // 64 instead of 23 cycles per wave-read at 2, 4 or 8 bytes off): 3.7; with the reads forced aligned
 // (wrong taps) 13.5 at one chunk per pass.
+// Round 2: four waves x (2 ears x 4 tiles), two operand sets, branch-free prefetch, no scratch: 18.2-18.8
+// (see fir_stage16 below); from there on the kernel is power-limited (profiles/r02_fir16/).
 #pragma once
 
 // IAMF_F16_EXP: timing-only elimination builds (WRONG results; the product is 0):
