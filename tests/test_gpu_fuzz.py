@@ -235,3 +235,45 @@ def test_random_demixer_configuration_matches_oracle(hip, seed):
             want = O.stream_run(omx, och, xd, fs)
         assert got[s].shape == want.shape, (seed, layers, out, s)
         assert np.array_equal(got[s], want), (seed, layers, out, s)
+
+
+LFE_OUT = ["B", "C", "D", "F", "H", "I", "J", "L712", "L312"]
+
+
+@pytest.mark.parametrize("seed", range(_N_SEEDS or 24))
+def test_random_lfe_configuration_matches_oracle(hip, seed):
+    """the same sweep with the HOA LFE generator on: ambisonics of order 1..3 to a layout with an LFE
+    channel, the generator's filter designed for the drawn sample rate, its state carried over the call partition.
+    The cases that are 16-bit, limited and chunk-aligned take render_wide4_kernel<.., LFE>, the others the generic
+    kernel."""
+    A, G = hip
+    rng = np.random.default_rng(3000 + seed)
+    out = LFE_OUT[int(rng.integers(len(LFE_OUT)))]
+    order = int(rng.integers(1, 4))
+    m = (order + 1) ** 2
+    mx, omx = A.get_h2m_matrix(order, A.SS[out]), O.get_h2m(order, O.SS[out])
+    assert mx.lfe1 >= 0
+    ch = A.layout_channels(A.SS[out])
+    fs = int(rng.choice([256, 480, 960, 1024, 1024, 1024, 2048]))
+    F = int(rng.integers(2, 9))
+    S = int(rng.integers(1, 4))
+    bits = int(rng.choice([16, 16, 16, 24, 32]))
+    fmt = {16: A.FMT_S16, 24: A.FMT_S24, 32: A.FMT_S32}[bits]
+    limiter = bool(rng.random() < 0.85)
+    thr = float(rng.choice([-1.0, -1.0, -3.0]))
+    rate = int(rng.choice([48000, 48000, 44100, 96000, 16000]))
+    pick = lambda: float(rng.choice([1.0, 1.0, 0.5, 1.7]))
+    eg, og = [pick() for _ in range(S)], [pick() for _ in range(S)]
+    x = np.stack([synth.hot(seed * 10 + s, m, F * fs, sigma=float(rng.choice([0.1, 0.3])), burst_phase=int(rng.integers(0, fs)),
+                            burst_period=int(rng.integers(900, 4000))) for s in range(S)])
+    t = np.arange(F * fs, dtype=np.float64) / rate
+    x[:, 0] += (0.3 * np.sin(2 * np.pi * 60.0 * t)).astype(np.float32)    # something for the 120 Hz low-pass to pass
+    got = G.hip_render(mx, ch, x, frame_size=fs, fmt=fmt, limiter=limiter, flush=limiter, frames_per_call=_partition(rng, F),
+                       gains=dict(element=eg, output=og, loudness=[1.0] * S), threshold_db=thr, sample_rate=rate,
+                       projection=A.PROJ_EXACT, lfe_hoa=True)
+    for s in range(S):
+        want = O.stream_run(omx, ch, x[s], fs, flush=limiter, element_gain=eg[s], output_gain=og[s], limiter_on=int(limiter),
+                            thr_db=thr, rate=rate, bit_depth=bits, lfe_rate=rate)
+        assert got[s].shape == want.shape, (seed, out, order, s, got[s].shape, want.shape)
+        assert np.array_equal(got[s], want), (seed, out, order, fs, F, bits, limiter, rate, s)
+    assert any(np.any(g[..., mx.lfe1, :] if g.ndim == 3 else g[:, mx.lfe1]) for g in got)
