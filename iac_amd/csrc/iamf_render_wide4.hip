@@ -87,6 +87,7 @@ bool launch_m(const RenderParams &p, hipStream_t st) {
     case 8: launch_mc<M, 8>(p, st); return true;
     case 10: launch_mc<M, 10>(p, st); return true;
     case 12: launch_mc<M, 12>(p, st); return true;
+    case 14: launch_mc<M, 14>(p, st); return true;   // Sound System G (4+9+0)
     case 24: launch_mc<M, 24>(p, st); return true;
     default: return false;
   }
@@ -97,7 +98,7 @@ bool launch_m(const RenderParams &p, hipStream_t st) {
 // 1 if a render_wide4_kernel instance exists for m inputs and c output channels
 extern "C" __attribute__((visibility("hidden"))) int iamf_hip_wide4_has(int m, int c) {
   return (m == 4 || m == 6 || m == 8 || m == 9 || m == 10 || m == 12 || m == 16) &&
-         (c == 6 || c == 8 || c == 10 || c == 12 || c == 24);
+         (c == 6 || c == 8 || c == 10 || c == 12 || c == 14 || c == 24);
 }
 
 // 1 if the down-mixer variant exists: 7.1.4 -> {10, 8, 6}, 5.1.4 / 7.1.2 -> {8, 6}, 5.1.2 / 7.1 -> 6 channels

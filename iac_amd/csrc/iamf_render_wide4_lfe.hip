@@ -42,6 +42,7 @@ bool launch_m(const RenderParams &p, hipStream_t st) {
     case 8: launch_mc<M, 8>(p, st); return true;
     case 10: launch_mc<M, 10>(p, st); return true;
     case 12: launch_mc<M, 12>(p, st); return true;
+    case 14: launch_mc<M, 14>(p, st); return true;
     case 24: launch_mc<M, 24>(p, st); return true;
     default: return false;
   }
@@ -51,7 +52,7 @@ bool launch_m(const RenderParams &p, hipStream_t st) {
 
 // 1 if the LFE variant exists for an ambisonics element of m channels and c output channels
 extern "C" __attribute__((visibility("hidden"))) int iamf_hip_wide4_has_lfe(int m, int c) {
-  return (m == 4 || m == 9 || m == 16) && (c == 6 || c == 8 || c == 10 || c == 12 || c == 24);
+  return (m == 4 || m == 9 || m == 16) && (c == 6 || c == 8 || c == 10 || c == 12 || c == 14 || c == 24);
 }
 
 // params: the caller's RenderParams (same definition, render_common.hpp); returns 1 if launched

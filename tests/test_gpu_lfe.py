@@ -70,7 +70,7 @@ def test_pipeline_formats_vs_oracle(fmt, bd):
         assert np.array_equal(got[s], O.stream_run(omx, 12, x[s], fs, bit_depth=bd, lfe_rate=48000)), s
 
 
-W4 = [(1, "B", 6), (2, "C", 8), (3, "D", 10), (3, "J", 12), (1, "H", 24), (3, "H", 24), (2, "L312", 6), (3, "L712", 10)]
+W4 = [(1, "B", 6), (2, "C", 8), (3, "D", 10), (3, "J", 12), (3, "G", 14), (1, "H", 24), (3, "H", 24), (2, "L312", 6), (3, "L712", 10)]
 
 
 @pytest.mark.parametrize("order,lay,ch", W4, ids=["o%d_%s" % (o, l) for o, l, _ in W4])

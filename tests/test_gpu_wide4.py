@@ -19,7 +19,7 @@ def hip():
     return A, G
 
 
-LAYOUTS = ["B", "C", "D", "J", "H"]  # 6, 8, 10, 12, 24 channels
+LAYOUTS = ["B", "C", "D", "J", "G", "H"]  # 6, 8, 10, 12, 14, 24 channels
 
 
 SOURCES = dict(L714=12, L514=10, L71=8, L51=6, TOA=16, SOA=9, FOA=4)
