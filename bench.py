@@ -367,8 +367,9 @@ class Workload:
             self.batch.reset()
             ms = float(np.median([a.elapsed_time(b) for a, b in ev[1:]]))
             rates.append(round(self.sf_per_step / (ms * 1e-3) / 1e6, 1))
-            if i >= 2 and rates[-1] >= 0.97 * max(rates) and (max(rates) > 1.07 * min(rates) or i >= 3):
-                break   # the current candidate is as fast as any seen, and either both modes showed or four agree
+            if i >= 2 and rates[-1] >= 0.97 * max(rates) and max(rates) > 1.07 * min(rates):
+                break   # both modes showed and the current candidate is in the fast one; else all `tries` are looked at
+                        # (on some devices every allocation is in the slow mode)
         best = int(np.argmax(rates))
         self.x = cands[best]
         self.placement = {"candidates_msamples_s": rates, "picked": best,
