@@ -489,6 +489,26 @@ def timed_region(wl, pipe, steps, world, dist):
     return elapsed, kernel_ms, emitted
 
 
+def device_info():
+    """What rocm-smi says about this rank's card (memory vendor and clocks): the render kernels' rate differs by
+    ~13 % between MI355X devices, and this is what can be read in-band about the one measured."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showmemvendor", "--showtemp", "--showpower",
+                              "--showcomputepartition", "--showmemorypartition", "--json"],
+                             capture_output=True, text=True, timeout=20).stdout
+        d = json.loads(out[out.index("{"):])
+        card = d.get("card%d" % int(os.environ.get("LOCAL_RANK", "0")), next(iter(d.values())))
+        info = {"memory_vendor": card.get("GPU memory vendor"), "mclk": card.get("mclk clock speed:"),
+                "fclk": card.get("fclk clock speed:"), "sclk_now": card.get("sclk clock speed:")}
+        for k, v in card.items():
+            if "emperature" in k or "ower" in k or "artition" in k:
+                info[k.strip(" :")] = v
+        return info
+    except Exception as e:   # noqa: BLE001 — a diagnostic, never a reason to fail the bench
+        return {"error": str(e)[:80]}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -626,6 +646,7 @@ def main():
             "x_realtime": round(value / 0.048, 1),
             "ranks_seen": ranks_seen, "rccl_version": rccl,
             "launched_by": os.environ.get("IAMF_LAUNCHED_BY", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
+            "device": device_info(),
             "repeats": {"n": len(regions), "steps_each": args.steps, "reported": "median",
                         "ms_per_step": [round(e / args.steps * 1e3, 4) for e, _ in regions],
                         "value_min": round(total_sf / max(e for e, _ in regions) / 1e6, 2),
