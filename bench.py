@@ -527,6 +527,10 @@ def parse_args(argv=None):
                     help="N>1: gather packed PCM to rank 0 over RCCL once after the last step (default, the "
                          "job's one exchange), after every step (overlapped with the next render), or never")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="development only: run the N > 1 control flow (launcher, barriers, max over ranks, gather, the "
+                         "JSON line) with every rank on GPU 0 and gloo instead of RCCL, which refuses two ranks on one "
+                         "device.  The line is marked `rehearsal` and its value means nothing")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="N=1, default workload: do not also measure BASELINE configs 2, 3 and the HRTF form of 4")
     ap.add_argument("--placement-tries", type=int, default=10,
@@ -564,47 +568,58 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
-    if torch.cuda.device_count() <= local_rank:
+    rehearse = bool(args.rehearse_one_gpu)
+    dev_index = 0 if rehearse else local_rank
+    if torch.cuda.device_count() <= dev_index:
         raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     ranks_seen, rccl = 1, None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         ranks_seen = dist.get_world_size()
         try:
-            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            rccl = None if rehearse else ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             rccl = "unknown"
         # every rank must sit on its own device: gather (device index, PCI bus id) and compare
-        mine = torch.tensor([local_rank], dtype=torch.int64, device=dev)
+        mine = torch.tensor([dev_index], dtype=torch.int64, device="cpu" if rehearse else dev)
         seen = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(seen, mine)
         devices_seen = sorted(int(t.item()) for t in seen)
-        if len(set(devices_seen)) != world:
+        if len(set(devices_seen)) != world and not rehearse:
             raise SystemExit("ranks share a device: %s" % devices_seen)
+
+    def gather_to_rank0(t, recv):   # gloo (the rehearsal) moves CPU tensors only
+        if rehearse:
+            dist.gather(t.cpu(), recv if rank == 0 else None, dst=0)
+        else:
+            dist.gather(t, recv if rank == 0 else None, dst=0)
 
     import iac_amd as A
     from iac_amd.sharding import GatherPipeline
     wl = Workload(A, args.workload, args, rank, dev)
     S, F, fs = wl.S, wl.F, wl.fs
-    pipe = GatherPipeline(wl.pcm, world, rank, enabled=world > 1 and args.gather == "step")
+    pipe = GatherPipeline(wl.pcm, world, rank, enabled=world > 1 and args.gather == "step" and not rehearse)
     final_recv = None
     if world > 1 and args.gather == "final" and rank == 0:
-        final_recv = [torch.empty_like(wl.pcm[0]) for _ in range(world)]
+        final_recv = [torch.empty_like(wl.pcm[0], device="cpu" if rehearse else dev) for _ in range(world)]
 
     for i in range(args.warmup):
         pipe.step(wl.render_into)
     pipe.drain()
     if world > 1 and args.gather == "final":   # untimed: sets up RCCL's point-to-point connections
-        dist.gather(wl.pcm[0], final_recv, dst=0)
+        gather_to_rank0(wl.pcm[0], final_recv)
 
     regions = []
     for r in range(max(1, args.repeats)):
         elapsed, kernel_ms, emitted = timed_region(wl, pipe, args.steps, world, dist)
         assert emitted >= args.steps * F * fs - 240, "every step must emit its F*fs sample-frames per stream"
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)   # the slowest rank's time
         regions.append((float(tmax.item()), kernel_ms))
@@ -614,7 +629,7 @@ def main():
         # It happens once per job whatever the number of steps, so it is timed on its own and
         # reported beside the K-step rate instead of being folded into it.
         tg = time.perf_counter()
-        dist.gather(wl.pcm[(args.steps * len(regions) - 1) % 2], final_recv, dst=0)
+        gather_to_rank0(wl.pcm[(args.steps * len(regions) - 1) % 2], final_recv)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -665,6 +680,9 @@ def main():
         }
         if wl.kind == "fir":
             out["config"]["parity"] = "unpinned (HRTF arithmetic is not in the reference tree)"
+        if rehearse:
+            out["rehearsal"] = "all %d ranks on GPU 0 over gloo: the control flow of the N > 1 path only, the value means nothing" % world
+            out["data"] = "REHEARSAL - not a measurement"
         if out["n_gpus"] != args.gpus:   # cannot happen past the check above; never print a line for another job
             raise SystemExit("n_gpus %d != --gpus %d" % (out["n_gpus"], args.gpus))
     headline_kind = wl.kind
