@@ -218,7 +218,7 @@ SIGNALS = {"hot": "hot (sigma 0.25 + 1.5 bursts)", "quiet": "quiet (sigma 0.05)"
 # Their input's placement does not matter (candidates within 2 %): one try.
 # streams per GPU = a whole number of rounds of the workgroups a CU holds (256 CUs x 3 for the 12-channel kernel,
 # x 2 for the 24-channel and HRTF kernels)
-EXTRA_CONFIGS = [("714_ssJ_limiter_s16", 3072, 1), ("toa_ssH_limiter_s16", 2048, 1), ("toa_hrtf256_limiter_s16", 1024, 4)]
+EXTRA_CONFIGS = [("714_ssJ_limiter_s16", 3072, 8), ("toa_ssH_limiter_s16", 2048, 8), ("toa_hrtf256_limiter_s16", 1024, 4)]
 
 
 def kernel_tag(kind, in_ch, out_ch):
@@ -533,7 +533,7 @@ def parse_args(argv=None):
                          "device.  The line is marked `rehearsal` and its value means nothing")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="N=1, default workload: do not also measure BASELINE configs 2, 3 and the HRTF form of 4")
-    ap.add_argument("--placement-tries", type=int, default=10,
+    ap.add_argument("--placement-tries", type=int, default=48,
                     help="setup: allocate up to this many candidate buffers for the element PCM, measure a few "
                          "launches on each and keep the fastest (the rate is bimodal per allocation, ~13 %% apart; "
                          "1 = take the first allocation as it comes)")

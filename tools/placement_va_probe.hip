@@ -1,0 +1,68 @@
+// placement_va_probe.hip — the two placement modes of DESIGN.md 3 outside the bench: a dozen 2.1 GB allocations of the
+// input (kept alive), the headline traffic shape timed on each, with the virtual address hipMalloc returned.
+//   hipcc --offload-arch=gfx950 -O3 tools/placement_va_probe.hip -o /tmp/pvp && /tmp/pvp
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+using v4 = __attribute__((ext_vector_type(4))) float;
+using u4 = __attribute__((ext_vector_type(4))) unsigned;
+
+template <int ROWS, int PIECES>
+__global__ __launch_bounds__(256, 2) void k_stream(const v4 *in, u4 *out, int chunks, long in_stride4) {
+  const int s = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const v4 *src = in + (long)s * in_stride4;
+  u4 *dst = out + (long)s * chunks * PIECES * 256;
+  v4 x[ROWS];
+#pragma unroll
+  for (int m = 0; m < ROWS; ++m) x[m] = __builtin_nontemporal_load(src + m * 256 + t);
+  for (int c = 0; c < chunks; ++c) {
+    float a = 0.f;
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) a += x[m].x + x[m].y + x[m].z + x[m].w;
+    if (c + 1 < chunks) {
+#pragma unroll
+      for (int m = 0; m < ROWS; ++m) x[m] = __builtin_nontemporal_load(src + ((long)(c + 1) * ROWS + m) * 256 + t);
+    }
+    __syncthreads();
+    const u4 w = {__float_as_uint(a), (unsigned)c, (unsigned)t, 0u};
+#pragma unroll
+    for (int k = 0; k < PIECES; ++k) __builtin_nontemporal_store(w, dst + ((long)c * PIECES * 4 + wave * PIECES + k) * 64 + lane);
+  }
+}
+
+int main() {
+  const int S = 512, chunks = 64, N = 48;
+  const size_t in_bytes = (size_t)S * (chunks * 16 * 4096 + 4096);
+  const long stride4 = (long)chunks * 16 * 256 + 256;
+  u4 *out, *out2;
+  (void)hipMalloc(&out, (size_t)S * chunks * 4096);
+  (void)hipMemset(out, 0, (size_t)S * chunks * 4096);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  v4 *in[N];
+  for (int i = 0; i < N; ++i) {
+    if (hipMalloc(&in[i], in_bytes) != hipSuccess) { printf("alloc %d failed\n", i); return 1; }
+    (void)hipMemset(in[i], 0, in_bytes);
+  }
+  (void)hipMalloc(&out2, (size_t)S * chunks * 4096);   // a second output buffer, allocated AFTER the inputs
+  (void)hipMemset(out2, 0, (size_t)S * chunks * 4096);
+  printf("out %p  out2 %p\n", (void *)out, (void *)out2);
+  for (int pass = 0; pass < 2; ++pass)
+    for (int i = 0; i < N; ++i) {
+      float best = 1e9f;
+      for (int rep = 0; rep < 5; ++rep) {
+        (void)hipEventRecord(e0);
+        k_stream<16, 1><<<S, 256>>>(in[i], pass ? out2 : out, chunks, stride4);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < best) best = ms;
+      }
+      printf("pass %d buffer %2d  va %p  (va >> 30) %% 64 = %2llu  %.3f ms  %5.0f GB/s\n", pass, i, (void *)in[i],
+             (unsigned long long)(((uintptr_t)in[i]) >> 30) % 64, best, (double)S * chunks * 17 * 4096 / best / 1e6);
+    }
+  return 0;
+}
