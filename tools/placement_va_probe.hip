@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256, 2) void k_stream(const v4 *in, u4 *out, int ch
   }
 }
 
-int main() {
+int main(int argc, char **argv) {
+  const bool contiguous = argc > 1;  // any argument: hipExtMallocWithFlags(hipDeviceMallocContiguous) instead of hipMalloc
   const int S = 512, chunks = 64, N = 48;
   const size_t in_bytes = (size_t)S * (chunks * 16 * 4096 + 4096);
   const long stride4 = (long)chunks * 16 * 256 + 256;
@@ -43,7 +44,9 @@ int main() {
   (void)hipEventCreate(&e1);
   v4 *in[N];
   for (int i = 0; i < N; ++i) {
-    if (hipMalloc(&in[i], in_bytes) != hipSuccess) { printf("alloc %d failed\n", i); return 1; }
+    const hipError_t e = contiguous ? hipExtMallocWithFlags(reinterpret_cast<void **>(&in[i]), in_bytes, hipDeviceMallocContiguous)
+                                    : hipMalloc(&in[i], in_bytes);
+    if (e != hipSuccess) { printf("alloc %d failed: %s\n", i, hipGetErrorString(e)); return 1; }
     (void)hipMemset(in[i], 0, in_bytes);
   }
   (void)hipMalloc(&out2, (size_t)S * chunks * 4096);   // a second output buffer, allocated AFTER the inputs
