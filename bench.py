@@ -276,8 +276,11 @@ class Workload:
             batch.set_projection(Pm.astype(np.float32))
         self.placement = None
         self.x = None
+        self.pcm_placement = None
         if args.placement_tries > 1 and kind in ("h2m", "m2m", "fir", "h2m_lfe", "h2m_proj"):
             self.pick_placement(args.placement_tries, dev)
+            if args.pcm_placement_tries > 2 and out_ch > 2:
+                self.pick_pcm_placement(args.pcm_placement_tries, dev)
 
         x = synth_hot_device(S, in_ch, F, fs, 1000 + rank, dev)
         if args.signal == "quiet":
@@ -375,6 +378,30 @@ class Workload:
         self.placement = {"candidates_msamples_s": rates, "picked": best,
                           "note": "same kernel on silence, different allocations of the input buffer, tried before "
                                   "anything else is allocated (setup, untimed)"}
+        del cands
+        torch.cuda.empty_cache()
+
+    def pick_pcm_placement(self, tries, dev):
+        """Setup, untimed: the same search for the two PCM output buffers of the multi-channel layouts, whose traffic is
+        a third (cfg2) to 43 % (cfg3) writes: tools/placement_va_probe.hip `out` shows 5.3 - 6.3 TB/s for the cfg3 shape
+        depending on where the OUTPUT lies.  `tries` candidates (the two already allocated among them), the chosen
+        input, silence; the best two stay."""
+        cands = list(self.pcm) + [torch.zeros((self.S, self.stride_bytes), dtype=torch.uint8, device=dev) for _ in range(tries - 2)]
+        rates = []
+        for buf in cands:
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+            for a, b in ev:
+                a.record()
+                self.batch.render(self.x.data_ptr(), self.stream_stride, self.frame_stride, self.F,
+                                  buf.data_ptr(), self.stride_bytes, self.stream)
+                b.record()
+            torch.cuda.synchronize()
+            self.batch.reset()
+            ms = float(np.median([a.elapsed_time(b) for a, b in ev[1:]]))
+            rates.append(round(self.sf_per_step / (ms * 1e-3) / 1e6, 1))
+        order = [int(i) for i in np.argsort(rates)[::-1]]
+        self.pcm = [cands[order[0]], cands[order[1]]]
+        self.pcm_placement = {"candidates_msamples_s": rates, "picked": order[:2]}
         del cands
         torch.cuda.empty_cache()
 
@@ -537,6 +564,9 @@ def parse_args(argv=None):
                     help="setup: allocate up to this many candidate buffers for the element PCM, measure a few "
                          "launches on each and keep the fastest (the rate is bimodal per allocation, ~13 %% apart; "
                          "1 = take the first allocation as it comes)")
+    ap.add_argument("--pcm-placement-tries", type=int, default=10,
+                    help="setup, layouts of more than two channels: candidates for the two PCM output buffers (see "
+                         "--placement-tries; 2 = keep the first two allocations)")
     ap.add_argument("--pcm-pad-kb", type=int, default=0,
                     help="the same stagger for the streams' PCM output regions (stream stride = the call's bytes + this)")
     ap.add_argument("--pad-kb", type=int, default=4,
@@ -673,6 +703,7 @@ def main():
                        "out_channels": wl.out_ch, "pcm": "s16", "limiter": "-1 dBFS, 240 look-ahead",
                        "signal": SIGNALS[args.signal], "parallelism": "streams sharded, dp%d" % world,
                        "input_stagger_kib": args.pad_kb, "input_placement": wl.placement,
+                       "pcm_placement": wl.pcm_placement,
                        "gather": args.gather if world > 1 else "n/a (1 GPU)"},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "gather_bytes_per_rank": wl.stride_bytes * S if world > 1 and args.gather == "final" else None,
@@ -712,7 +743,7 @@ def main():
                                     "streams_per_gpu": streams2, "frames_per_step": w2.F,
                                     "ms_per_step": round(el / args.steps * 1e3, 4), "dtype": dt2,
                                     "in_channels": w2.in_ch, "out_channels": w2.out_ch,
-                                    "input_placement": w2.placement, "roofline": r2}
+                                    "input_placement": w2.placement, "pcm_placement": w2.pcm_placement, "roofline": r2}
             if w2.kind == "fir":
                 out["configs"][name]["parity"] = "unpinned (HRTF arithmetic is not in the reference tree)"
             w2.close()

@@ -52,6 +52,32 @@ int main(int argc, char **argv) {
   (void)hipMalloc(&out2, (size_t)S * chunks * 4096);   // a second output buffer, allocated AFTER the inputs
   (void)hipMemset(out2, 0, (size_t)S * chunks * 4096);
   printf("out %p  out2 %p\n", (void *)out, (void *)out2);
+  if (argc > 1 && argv[1][0] == 'o') {
+    // "out": the cfg3 shape (64 B read + 48 B written per sample-frame) with ONE input buffer (the first fast-looking one
+    // is not known here: input 20, past the usual slow runs) against 40 candidate OUTPUT buffers of 1.6 GB
+    const int NO = 40;
+    u4 *outs[NO];
+    for (int j = 0; j < NO; ++j) {
+      if (hipMalloc(&outs[j], (size_t)S * chunks * 12 * 4096) != hipSuccess) { printf("out alloc %d failed\n", j); return 1; }
+      (void)hipMemset(outs[j], 0, (size_t)S * chunks * 12 * 4096);
+    }
+    for (int which : {20, 2}) {
+      for (int j = 0; j < NO; ++j) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 5; ++rep) {
+          (void)hipEventRecord(e0);
+          k_stream<16, 12><<<S, 256>>>(in[which], outs[j], chunks, stride4);
+          (void)hipEventRecord(e1);
+          (void)hipEventSynchronize(e1);
+          float ms;
+          (void)hipEventElapsedTime(&ms, e0, e1);
+          if (rep > 0 && ms < best) best = ms;
+        }
+        printf("cfg3 input %2d output %2d  %.3f ms  %5.0f GB/s\n", which, j, best, (double)S * chunks * 28 * 4096 / best / 1e6);
+      }
+    }
+    return 0;
+  }
   for (int pass = 0; pass < 2; ++pass)
     for (int i = 0; i < N; ++i) {
       float best = 1e9f;
