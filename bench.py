@@ -279,7 +279,7 @@ class Workload:
         self.pcm_placement = None
         if args.placement_tries > 1 and kind in ("h2m", "m2m", "fir", "h2m_lfe", "h2m_proj"):
             self.pick_placement(args.placement_tries, dev)
-            if args.pcm_placement_tries > 2 and out_ch > 2:
+            if args.pcm_placement_tries > 2:
                 self.pick_pcm_placement(args.pcm_placement_tries, dev)
 
         x = synth_hot_device(S, in_ch, F, fs, 1000 + rank, dev)
@@ -382,10 +382,11 @@ class Workload:
         torch.cuda.empty_cache()
 
     def pick_pcm_placement(self, tries, dev):
-        """Setup, untimed: the same search for the two PCM output buffers of the multi-channel layouts, whose traffic is
-        a third (cfg2) to 43 % (cfg3) writes: tools/placement_va_probe.hip `out` shows 5.3 - 6.3 TB/s for the cfg3 shape
-        depending on where the OUTPUT lies.  `tries` candidates (the two already allocated among them), the chosen
-        input, silence; the best two stay."""
+        """Setup, untimed: the same search for the two PCM output buffers.  What is slow is a PAIR: an input region and an
+        output region of the same kind (tools/placement_va_probe.hip `out`: every input buffer is slow with one group of
+        output buffers and fast with the other, or fast with both — DESIGN.md 3), and the timed region alternates
+        between two PCM buffers, so both have to suit the chosen input.  `tries` candidates (the two already allocated
+        among them), the chosen input, silence; the best two stay."""
         cands = list(self.pcm) + [torch.zeros((self.S, self.stride_bytes), dtype=torch.uint8, device=dev) for _ in range(tries - 2)]
         rates = []
         for buf in cands:
@@ -565,7 +566,7 @@ def parse_args(argv=None):
                          "launches on each and keep the fastest (the rate is bimodal per allocation, ~13 %% apart; "
                          "1 = take the first allocation as it comes)")
     ap.add_argument("--pcm-placement-tries", type=int, default=10,
-                    help="setup, layouts of more than two channels: candidates for the two PCM output buffers (see "
+                    help="setup: candidates for the two PCM output buffers, tried with the chosen input (see "
                          "--placement-tries; 2 = keep the first two allocations)")
     ap.add_argument("--pcm-pad-kb", type=int, default=0,
                     help="the same stagger for the streams' PCM output regions (stream stride = the call's bytes + this)")
