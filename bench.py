@@ -372,7 +372,7 @@ class Workload:
             rates.append(round(self.sf_per_step / (ms * 1e-3) / 1e6, 1))
             if i >= 2 and rates[-1] >= 0.97 * max(rates) and max(rates) > 1.07 * min(rates):
                 break   # both modes showed and the current candidate is in the fast one; else all `tries` are looked at
-                        # (on some devices every allocation is in the slow mode)
+                        # (the first PCM buffer may be of the same kind as every input candidate of a long run)
         best = int(np.argmax(rates))
         self.x = cands[best]
         self.placement = {"candidates_msamples_s": rates, "picked": best,
