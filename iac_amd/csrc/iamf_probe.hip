@@ -4,9 +4,10 @@
 // reads `rows` x 16 B (rows 4 KiB apart inside a frame of rows x 4 KiB, prefetched one chunk ahead, non-temporal)
 // and writes `pieces` x 16 B, each store instruction covering 1 KiB contiguous per wave — the geometry of
 // render_fast.hpp (rows 16, pieces 1) and render_wide4.hpp (cfg2: 12 / 6, cfg3: 16 / 12).
-// Round-2 finding (tools/rw_mix_probe.hip, profiles/r02_rw_mix.txt): read-only this pattern runs at 7.1 TB/s;
-// ANY share of writes puts it in a 5.2-6.0 TB/s regime (headline shape 5.5-5.85, cfg2 5.2-5.3, cfg3 5.8-6.05),
-// whichever wave issues the stores.  Nothing here is used by the render path.
+// Round-2 findings: read-only this pattern runs at 7.1 TB/s; with a share of writes at 6.2-6.5 TB/s (headline shape)
+// when input and output lie in memory regions of different kinds and at 5.45 TB/s when they lie in regions of the
+// same kind (tools/placement_va_probe.hip) — iamf_hip_pick_buffer_pair below finds a fast pair among
+// candidates.  Nothing here is used by the render path.
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
@@ -63,4 +64,51 @@ extern "C" int iamf_hip_probe_traffic(int n_streams, int chunks, int rows, int p
     default: return IAMF_HIP_ERR_UNIMPLEMENTED;
   }
   return hipGetLastError() == hipSuccess ? IAMF_HIP_OK : IAMF_HIP_ERR_DEVICE;
+}
+
+// Times the traffic kernel on every (input candidate, output candidate) pair — 1 + reps launches each, the median of
+// the reps — and reports the fastest pair: what a host with long-lived stream buffers does once at start-up
+// (INTEGRATION.md 5).  Synchronous; the candidates' contents are read / overwritten.
+extern "C" int iamf_hip_pick_buffer_pair(int n_streams, int chunks, int rows, int pieces, const void *const *d_in_candidates,
+                                         int n_in, int64_t in_stream_stride_bytes, void *const *d_out_candidates, int n_out,
+                                         int64_t out_stream_stride_bytes, void *stream, int *best_in, int *best_out,
+                                         float *ms_out) {
+  if (!d_in_candidates || !d_out_candidates || n_in <= 0 || n_out <= 0 || n_in > 256 || n_out > 256 || !best_in || !best_out)
+    return IAMF_HIP_ERR_BAD_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    return IAMF_HIP_ERR_DEVICE;
+  }
+  constexpr int kReps = 3;
+  int rc = IAMF_HIP_OK;
+  float best = 0.f;
+  *best_in = *best_out = 0;
+  for (int i = 0; i < n_in && rc == IAMF_HIP_OK; ++i)
+    for (int j = 0; j < n_out && rc == IAMF_HIP_OK; ++j) {
+      float t[kReps];
+      for (int r = -1; r < kReps && rc == IAMF_HIP_OK; ++r) {  // r = -1: untimed first touch
+        if (hipEventRecord(e0, st) != hipSuccess) rc = IAMF_HIP_ERR_DEVICE;
+        if (rc == IAMF_HIP_OK)
+          rc = iamf_hip_probe_traffic(n_streams, chunks, rows, pieces, d_in_candidates[i], in_stream_stride_bytes,
+                                      d_out_candidates[j], out_stream_stride_bytes, stream);
+        if (rc == IAMF_HIP_OK && (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = IAMF_HIP_ERR_DEVICE;
+        float ms = 0.f;
+        if (rc == IAMF_HIP_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = IAMF_HIP_ERR_DEVICE;
+        if (r >= 0) t[r] = ms;
+      }
+      if (rc != IAMF_HIP_OK) break;
+      float a = t[0], b = t[1], c = t[2];   // median of three
+      const float med = a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b));
+      if (ms_out) ms_out[i * n_out + j] = med;
+      if ((i == 0 && j == 0) || med < best) {
+        best = med;
+        *best_in = i;
+        *best_out = j;
+      }
+    }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
 }

@@ -104,6 +104,9 @@ def lib():
         L.iamf_hip_get_m2m_matrix.argtypes = [C.c_int, C.c_int, C.POINTER(Matrix)]
         L.iamf_hip_probe_traffic.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                              C.c_int64, C.c_void_p]
+        L.iamf_hip_pick_buffer_pair.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int64,
+                                                C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_void_p,
+                                                C.POINTER(C.c_int), C.POINTER(C.c_int), FP]
         L.iamf_hip_get_m2m_matrix_variant.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Matrix)]
         L.iamf_hip_layout_channels.argtypes = [C.c_int]
         L.iamf_hip_batch_create.argtypes = [C.POINTER(BatchConfig), C.POINTER(C.c_void_p)]
@@ -319,3 +322,20 @@ class Resampler:
         if self.h:
             lib().iamf_hip_resampler_destroy(self.h)
             self.h = None
+
+
+def pick_buffer_pair(n_streams, chunks, rows, pieces, in_ptrs, in_stream_stride_bytes, out_ptrs, out_stream_stride_bytes,
+                     stream=None):
+    """iamf_hip_pick_buffer_pair: (best_in, best_out, ms[n_in][n_out]) over candidate device pointers (ints)"""
+    import numpy as np
+    n_in, n_out = len(in_ptrs), len(out_ptrs)
+    ins = (C.c_void_p * n_in)(*in_ptrs)
+    outs = (C.c_void_p * n_out)(*out_ptrs)
+    bi, bo = C.c_int(-1), C.c_int(-1)
+    ms = np.zeros((n_in, n_out), dtype=np.float32)
+    r = lib().iamf_hip_pick_buffer_pair(n_streams, chunks, rows, pieces, ins, n_in, in_stream_stride_bytes, outs, n_out,
+                                        out_stream_stride_bytes, C.c_void_p(stream or 0), C.byref(bi), C.byref(bo),
+                                        ms.ctypes.data_as(FP))
+    if r != 0:
+        raise RuntimeError("iamf_hip_pick_buffer_pair: %d" % r)
+    return bi.value, bo.value, ms

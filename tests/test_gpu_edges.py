@@ -169,3 +169,26 @@ def test_facade_error_behaviour(hip):
     lib.IAMF_decoder_set_bit_depth(d, 16)
     assert lib.IAMF_decoder_configure(d, bad + b"\x20\x00", len(bad) + 2, C.byref(rs)) == -6
     lib.IAMF_decoder_close(d)
+
+
+def test_pick_buffer_pair_reports_the_fastest_of_the_measured_pairs():
+    """iamf_hip_pick_buffer_pair: times the no-compute traffic kernel on every (input, output)
+    candidate pair and returns the indices of the smallest median; bad arguments are refused"""
+    import ctypes as C
+
+    import torch
+
+    import iac_amd as A
+    from iac_amd import hipabi
+    S, chunks, rows, pieces = 64, 8, 16, 1
+    in_stride, out_stride = chunks * rows * 4096 + 4096, chunks * pieces * 4096
+    ins = [torch.zeros(S * in_stride, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    outs = [torch.zeros(S * out_stride, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    bi, bo, ms = hipabi.pick_buffer_pair(S, chunks, rows, pieces, [t.data_ptr() for t in ins], in_stride,
+                                         [t.data_ptr() for t in outs], out_stride)
+    assert ms.shape == (3, 2) and (ms > 0).all()
+    assert (bi, bo) == tuple(int(v) for v in np.unravel_index(np.argmin(ms), ms.shape))
+    assert outs[bo].any()   # the probe wrote into the output candidates
+    L = A.lib()
+    bad = L.iamf_hip_pick_buffer_pair(S, chunks, rows, pieces, None, 3, in_stride, None, 2, out_stride, None, None, None, None)
+    assert bad != 0
