@@ -19,6 +19,7 @@ from .hipabi import (  # noqa: F401
     PROJ_MFMA,
     SS,
     Batch,
+    PairAlloc,
     BatchConfig,
     DemixConfig,
     DemixFrame,
