@@ -99,11 +99,11 @@ int main() {
     u4 *o = r == 0 ? ref_out : reinterpret_cast<u4 *>(va[8 * (r - 1)]);
     printf("inputs against reference output %d (%s): ", r, r == 0 ? "hipMalloc" : "start of a chunk");
     for (int i = 0; i < NCH; ++i) {
-      if (r > 0 && i == 8 * (r - 1)) { printf("-"); continue; }
+      if (r > 0 && i == 8 * (r - 1)) { printf(" --"); continue; }
       const float ms = best_ms([&] { k_stream<16, 1><<<S1, 256>>>(static_cast<const v4 *>(va[i]), o, chunks, stride4); });
       const float g = (float)((double)S1 * chunks * 17 * 4096 / ms / 1e6);
       if (r == 0) rate[i] = g;
-      printf("%c", g > 5900 ? 'F' : 's');
+      printf(" %2.0f", g / 100);
     }
     printf("   (last %.0f GB/s)\n", rate[NCH - 1]);
   }
