@@ -1,3 +1,6 @@
+"""What iamf_hip_pair_alloc_create delivers on the card it runs on (IAMF_HIP_PAIR_DEBUG=1 prints the kinds it found):
+the cfg3 traffic shape at 2048 streams and the headline shape at 512 on the assembled buffers, next to plain allocations.
+   python tools/pair_alloc_check.py        (on a GPU box)"""
 import sys, time
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import torch, numpy as np
