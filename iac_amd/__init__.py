@@ -19,7 +19,6 @@ from .hipabi import (  # noqa: F401
     PROJ_MFMA,
     SS,
     Batch,
-    PairAlloc,
     BatchConfig,
     DemixConfig,
     DemixFrame,

@@ -107,10 +107,6 @@ def lib():
         L.iamf_hip_pick_buffer_pair.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int64,
                                                 C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_void_p,
                                                 C.POINTER(C.c_int), C.POINTER(C.c_int), FP]
-        L.iamf_hip_pair_alloc_create.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_void_p),
-                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
-        L.iamf_hip_pair_alloc_destroy.argtypes = [C.c_void_p]
-        L.iamf_hip_pair_alloc_destroy.restype = None
         L.iamf_hip_get_m2m_matrix_variant.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Matrix)]
         L.iamf_hip_layout_channels.argtypes = [C.c_int]
         L.iamf_hip_batch_create.argtypes = [C.POINTER(BatchConfig), C.POINTER(C.c_void_p)]
@@ -344,41 +340,3 @@ def pick_buffer_pair(n_streams, chunks, rows, pieces, in_ptrs, in_stream_stride_
         raise RuntimeError("iamf_hip_pick_buffer_pair: %d" % r)
     return bi.value, bo.value, ms
 
-
-class PairAlloc:
-    """iamf_hip_pair_alloc: one input buffer and n_out output buffers assembled from device-memory chunks of different
-    kinds.  .d_in, .d_out[j] are device pointers (ints); .view(ptr, nbytes, torch_dtype) wraps one as a
-    torch tensor without copying.  Keep the object alive as long as the buffers are in use."""
-
-    def __init__(self, in_bytes, out_bytes, n_out, stream=None):
-        h, d_in, kinds = C.c_void_p(), C.c_void_p(), C.c_int(0)
-        d_out = (C.c_void_p * n_out)()
-        r = lib().iamf_hip_pair_alloc_create(in_bytes, out_bytes, n_out, C.c_void_p(stream or 0), C.byref(h), C.byref(d_in),
-                                             d_out, C.byref(kinds))
-        if r != 0:
-            raise RuntimeError("iamf_hip_pair_alloc_create: %d" % r)
-        self._h, self.d_in, self.d_out, self.kinds = h, d_in.value, [int(p) for p in d_out], kinds.value
-        self.in_bytes, self.out_bytes = in_bytes, out_bytes
-
-    @staticmethod
-    def view(ptr, nbytes, dtype):
-        import torch
-
-        class _Mem:
-            pass
-        m = _Mem()
-        item = torch.empty((), dtype=dtype).element_size()
-        typestr = {torch.float32: "<f4", torch.uint8: "|u1"}[dtype]
-        m.__cuda_array_interface__ = {"shape": (nbytes // item,), "typestr": typestr, "data": (ptr, False), "version": 2}
-        return torch.as_tensor(m, device="cuda")
-
-    def close(self):
-        if self._h:
-            lib().iamf_hip_pair_alloc_destroy(self._h)
-            self._h = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:   # noqa: BLE001 — interpreter shutdown
-            pass

@@ -344,16 +344,6 @@ int iamf_hip_probe_traffic(int n_streams, int chunks, int rows, int pieces, cons
 int iamf_hip_pick_buffer_pair(int n_streams, int chunks, int rows, int pieces, const void *const *d_in_candidates,
                               int n_in, int64_t in_stream_stride_bytes, void *const *d_out_candidates, int n_out,
                               int64_t out_stream_stride_bytes, void *stream, int *best_in, int *best_out, float *ms);
-/* The same knowledge as an allocator: one input buffer of in_bytes and n_out (<= 16) output buffers of out_bytes each,
- * every one a contiguous range of device memory ASSEMBLED (hipMemCreate / hipMemMap) from 2 GiB chunks — the input
- * from chunks of one kind, the outputs from chunks of other kinds, the kinds found by timing the traffic kernel on
- * pairs of chunks at creation (a fraction of a second; *kinds_found, if not NULL, receives how many kinds showed).
- * The buffers behave like hipMalloc memory (not zeroed) and live until iamf_hip_pair_alloc_destroy.  Fails with
- * IAMF_HIP_ERR_DEVICE if the card has not enough free memory for the chunks it wants to look at. */
-typedef struct iamf_hip_pair_alloc iamf_hip_pair_alloc;
-int iamf_hip_pair_alloc_create(int64_t in_bytes, int64_t out_bytes, int n_out, void *stream,
-                               iamf_hip_pair_alloc **alloc, void **d_in, void **d_out, int *kinds_found);
-void iamf_hip_pair_alloc_destroy(iamf_hip_pair_alloc *alloc);
 
 /* ------------------------------------------------------------------------------------------
  * Decoder facade extension.  The reference chooses at BUILD time whether scene-based elements feed
