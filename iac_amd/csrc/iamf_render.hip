@@ -32,6 +32,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -172,7 +173,8 @@ float ease(float x) {
 struct iamf_hip_batch {
   iamf_hip_batch_config cfg;
   int device = 0;                    // the HIP device the batch was created on; every later call must run on it
-  hipStream_t last_stream = nullptr; // stream of the last render / flush: the synchronous setters wait for it
+  hipEvent_t done = nullptr;         // recorded behind every render / flush on the caller's stream: the synchronous
+                                     // setters and destroy wait for IT, so the caller's stream may be gone by then
   bool rendered = false;
   int m = 0, n_feeds = 0;
   int32_t src_feed[kMaxOut];
@@ -231,9 +233,10 @@ bool on_batch_device(const iamf_hip_batch *b) {
 }
 
 // the setters copy into buffers a queued render may still be reading (renders are asynchronous on the
-// caller's stream, which may be non-blocking with respect to the null stream): wait for that stream first
+// caller's stream, which may be non-blocking with respect to the null stream): wait for the batch's own
+// event behind the last render (not for the stream handle, which the caller may have destroyed since)
 int quiesce(iamf_hip_batch *b) {
-  if (b->rendered) HIPCHK(hipStreamSynchronize(b->last_stream));
+  if (b->rendered) HIPCHK(hipEventSynchronize(b->done));
   return IAMF_HIP_OK;
 }
 
@@ -485,8 +488,6 @@ const int kLayoutTop[9] = {0, 0, 0, 2, 4, 0, 2, 4, 2};
 
 int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
   if (!on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
-  b->last_stream = static_cast<hipStream_t>(a.stream);
-  b->rendered = true;
   RenderParams p;
   memset(&p, 0, sizeof(p));
   p.in = a.d_in;
@@ -654,6 +655,8 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
                        static_cast<uint8_t *>(a.d_pcm), a.pcm_stream_stride_bytes, n_emit, p.out_ch, sc, bps);
     HIPCHK(hipGetLastError());
   }
+  HIPCHK(hipEventRecord(b->done, static_cast<hipStream_t>(a.stream)));
+  b->rendered = true;
   return n_emit;
 }
 
@@ -839,6 +842,7 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
       return IAMF_HIP_ERR_DEVICE;              \
     }                                          \
   } while (0)
+  CREATE_CHK(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
   CREATE_CHK(hipMalloc(&b->d_matrix, sizeof(float) * fm.size()));
   CREATE_CHK(hipMalloc(&b->d_gains, sizeof(float) * 3 * ns));
   CREATE_CHK(hipMalloc(&b->d_ctab, sizeof(float) * ctab.size()));
@@ -913,7 +917,8 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
       if (on) (void)hipSetDevice(dev);
     }
   } restore{sw, cur};
-  if (b->rendered) (void)hipStreamSynchronize(b->last_stream);
+  if (b->rendered) (void)hipEventSynchronize(b->done);
+  if (b->done) (void)hipEventDestroy(b->done);
   (void)hipFree(b->d_matrix_pre);
   (void)hipFree(b->d_matrix);
   (void)hipFree(b->d_gains);
@@ -1201,7 +1206,7 @@ const struct { float alpha, beta, gamma, delta; int woff; } kDemixMat[7] = {
     {1.0, (float)0.866, (float)0.866, (float)0.866, 1}};
 const float kDemixW[11] = {0.0, (float)0.0179, (float)0.0391, (float)0.0658, (float)0.1038, 0.25,
                            (float)0.3962, (float)0.4342, (float)0.4609, (float)0.4821, 0.5};
-void demix_factors(int mode, int w_idx, float out[5]) {
+static void demix_factors(int mode, int w_idx, float out[5]) {
   out[0] = kDemixMat[mode].alpha;
   out[1] = kDemixMat[mode].beta;
   out[2] = kDemixMat[mode].gamma;

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 

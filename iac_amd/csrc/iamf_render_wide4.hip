@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <atomic>
 #include <string.h>
 
 #include <type_traits>

@@ -12,21 +12,33 @@ constexpr int kMaxIn = 24;
 
 // Opting a kernel into more than 64 KiB of dynamic LDS is a PER-DEVICE attribute: one flag per device
 // ordinal, set only when every hipFuncSetAttribute of the group succeeded (a failed opt-in is retried
-// and surfaces as a launch error instead of being remembered as done).
+// and surfaces as a launch error instead of being remembered as done).  Host threads may drive batches on
+// different devices at once: the begin..end bracket keeps its device and result per THREAD and only the
+// done flags are shared (atomic; opting in twice is harmless).  Ordinals >= kMaxDevices opt in on every launch.
 constexpr int kMaxDevices = 64;
 struct OptIn {
-  bool done[kMaxDevices] = {};
-  bool ok = true;
-  int dev = 0;
+  std::atomic<bool> done[kMaxDevices] = {};
+  struct Bracket {
+    int dev;
+    bool ok;
+  };
+  static Bracket &cur() {
+    static thread_local Bracket b{0, true};
+    return b;
+  }
   bool begin() {  // true if this device still has to opt in
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
-    ok = true;
-    return !done[dev];
+    Bracket &b = cur();
+    if (hipGetDevice(&b.dev) != hipSuccess || b.dev < 0) b.dev = kMaxDevices;
+    b.ok = true;
+    return b.dev >= kMaxDevices || !done[b.dev].load(std::memory_order_acquire);
   }
   void set(const void *fn, int bytes) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) ok = false;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) cur().ok = false;
   }
-  void end() { done[dev] = ok; }
+  void end() {
+    const Bracket &b = cur();
+    if (b.dev < kMaxDevices && b.ok) done[b.dev].store(true, std::memory_order_release);
+  }
 };
 
 struct LimState {  // per stream, persisted in HBM between calls

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
   auto load_x = [&](int cbase, int tt) {
     if constexpr (LFE) {  // transposed by blocks of 64 streams (lfe_index, render_lfe.hpp); unconditional like the rest
       const int k0 = cbase + 4 * tt;
-      const int k = k0 < p.total ? k0 : 4 * tt;
+      const int k = k0 < p.total ? k0 : p.total - 4;   // past the end: the call's last quad (total >= 256, a multiple of 64)
       lq = ld_stream4(p.lfe + (((((int64_t)(s >> 6) * p.lfe_t4 + (k >> 2)) * 64 + (s & 63)) << 2)));
     }
     if constexpr (MIX) {
@@ -494,8 +494,10 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
 #pragma unroll
       for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
     } else {
+      // unconditional loads, as in the MFMA variant; a lane past the end of the call re-reads the call's last quad
+      // (4 * tt would lie past a call shorter than one chunk: total is only known to be >= 256 and a multiple of 64)
       const int k0 = cbase + 4 * tt;
-      const int k = k0 < p.total ? k0 : 4 * tt;   // unconditional loads, as in the MFMA variant
+      const int k = k0 < p.total ? k0 : p.total - 4;
       const int f = k / fs;
       const int i = k - f * fs;
       const float *src = in_s + (int64_t)f * p.in_frame_stride + i;

@@ -35,11 +35,12 @@ def rank_env(rank, world, port, base=None):
     return env
 
 
-def launch_ranks(n, child_argv, timeout=None):
+def launch_ranks(n, child_argv, timeout=None, grace=10.0):
     """Start `n` children `child_argv` (a full command line), rank r with rank_env(r, n, port).
     Rank 0's stdout is relayed to ours line by line, every child's stderr to ours; the other
     ranks' stdout is dropped (they print nothing in bench.py).  Returns 0 only if EVERY child
-    exited 0; on the first failure the remaining children are terminated (their own PIDs only)."""
+    exited 0; on the first failure (or on `timeout`) the remaining children are terminated (their own PIDs
+    only) and, if still alive `grace` seconds later, killed."""
     port = free_port()
     procs = []
     for r in range(n):
@@ -58,6 +59,15 @@ def launch_ranks(n, child_argv, timeout=None):
     pending = set(range(n))
     import time
     t0 = time.monotonic()
+    kill_at = None   # once the others were asked to stop (SIGTERM): when to stop asking (SIGKILL)
+
+    def stop_pending():
+        nonlocal kill_at
+        for q in pending:
+            procs[q].terminate()
+        if kill_at is None:
+            kill_at = time.monotonic() + grace
+
     while pending:
         for r in sorted(pending):
             code = procs[r].poll()
@@ -67,14 +77,24 @@ def launch_ranks(n, child_argv, timeout=None):
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 1
                 sys.stderr.write("launch: rank %d exited with %d; stopping the other ranks\n" % (r, code))
-                for q in pending:
-                    procs[q].terminate()
+                stop_pending()
         if timeout is not None and time.monotonic() - t0 > timeout and pending:
             sys.stderr.write("launch: timeout after %.0f s; stopping ranks %s\n" % (timeout, sorted(pending)))
-            for q in pending:
-                procs[q].terminate()
+            stop_pending()
             rc = rc or 124
             timeout = None
+        if kill_at is not None and pending and time.monotonic() > kill_at:
+            # a rank blocked inside a collective or a HIP call may not die on SIGTERM: these are our own
+            # child PIDs, so kill them and reap them — the launcher must never hang on a wedged rank
+            sys.stderr.write("launch: ranks %s ignored SIGTERM for %.0f s; killing them\n" % (sorted(pending), grace))
+            for q in sorted(pending):
+                procs[q].kill()
+            for q in sorted(pending):
+                try:
+                    procs[q].wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    pass
+            pending.clear()
         time.sleep(0.05)
     t.join(timeout=10)
     return rc

@@ -148,7 +148,8 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b);
  * element mix gain and output mix gain as iamf_frame_gain applies a constant gain
  * (IAMF_decoder.c:1392-1397: only if != 1 and > 0), and the loudness gain
  * db2lin(target - loudness) of iamf_loudness_process (IAMF_decoder.c:3206-3221).  Synchronous, and ordered after the renders already queued: it
- * first waits for the stream of the batch's last render / flush call. */
+ * first waits for the batch's last render / flush call (an event the batch itself records behind every call, so the
+ * caller's stream need not outlive the call). */
 int iamf_hip_batch_set_gains(iamf_hip_batch *b, const float *element_gain,
                              const float *output_gain, const float *loudness_gain);
 

@@ -11,7 +11,20 @@ keys = ["RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "
 rec = {k: os.environ.get(k) for k in keys}
 rec["argv"] = sys.argv[1:]
 rec["pid"], rec["ppid"] = os.getpid(), os.getppid()
+if os.environ.get("STUB_WEDGE_RANK") == str(rank):   # a rank stuck in a collective: ignores SIGTERM, never exits
+    import signal
+    import time
+    signal.signal(signal.SIGTERM, signal.SIG_IGN)
+    with open(os.path.join(os.environ["STUB_OUT"], "wedged%d.pid" % rank), "w") as f:
+        f.write(str(os.getpid()))
+    time.sleep(600)
 if os.environ.get("STUB_FAIL_RANK") == str(rank):
+    if os.environ.get("STUB_WEDGE_RANK"):   # fail only once the wedged rank has installed its handler
+        import time
+        for _ in range(200):
+            if os.path.exists(os.path.join(os.environ["STUB_OUT"], "wedged%s.pid" % os.environ["STUB_WEDGE_RANK"])):
+                break
+            time.sleep(0.05)
     sys.exit(7)
 if os.environ.get("STUB_RENDEZVOUS") == "1":
     import torch

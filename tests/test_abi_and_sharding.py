@@ -30,6 +30,24 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
 
 
+def test_library_exports_only_the_two_api_prefixes():
+    """A drop-in .so must not leak internal names into the host's namespace (an unprefixed
+    `demix_factors` used to sit beside the 19 API symbols): every defined dynamic symbol is IAMF_* or iamf_hip_*."""
+    import subprocess
+
+    import iac_amd
+    iac_amd.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", iac_amd.lib_path()], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert len(names) >= 30
+    stray = [n for n in names if not (n.startswith("IAMF_") or n.startswith("iamf_hip_"))]
+    assert stray == [], stray
+    ref_api = re.findall(r"\b(IAMF_[a-z_]+)\s*\(", re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "IAMF_decoder.h")).read(), flags=re.S))
+    assert len(set(ref_api)) == 19
+    for n in set(ref_api):
+        assert n in names, n
+
+
 def test_matrix_lookup_needs_no_gpu():
     import iac_amd as A
     h = A.get_h2m_matrix(3, A.SS["H"])

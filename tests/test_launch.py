@@ -46,6 +46,33 @@ def test_a_failing_rank_fails_the_launch(tmp_path):
     assert "rank 1 exited with 7" in p.stderr
 
 
+def test_a_rank_that_ignores_sigterm_is_killed_and_the_launch_returns(tmp_path):
+    """a rank blocked in a collective may not die on SIGTERM; the launcher escalates to SIGKILL after a
+    bounded grace period instead of polling forever."""
+    import time
+    sys.path.insert(0, ROOT)
+    from iac_amd import launch
+    env = _env(tmp_path, STUB_FAIL_RANK="0", STUB_WEDGE_RANK="1")
+    old = dict(os.environ)
+    os.environ.clear()
+    os.environ.update(env)
+    try:
+        t0 = time.monotonic()
+        rc = launch.launch_ranks(2, [sys.executable, STUB], grace=1.0)
+        took = time.monotonic() - t0
+    finally:
+        os.environ.clear()
+        os.environ.update(old)
+    assert rc == 7 and took < 60
+    pid = int(open(os.path.join(str(tmp_path), "wedged1.pid")).read())
+    try:   # reaped: the PID is gone (or, at worst, belongs to nobody we can signal)
+        os.kill(pid, 0)
+        alive = True
+    except OSError:
+        alive = False
+    assert not alive
+
+
 def test_world_size_mismatch_is_refused_before_any_gpu_call(tmp_path):
     env = _env(tmp_path, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, BENCH, "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
