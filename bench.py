@@ -465,7 +465,7 @@ class Workload:
         torch.cuda.synchronize()
         if n != F * fs - 240:
             return {"ok": False, "why": "first launch after a reset emitted %d sample-frames, not %d" % (n, F * fs - 240)}
-        picks = sorted({0, min(S - 1, S // 3), min(S - 1, (2 * S) // 3 + 1), S - 1})[:k]
+        picks = sorted({int(round(i * (S - 1) / max(1, k - 1))) for i in range(k)}) if k > 1 else [0]   # spread over the shard
         nfl = F * self.in_ch * fs
         xs = {s_: self.x[s_, :nfl].cpu().numpy().reshape(F, self.in_ch, fs) for s_ in picks}
         got = {s_: buf[s_, :n * self.out_ch * 2].cpu().numpy().view(np.int16).reshape(n, self.out_ch) for s_ in picks}

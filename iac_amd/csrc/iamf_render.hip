@@ -42,6 +42,8 @@
 
 #include "../../include/iamf_hip.h"
 
+#define IAMF_FFT_HOST_TABLES   // render_fir_fft.hpp: the host-side table builder is compiled in this unit
+
 extern "C" int iamf_hip_fir_m2b_has(int m);                                           // iamf_render_fir_m2b.hip
 extern "C" int iamf_hip_fir_m2b_launch(const void *params, int m, hipStream_t st);    // iamf_render_fir_m2b.hip
 extern "C" int iamf_hip_wide4_has_mix(int m, int c);                                  // iamf_render_wide4_mix.hip
@@ -59,6 +61,7 @@ namespace {
 #include "render_downmix.hpp"
 #include "render_fir.hpp"
 #include "render_fir16.hpp"
+#include "render_fir_fft.hpp"
 #include "render_fast.hpp"
 #include "render_generic.hpp"
 #include "render_wide.hpp"
@@ -210,6 +213,8 @@ struct iamf_hip_batch {
   int fir_taps = 0;
   float *d_fir_hist[2] = {nullptr, nullptr};
   void *d_fir_h16 = nullptr;    // split-f16 filter tables (render_fir16.hpp)
+  float *d_fir_pq = nullptr, *d_fir_tw = nullptr;   // spectra and twiddles of the FFT stage (render_fir_fft.hpp)
+  float *d_fir_zero = nullptr;                      // 64 zero floats for that stage
   float fir_inv_scale = 1.f;
   int fir_cur = 0;
   // HOA LFE generator (render_lfe.hpp)
@@ -278,10 +283,16 @@ void launch_fir_m(const RenderParams &p, dim3 grid, hipStream_t st) {
   if (opted.begin()) {
     opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 1>), 120 * 1024);
     opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 2>), 120 * 1024);
+    opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 3>), 120 * 1024);
     opted.end();
   }
-  // 8 waves either way: render_fir.hpp / render_fir16.hpp
-  if (p.fir_h16 && !getenv("IAMF_HIP_FIR_F32")) {
+  // Three stages with one specification (render_fir.hpp): overlap-save FFT on the VALU (default, render_fir_fft.hpp),
+  // split-f16 MFMA (IAMF_HIP_FIR_F16=1, render_fir16.hpp), f32 MFMA (IAMF_HIP_FIR_F32=1); they differ in the last bits
+  const int stage = fir_stage_choice(p);
+  if (stage == 3) {
+    static_assert(fast_lds_floats(2, M, 3) * 4 <= 80 * 1024, "two workgroups per CU");
+    hipLaunchKernelGGL((render_fast_kernel<M, 2, 3>), grid, dim3(256), sizeof(float) * (size_t)fast_lds_floats(2, M, 3), st, p);
+  } else if (stage == 2) {
     static_assert(fast_lds_floats(2, M, 2) * 4 <= 80 * 1024, "two workgroups per CU");
     hipLaunchKernelGGL((render_fast_kernel<M, 2, 2>), grid, dim3(256), sizeof(float) * (size_t)fast_lds_floats(2, M, 2), st, p);
   } else {
@@ -582,6 +593,9 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
     p.fir_hist_next = b->d_fir_hist[b->fir_cur ^ 1];
     p.fir_h16 = b->d_fir_h16;
     p.fir_inv_scale = b->fir_inv_scale;
+    p.fir_pq = b->d_fir_pq;
+    p.fir_tw = b->d_fir_tw;
+    p.fir_zero = b->d_fir_zero;
   }
   if (b->lfe && a.d_in && total > 0) {
     // HOA LFE generator: feed-forward part in parallel, the recurrence one lane per stream, both on the
@@ -890,6 +904,16 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
       CREATE_CHK(hipMemcpy(b->d_fir_h16, tab.data(), tab.size() * sizeof(_Float16), hipMemcpyHostToDevice));
       b->fir_inv_scale = 1.f / (scale * kF16InScale);
     }
+    {  // the FFT stage's tables (render_fir_fft.hpp): pair spectra in the transform's own bin order, twiddles
+      std::vector<float> pq, tw;
+      fft_build_tables(mx.mat, mx.m, taps, pq, tw);
+      CREATE_CHK(hipMalloc(&b->d_fir_pq, pq.size() * sizeof(float)));
+      CREATE_CHK(hipMemcpy(b->d_fir_pq, pq.data(), pq.size() * sizeof(float), hipMemcpyHostToDevice));
+      CREATE_CHK(hipMalloc(&b->d_fir_tw, tw.size() * sizeof(float)));
+      CREATE_CHK(hipMemcpy(b->d_fir_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+      CREATE_CHK(hipMalloc(&b->d_fir_zero, 64 * sizeof(float)));
+      CREATE_CHK(hipMemset(b->d_fir_zero, 0, 64 * sizeof(float)));
+    }
   }
   CREATE_CHK(hipMalloc(&b->d_dmx_tab, sizeof(dmx_tab)));
   CREATE_CHK(hipMemcpy(b->d_dmx_tab, dmx_tab, sizeof(dmx_tab), hipMemcpyHostToDevice));
@@ -934,6 +958,9 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_fir_hist[0]);
   (void)hipFree(b->d_fir_hist[1]);
   (void)hipFree(b->d_fir_h16);
+  (void)hipFree(b->d_fir_pq);
+  (void)hipFree(b->d_fir_tw);
+  (void)hipFree(b->d_fir_zero);
   (void)hipFree(b->d_lfe_state);
   (void)hipFree(b->d_lfe_next);
   (void)hipFree(b->d_lfe_u);

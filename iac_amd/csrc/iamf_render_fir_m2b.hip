@@ -22,6 +22,7 @@ namespace {
 #include "render_downmix.hpp"
 #include "render_fir.hpp"
 #include "render_fir16.hpp"
+#include "render_fir_fft.hpp"
 #include "render_fast.hpp"
 
 template <int M>
@@ -30,10 +31,15 @@ void launch_fir_m(const RenderParams &p, hipStream_t st) {
   if (opted.begin()) {
     opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 1>), 120 * 1024);
     opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 2>), 120 * 1024);
+    opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 3>), 120 * 1024);
     opted.end();
   }
   const dim3 grid((unsigned)p.n_streams);
-  if (p.fir_h16 && !getenv("IAMF_HIP_FIR_F32")) {
+  const int stage = fir_stage_choice(p);   // as launch_fir_m of iamf_render.hip
+  if (stage == 3) {
+    static_assert(fast_lds_floats(2, M, 3) * 4 <= 80 * 1024, "two workgroups per CU");
+    hipLaunchKernelGGL((render_fast_kernel<M, 2, 3>), grid, dim3(256), sizeof(float) * (size_t)fast_lds_floats(2, M, 3), st, p);
+  } else if (stage == 2) {
     static_assert(fast_lds_floats(2, M, 2) * 4 <= 80 * 1024, "two workgroups per CU");
     hipLaunchKernelGGL((render_fast_kernel<M, 2, 2>), grid, dim3(256), sizeof(float) * (size_t)fast_lds_floats(2, M, 2), st, p);
   } else {

@@ -17,6 +17,7 @@ namespace {
 #include "render_downmix.hpp"
 #include "render_fir.hpp"
 #include "render_fir16.hpp"
+#include "render_fir_fft.hpp"
 #include "render_fast.hpp"
 #include "render_wide4.hpp"
 

@@ -123,6 +123,9 @@ struct RenderParams {
   float *fir_hist_next;     // device, same shape: history after this call
   const void *fir_h16;      // device: split-f16 filter tables [M][ear][hi/lo][shift 8][304] (render_fir16.hpp) or nullptr
   float fir_inv_scale;      // 1 / (filter scale * input scale) of those tables
+  const float *fir_pq;      // device: spectra tables of the FFT stage [pairs][16][64] x 4 floats (render_fir_fft.hpp) or nullptr
+  const float *fir_tw;      // device: its twiddles [16][64] + [16][4] complex
+  const float *fir_zero;    // device: 64 zero floats (what that stage loads for runs past the end of a call)
 };
 
 // IAChannel ids (reference IAMF_types.h:61-90; L5/R5 alias L7/R7)
@@ -150,3 +153,10 @@ __device__ __forceinline__ float to_scaled(float x, float scale, float lo, float
   return rintf(x);  // v_rndne_f32: ties to even, like lrintf in the default rounding mode
 }
 
+// which HRTF stage a FIR call runs (host): 3 = overlap-save FFT (default), 2 = split-f16 MFMA, 1 = f32 MFMA
+inline int fir_stage_choice(const RenderParams &p) {
+  if (getenv("IAMF_HIP_FIR_F32")) return 1;
+  if (getenv("IAMF_HIP_FIR_F16") && p.fir_h16) return 2;
+  if (p.fir_pq && p.fir_tw && p.fir_zero && (p.frame_size & 63) == 0) return 3;   // its input runs of 64 must not straddle frames
+  return p.fir_h16 ? 2 : 1;
+}

@@ -181,7 +181,7 @@ __host__ __device__ constexpr int fast_lds_floats(int oc, int m, int fir = 0) {
   // The HRTF variant reads the table from global memory (it has no input prefetch that an in-loop
   // load could drain).
   return oc * kFRing + 2 * kFRing + kFRing / 16 + 2 * kFChunk + (fir ? 0 : 2 * kFWin) + ((oc * m + 15) & ~15) + 16 +
-         (fir == 2 ? kF16LdsFloats : (fir ? kFirLdsFloats : 16 /* second element's matrix rows */));
+         (fir == 3 ? kFftLdsFloats : (fir == 2 ? kF16LdsFloats : (fir ? kFirLdsFloats : 16 /* second element's matrix rows */)));
 }
 
 __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
@@ -200,9 +200,10 @@ __device__ __forceinline__ int ring_wrap(int i) {  // i in [-R, 2R)
 //      IAMF_decoder.c:1383-1408) instead of constants.
 constexpr int kFIn2 = 4;
 // FIR:  0 = gain matrix; 1 = HRTF stage on the f32 MFMA (render_fir.hpp); 2 = HRTF stage on the f16
-//       MFMA with split operands (render_fir16.hpp)
+//       MFMA with split operands (render_fir16.hpp); 3 = HRTF stage by overlap-save FFT on the VALU
+//       (render_fir_fft.hpp: one pass per THREE chunks, a wave per 768-sample hop)
 template <int M, int OC, int FIR = 0, bool DOWN = false, bool IN2 = false>
-__global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR == 2 ? 2 : ((FIR || (M <= 16 && !IN2)) ? 4 : 2)) void render_fast_kernel(const RenderParams p) {
+__global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <= 16 && !IN2)) ? 4 : 2)) void render_fast_kernel(const RenderParams p) {
   static_assert(!(FIR && DOWN), "one renderer");
   static_assert(!(IN2 && (FIR || DOWN)), "the second element joins a matrix-rendered first one");
   extern __shared__ float lds[];
@@ -277,6 +278,8 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR == 2 ? 2 : ((FIR || (M <=
 #pragma unroll
   for (int c = 0; c < OC; ++c) live[c] = FIR || DOWN || p.src_feed[c] >= 0;
   const float *fir_hist = FIR ? p.fir_hist + (int64_t)s * M * kFirHist : nullptr;
+  FftTwiddles ftw;
+  if constexpr (FIR == 3) fft_load_twiddles(p.fir_tw, t, fir + kFftLdsFloats - kFftTw2Floats, ftw);
   // second element: constant gain (skipped by the reference when it is 1 or not positive)
   const float eg2 = (IN2 && p.in2) ? p.gains2[s] : 1.f;
   const float m_eg2 = (eg2 != 1.f && eg2 > 0.f) ? eg2 : 1.f;
@@ -376,6 +379,12 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR == 2 ? 2 : ((FIR || (M <=
       if (((c0 >> 10) & 3) == 0) fir_stage16<M>(p, in_s, fir_hist, c0, fir, fir);
     }
     else if constexpr (FIR == 1) fir_stage<M>(p, in_s, fir_hist, c0, fir, fir);  // ... as four partial sums per ear
+    else if constexpr (FIR == 3) {  // both ears of this chunk and the next two: chunk 0 -> arr_p / arr_g, the others -> fir
+      if ((c0 >> 10) % 3 == 0) {
+        fir_stage_fft<M>(p, in_s, fir_hist, c0, reinterpret_cast<fft_c32 *>(fir), ftw, arr_p, fir + kFftHops * kFftScratch * 2);
+        __syncthreads();
+      }
+    }
     float4 yd[DOWN ? OC : 1];
     if constexpr (DOWN) {
       float4 cf[5];
@@ -386,7 +395,12 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR == 2 ? 2 : ((FIR || (M <=
 #pragma unroll
     for (int c = 0; c < OC; ++c) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (FIR == 2) {
+      if constexpr (FIR == 3) {
+        // ear c of this chunk, left by the FFT stage's last pass (render_fir_fft.hpp)
+        const int cj = (c0 >> 10) % 3;
+        const float *p0 = cj == 0 ? arr_p + c * kFChunk : fir + kFftHops * kFftScratch * 2 + (c * 2 + cj - 1) * kFChunk;
+        v = *reinterpret_cast<const float4 *>(p0 + 4 * t);
+      } else if constexpr (FIR == 2) {
         // ear c of this chunk, left by the split-f16 stage's last pass
         const float *p0 = fir + (c * 4 + ((c0 >> 10) & 3)) * kF16Part;
         const int u = 4 * t + ((4 * t) >> 5);  // padded index; 4 consecutive samples stay in one 32-block

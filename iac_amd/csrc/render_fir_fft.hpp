@@ -1,0 +1,516 @@
+// render_fir_fft.hpp — the binaural HRTF stage of render_fir.hpp by OVERLAP-SAVE in the frequency domain,
+// on the VALU (render_fast_kernel<M, 2, 3>).
+//
+//     y[e][t] = sum_{c < M} sum_{k < L} h[e][c][k] * x[c][t - k]          (e = 0,1; L <= 256)
+//
+// PARITY UNPINNED, as the other two HRTF stages: the reference delegates binaural rendering to Resonance Audio /
+// BEAR, whose sources are not in its tree (h2b_rdr.c:109-130, m2b_rdr.c:103-121, call sites IAMF_decoder.c:2568-2570,
+// 2608-2610); the formula above is this library's specification, checked against float64 (tests/test_gpu_fir.py).
+//
+// Why.  The direct form costs 16 384 flop per sample-frame at 16 channels x 256 taps; on the f16 matrix cores with
+// split operands that is 49 152 issued flop and the kernel ends up power-limited at 0.12 of the f16 peak (18.5
+// Gsamples/s).  Overlap-save with N = 1024, hop 768 (N - hop = 256 >= L) costs ~770 flop per
+// sample-frame on the vector ALU and moves the stage towards the HBM bound of the whole kernel (68 B per sample-frame).
+//
+// Algebra.  Two real channels a, b ride one complex FFT, z_p = x_a + i x_b, and both ears ride one inverse FFT,
+// w = y_left + i y_right.  With g_c = h_left,c + i h_right,c and G_c = FFT(g_c):
+//     W[k] = sum_p  P_p[k] Z_p[k] + Q_p[k] conj(Z_p[N - k]),   P_p = (G_a - i G_b) / 2,  Q_p = (G_a + i G_b) / 2.
+// The mirrored term is not taken per pair: U[k] += P_p[k] Z_p[k] and V[k] += conj(Q_p[N - k]) Z_p[k] accumulate in
+// the lane's own bins, and W[k] = U[k] + conj(V[N - k]) needs ONE mirror exchange per hop.  The tables hold
+// P_p / N and conj(Q_p[N - k]) / N in the FFT's own (permuted) bin order, so no reordering pass exists at all:
+// the forward FFT is decimation in frequency (natural in, permuted out), the inverse is its exact transpose
+// (permuted in, natural out).
+//
+// One WAVE runs one hop from input to output — 8 forward FFTs (M = 16), the accumulation, the mirror, one inverse —
+// so the stage has no workgroup barrier inside; the four waves of the workgroup take four consecutive hops = 3072
+// samples = three chunks per pass.  A 1024-point FFT = 16 x 16 x 4 with 16 complex points per lane:
+//     n = 64 n1 + 4 n2 + n3,  k = k1 + 16 k2 + 256 k3
+//     A: DFT16 over n1 (registers), x W_1024^{l k1} (l = 4 n2 + n3 = lane)      -> exchange 1 (LDS)
+//     B: DFT16 over n2 (registers), x W_64^{n3 k2}                              -> exchange 2 (LDS, inside quads)
+//     C: DFT4 over n3 (registers)
+// LDS layouts are padded / skewed so that every ds_write_b64 (banks mod 32, 16-lane groups) and ds_read_b64 (banks
+// mod 64, 32-lane groups) is conflict-free (MI355X_MICROARCH.md, LDS): element (k1, n2, n3) of exchange 1 sits at
+// 68 k1 + 4 n2 + n3; element (k1, k2 = 4 g + j, n3) of exchange 2 at 68 k1 + 16 g + 4 n3 + ((n3 + j) & 3).
+//
+// The arithmetic core below is __host__ __device__: tests/fft_host/ runs it lane by lane on the CPU against a
+// float64 DFT and a direct convolution (-m "not gpu"), so the index algebra is checked without a GPU.
+#pragma once
+
+#ifndef FFT_HD
+#define FFT_HD __host__ __device__ __forceinline__
+#endif
+
+constexpr int kFftN = 1024;          // FFT size
+constexpr int kFftHop = 768;         // new samples per hop; kFftN - kFftHop = 256 >= taps
+constexpr int kFftHops = 4;          // hops per pass = waves per workgroup
+constexpr int kFftSpan = kFftHop * kFftHops;   // 3072 samples = three 1024-sample chunks per pass
+constexpr int kFftRow = 68;          // exchange stride of k1 in complex elements (64 + 4 of padding)
+constexpr int kFftScratch = 16 * kFftRow;      // complex elements of LDS one wave needs (1088 >= 1024 for the mirror)
+
+typedef float fft_c32 __attribute__((ext_vector_type(2)));   // (re, im)
+
+FFT_HD fft_c32 fft_mk(float re, float im) {
+  fft_c32 r;
+  r.x = re;
+  r.y = im;
+  return r;
+}
+// Complex products.  On the device every one is exactly TWO packed instructions: v_pk_mul_f32 / v_pk_fma_f32 pick the
+// halves of their 64-bit operands per result half (op_sel for the low result, op_sel_hi for the high one) and negate
+// them (neg_lo / neg_hi), so neither the broadcast of a.x / a.y nor the swap (-b.y, b.x) costs an instruction or a
+// register.  Written as inline asm because the compiler builds the broadcast pairs and the swapped operand as values of
+// their own (for loop-invariant twiddles it even hoists them: 60 registers, which it then spills).
+#if defined(__HIP_DEVICE_COMPILE__)
+// a * b = (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+__device__ __forceinline__ fft_c32 fft_cmul(fft_c32 a, fft_c32 b) {
+  fft_c32 t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                                      // (a.x b.x, a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));  // (-a.y b.y, a.y b.x) + t
+  return d;
+}
+// a * conj(b) = (a.x b.x + a.y b.y, -a.x b.y + a.y b.x)
+__device__ __forceinline__ fft_c32 fft_cmul_conj(fft_c32 a, fft_c32 b) {
+  fft_c32 t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                          // (a.x b.x, -a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(t));           // (a.y b.y, a.y b.x) + t
+  return d;
+}
+// acc + a * b
+__device__ __forceinline__ fft_c32 fft_cmac(fft_c32 acc, fft_c32 a, fft_c32 b) {
+  fft_c32 t, d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(b), "v"(acc));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));
+  return d;
+}
+// a + w d and a - w d with w = -i (INV = false) or +i (INV = true):  -i d = (d.y, -d.x)
+template <bool INV>
+__device__ __forceinline__ fft_c32 fft_add_rot(fft_c32 a, fft_c32 d) {
+  fft_c32 r;
+  if (INV) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));   // (a.x - d.y, a.y + d.x)
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));       // (a.x + d.y, a.y - d.x)
+  return r;
+}
+template <bool INV>
+__device__ __forceinline__ fft_c32 fft_sub_rot(fft_c32 a, fft_c32 d) { return fft_add_rot<!INV>(a, d); }
+// w a
+template <bool INV>
+__device__ __forceinline__ fft_c32 fft_rot(fft_c32 a) { return fft_add_rot<INV>(fft_mk(0.f, 0.f), a); }
+#else
+FFT_HD fft_c32 fft_cmul(fft_c32 a, fft_c32 b) {
+  const fft_c32 bx = fft_mk(b.x, b.x), by = fft_mk(b.y, b.y), ar = fft_mk(-a.y, a.x);
+  return __builtin_elementwise_fma(by, ar, bx * a);
+}
+FFT_HD fft_c32 fft_cmul_conj(fft_c32 a, fft_c32 b) {
+  const fft_c32 bx = fft_mk(b.x, b.x), by = fft_mk(b.y, b.y), ar = fft_mk(a.y, -a.x);
+  return __builtin_elementwise_fma(by, ar, bx * a);
+}
+FFT_HD fft_c32 fft_cmac(fft_c32 acc, fft_c32 a, fft_c32 b) {
+  const fft_c32 bx = fft_mk(b.x, b.x), by = fft_mk(b.y, b.y), ar = fft_mk(-a.y, a.x);
+  return __builtin_elementwise_fma(by, ar, __builtin_elementwise_fma(bx, a, acc));
+}
+template <bool INV>
+FFT_HD fft_c32 fft_rot(fft_c32 a) {   // -i a (INV = false) or +i a (INV = true)
+  return INV ? fft_mk(-a.y, a.x) : fft_mk(a.y, -a.x);
+}
+template <bool INV>
+FFT_HD fft_c32 fft_add_rot(fft_c32 a, fft_c32 d) { return a + fft_rot<INV>(d); }
+template <bool INV>
+FFT_HD fft_c32 fft_sub_rot(fft_c32 a, fft_c32 d) { return a - fft_rot<INV>(d); }
+#endif
+
+// 4-point DFT in place; INV = false: W_4 = -i, INV = true: W_4 = +i (unscaled).  Eight packed additions.
+template <bool INV>
+FFT_HD void fft_dft4(fft_c32 &a0, fft_c32 &a1, fft_c32 &a2, fft_c32 &a3) {
+  const fft_c32 t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
+  a0 = t0 + t2;
+  a2 = t0 - t2;
+  a1 = fft_add_rot<INV>(t1, d);
+  a3 = fft_sub_rot<INV>(t1, d);
+}
+
+// 16-point DFT in place, natural order in and out: X[k] = sum_n x[n] W_16^{+-nk}
+template <bool INV>
+FFT_HD void fft_dft16(fft_c32 (&z)[16]) {
+  // n = 4 n1 + n2, k = k1 + 4 k2: DFT4 over n1, twiddle W_16^{n2 k1}, DFT4 over n2
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) fft_dft4<INV>(z[n2], z[n2 + 4], z[n2 + 8], z[n2 + 12]);   // z[n2 + 4 k1]
+  constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+  const float sg = INV ? 1.f : -1.f;   // forward: e^{-i phi}
+  const fft_c32 w1 = fft_mk(c1, sg * s1), w2 = fft_mk(h, sg * h), w3 = fft_mk(s1, sg * c1), w6 = fft_mk(-h, sg * h),
+                w9 = fft_mk(-c1, -sg * s1);
+  // (n2, k1): 1,1 -> W^1   1,2 -> W^2   1,3 -> W^3   2,1 -> W^2   2,2 -> W^4 = -+i   2,3 -> W^6   3,1 -> W^3   3,2 -> W^6   3,3 -> W^9
+  z[1 + 4] = fft_cmul(z[1 + 4], w1);
+  z[1 + 8] = fft_cmul(z[1 + 8], w2);
+  z[1 + 12] = fft_cmul(z[1 + 12], w3);
+  z[2 + 4] = fft_cmul(z[2 + 4], w2);
+  z[2 + 8] = fft_rot<INV>(z[2 + 8]);
+  z[2 + 12] = fft_cmul(z[2 + 12], w6);
+  z[3 + 4] = fft_cmul(z[3 + 4], w3);
+  z[3 + 8] = fft_cmul(z[3 + 8], w6);
+  z[3 + 12] = fft_cmul(z[3 + 12], w9);
+  // DFT4 over n2 for every k1: inputs z[n2 + 4 k1], outputs X[k1 + 4 k2]
+  fft_c32 o[16];
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    fft_c32 a0 = z[0 + 4 * k1], a1 = z[1 + 4 * k1], a2 = z[2 + 4 * k1], a3 = z[3 + 4 * k1];
+    fft_dft4<INV>(a0, a1, a2, a3);
+    o[k1] = a0;
+    o[k1 + 4] = a1;
+    o[k1 + 8] = a2;
+    o[k1 + 12] = a3;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) z[k] = o[k];
+}
+
+// ---- the three register stages and the two exchanges.  `S` is the wave's LDS scratch (kFftScratch elements). ----
+// Layouts (lane, register):  L0 (4 n2 + n3, n1)   L1 (4 k1 + n3, n2)   L2 (4 k1 + j, 4 g + n3 or 4 g + k3), k2 = 4 g + j
+FFT_HD int fft_e1(int k1, int n2, int n3) { return kFftRow * k1 + 4 * n2 + n3; }
+FFT_HD int fft_e2(int k1, int g, int n3, int j) { return kFftRow * k1 + 16 * g + 4 * n3 + ((n3 + j) & 3); }
+// bin held by register r of lane `lane` after the forward transform / before the inverse (layout L2)
+FFT_HD int fft_bin(int lane, int r) { return (lane >> 2) + 16 * ((lane & 3) + 4 * (r >> 2)) + 256 * (r & 3); }
+
+// tw1[k1] = W_1024^{lane k1}, tw2[k2] = W_64^{(lane & 3) k2}  (forward sign; the inverse conjugates)
+FFT_HD void fft_fwd_a(fft_c32 (&z)[16], const fft_c32 (&tw1)[16]) {
+  fft_dft16<false>(z);
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) z[k1] = fft_cmul(z[k1], tw1[k1]);
+}
+template <typename P>
+FFT_HD void fft_x1_write(const fft_c32 (&z)[16], int lane, P S) {   // from L0 (forward) : z[k1] of lane l
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) S[kFftRow * k1 + lane] = z[k1];
+}
+template <typename P>
+FFT_HD void fft_x1_read(fft_c32 (&z)[16], int lane, P S) {          // into L1: z[n2]
+  const int b = fft_e1(lane >> 2, 0, lane & 3);
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) z[n2] = S[b + 4 * n2];
+}
+FFT_HD void fft_fwd_b(fft_c32 (&z)[16], const fft_c32 (&tw2)[16]) {
+  fft_dft16<false>(z);
+#pragma unroll
+  for (int k2 = 1; k2 < 16; ++k2) z[k2] = fft_cmul(z[k2], tw2[k2]);
+}
+// the same with the twiddles read where they are used: tw2s[4 k2] (a table [k2][n3] offset by the lane's n3)
+FFT_HD void fft_fwd_b_tab(fft_c32 (&z)[16], const fft_c32 *tw2s) {
+  fft_dft16<false>(z);
+#pragma unroll
+  for (int k2 = 1; k2 < 16; ++k2) z[k2] = fft_cmul(z[k2], tw2s[4 * k2]);
+}
+FFT_HD void fft_inv_b_tab(fft_c32 (&z)[16], const fft_c32 *tw2s) {
+#pragma unroll
+  for (int k2 = 1; k2 < 16; ++k2) z[k2] = fft_cmul_conj(z[k2], tw2s[4 * k2]);
+  fft_dft16<true>(z);
+}
+template <typename P>
+FFT_HD void fft_x2_write(const fft_c32 (&z)[16], int lane, P S) {   // from L1: z[k2]
+  const int k1 = lane >> 2, n3 = lane & 3;
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) S[fft_e2(k1, k2 >> 2, n3, k2 & 3)] = z[k2];
+}
+template <typename P>
+FFT_HD void fft_x2_read(fft_c32 (&z)[16], int lane, P S) {          // into L2: z[4 g + n3]
+  const int k1 = lane >> 2, j = lane & 3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = S[fft_e2(k1, r >> 2, r & 3, j)];
+}
+FFT_HD void fft_fwd_c(fft_c32 (&z)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) fft_dft4<false>(z[4 * g], z[4 * g + 1], z[4 * g + 2], z[4 * g + 3]);
+}
+// the inverse: the same graph transposed, twiddles conjugated (unscaled: the tables carry 1 / N)
+FFT_HD void fft_inv_c(fft_c32 (&z)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) fft_dft4<true>(z[4 * g], z[4 * g + 1], z[4 * g + 2], z[4 * g + 3]);
+}
+template <typename P>
+FFT_HD void fft_x2_write_back(const fft_c32 (&z)[16], int lane, P S) {   // from L2: z[4 g + n3]
+  const int k1 = lane >> 2, j = lane & 3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) S[fft_e2(k1, r >> 2, r & 3, j)] = z[r];
+}
+template <typename P>
+FFT_HD void fft_x2_read_back(fft_c32 (&z)[16], int lane, P S) {          // into L1: z[k2]
+  const int k1 = lane >> 2, n3 = lane & 3;
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) z[k2] = S[fft_e2(k1, k2 >> 2, n3, k2 & 3)];
+}
+FFT_HD void fft_inv_b(fft_c32 (&z)[16], const fft_c32 (&tw2)[16]) {
+#pragma unroll
+  for (int k2 = 1; k2 < 16; ++k2) z[k2] = fft_cmul_conj(z[k2], tw2[k2]);
+  fft_dft16<true>(z);
+}
+template <typename P>
+FFT_HD void fft_x1_write_back(const fft_c32 (&z)[16], int lane, P S) {   // from L1: z[n2]
+  const int b = fft_e1(lane >> 2, 0, lane & 3);
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) S[b + 4 * n2] = z[n2];
+}
+template <typename P>
+FFT_HD void fft_x1_read_back(fft_c32 (&z)[16], int lane, P S) {          // into L0: z[k1]
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) z[k1] = S[kFftRow * k1 + lane];
+}
+FFT_HD void fft_inv_a(fft_c32 (&z)[16], const fft_c32 (&tw1)[16]) {
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) z[k1] = fft_cmul_conj(z[k1], tw1[k1]);
+  fft_dft16<true>(z);
+}
+// W[k] = U[k] + conj(V[N - k]).  Register r of lane `lane` holds bin L + 64 q, L = (lane >> 2) + 16 (lane & 3), q = (r >> 2)
+// + 4 (r & 3); V goes through the scratch at POSITION lane + 64 q (contiguous lanes: conflict-free).  The mirror bin
+// 1024 - L - 64 q is (64 - L) + 64 (15 - q) for L > 0, held by lane 67 - lane (lanes 4..63) or 4 - lane (lanes 1..3) in its
+// register of q' = 15 - q; for L = 0 (lane 0) it is 64 (16 - q): lane 0 itself, q' = 16 - q, and so that q = 0 needs no
+// wrap lane 0 also stores its bin 0 at position 1024.  Every read address is a per-lane base + a compile-time offset.
+FFT_HD int fft_mirror_q(int r) { return (r >> 2) + 4 * (r & 3); }
+FFT_HD int fft_mirror_base(int lane) { return lane == 0 ? 64 : (lane < 4 ? 4 - lane : 67 - lane); }
+FFT_HD fft_c32 fft_add_conj(fft_c32 a, fft_c32 m) {   // a + conj(m)
+#if defined(__HIP_DEVICE_COMPILE__)
+  fft_c32 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(m));
+  return r;
+#else
+  return fft_mk(a.x + m.x, a.y - m.y);
+#endif
+}
+template <typename P>
+FFT_HD void fft_mirror_write(const fft_c32 (&v)[16], int lane, P S) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) S[lane + 64 * fft_mirror_q(r)] = v[r];
+  if (lane == 0) S[1024] = v[0];
+}
+template <typename P>
+FFT_HD void fft_mirror_read_add(fft_c32 (&u)[16], int lane, P S) {
+  const int b = fft_mirror_base(lane);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) u[r] = fft_add_conj(u[r], S[b + 64 * (15 - fft_mirror_q(r))]);
+}
+
+// ---- host side: the tables of one HRIR set ----
+// hrir: [2 ears][m][taps] floats.  pq: [pairs][16 registers][64 lanes] x (P'.re, P'.im, Q'.re, Q'.im), P' = P / N,
+// Q'[k] = conj(Q[N - k]) / N, in the layout-L2 bin order; tw: [16][64] (W_1024^{lane k1}) then [16][4] (W_64^{n3 k2})
+// complex.  Returns the number of pairs.  Everything is evaluated in double and rounded once.
+// (compiled where IAMF_FFT_HOST_TABLES is defined; the includer provides <math.h> and <vector>)
+#if defined(IAMF_FFT_HOST_TABLES)
+inline int fft_build_tables(const float *hrir, int m, int taps, std::vector<float> &pq, std::vector<float> &tw) {
+  const int pairs = (m + 1) / 2;
+  const double two_pi = 6.283185307179586476925286766559;
+  std::vector<double> cr(kFftN), ci(kFftN);
+  for (int k = 0; k < kFftN; ++k) {
+    cr[k] = cos(two_pi * k / kFftN);
+    ci[k] = -sin(two_pi * k / kFftN);
+  }
+  // G_c[k] = sum_n (hl[n] + i hr[n]) W^{nk}
+  std::vector<double> gr((size_t)m * kFftN), gi((size_t)m * kFftN);
+  for (int c = 0; c < m; ++c)
+    for (int k = 0; k < kFftN; ++k) {
+      double ar = 0, ai = 0;
+      for (int n = 0; n < taps; ++n) {
+        const double hl = hrir[((size_t)0 * m + c) * taps + n], hr = hrir[((size_t)1 * m + c) * taps + n];
+        const int e = (n * k) & (kFftN - 1);
+        ar += hl * cr[e] - hr * ci[e];
+        ai += hl * ci[e] + hr * cr[e];
+      }
+      gr[(size_t)c * kFftN + k] = ar;
+      gi[(size_t)c * kFftN + k] = ai;
+    }
+  pq.assign((size_t)pairs * 16 * 64 * 4, 0.f);
+  for (int p = 0; p < pairs; ++p) {
+    const int a = 2 * p, b = 2 * p + 1;
+    auto G = [&](int c, int k, double &re, double &im) {
+      re = c < m ? gr[(size_t)c * kFftN + k] : 0.0;
+      im = c < m ? gi[(size_t)c * kFftN + k] : 0.0;
+    };
+    for (int r = 0; r < 16; ++r)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int k = fft_bin(lane, r), km = (kFftN - k) & (kFftN - 1);
+        double ar, ai, br, bi;
+        G(a, k, ar, ai);
+        G(b, k, br, bi);
+        // P = (Ga - i Gb) / 2 = ((ar + bi) + i (ai - br)) / 2
+        const double pr = 0.5 * (ar + bi), pi = 0.5 * (ai - br);
+        G(a, km, ar, ai);
+        G(b, km, br, bi);
+        // Q[km] = (Ga + i Gb) / 2 = ((ar - bi) + i (ai + br)) / 2 ; Q' = conj(Q[km])
+        const double qr = 0.5 * (ar - bi), qi = -0.5 * (ai + br);
+        float *o = &pq[(((size_t)p * 16 + r) * 64 + lane) * 4];
+        o[0] = (float)(pr / kFftN);
+        o[1] = (float)(pi / kFftN);
+        o[2] = (float)(qr / kFftN);
+        o[3] = (float)(qi / kFftN);
+      }
+  }
+  tw.assign((size_t)(16 * 64 + 16 * 4) * 2, 0.f);
+  for (int k1 = 0; k1 < 16; ++k1)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int e = (lane * k1) & (kFftN - 1);
+      tw[((size_t)k1 * 64 + lane) * 2 + 0] = (float)cr[e];
+      tw[((size_t)k1 * 64 + lane) * 2 + 1] = (float)ci[e];
+    }
+  for (int k2 = 0; k2 < 16; ++k2)
+    for (int n3 = 0; n3 < 4; ++n3) {
+      const int e = (16 * n3 * k2) & (kFftN - 1);   // W_64^{n3 k2} = W_1024^{16 n3 k2}
+      tw[((size_t)16 * 64 + k2 * 4 + n3) * 2 + 0] = (float)cr[e];
+      tw[((size_t)16 * 64 + k2 * 4 + n3) * 2 + 1] = (float)ci[e];
+    }
+  return pairs;
+}
+#endif
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------------------------------------------
+// device stage.  LDS of the variant: [4 waves][kFftScratch] complex scratch + [2 ears][2 chunks][1024] floats
+// (chunks 1 and 2 of the pass; chunk 0 goes to the limiter's arr_p / arr_g, which are dead until the chunk's own
+// window maxima are written).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kFftLdsFloats = kFftHops * kFftScratch * 2 + 2 * 2 * 1024 + 16 * 4 * 2;   // + the tw2 table
+
+// Lane-constant twiddles: tw1[k1] = W_1024^{lane k1} lives in registers for the whole kernel; tw2[k2] = W_64^{(lane & 3) k2}
+// (64 values per workgroup) is read from LDS where it is used — 30 registers that the accumulators need more.
+constexpr int kFftTw2Floats = 16 * 4 * 2;
+struct FftTwiddles {
+  fft_c32 tw1[16];
+  const fft_c32 *tw2;   // LDS: [k2][n3], already offset by the lane's n3
+};
+__device__ __forceinline__ void fft_load_twiddles(const float *tw, int t, float *tw2_lds, FftTwiddles &o) {
+  const fft_c32 *g = reinterpret_cast<const fft_c32 *>(tw);
+  const int lane = t & 63;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) o.tw1[k] = g[k * 64 + lane];
+  if (t < 64) reinterpret_cast<fft_c32 *>(tw2_lds)[t] = g[16 * 64 + t];   // visible after the kernel's first barrier
+  o.tw2 = reinterpret_cast<const fft_c32 *>(tw2_lds) + (lane & 3);
+}
+
+__device__ __forceinline__ void fft_wave_sync() {   // LDS accesses of one wave execute in order; keep the compiler from reordering them
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// The 16 runs of channel pair `pr` -> z (re = channel 2 pr, im = channel 2 pr + 1 or zeros).  Lane n1 < 16 of (ra_lo,
+// ra_hi, rcs) holds run n1's address for channel 0 and its channel stride in bytes (fir_stage_fft); v_readlane brings them
+// to scalar registers where they are used, so every load is (scalar base) + 4 lane and the 16 runs cost three vector
+// registers instead of 48 scalar ones.
+template <int M>
+__device__ __forceinline__ void fft_fetch(int pr, fft_c32 (&z)[16], unsigned ra_lo, unsigned ra_hi, unsigned rcs,
+                                          uint64_t a_zero, unsigned lo) {
+  const int a = 2 * pr, b = 2 * pr + 1;
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    const uint64_t r0 = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)ra_hi, n1) << 32) |
+                        (unsigned)__builtin_amdgcn_readlane((int)ra_lo, n1);
+    const uint64_t cs = (unsigned)__builtin_amdgcn_readlane((int)rcs, n1);
+    // (addresses built from integers: say that they are GLOBAL ones, or the loads become flat loads)
+    typedef const float __attribute__((address_space(1))) *gptr;
+    const gptr sa = (gptr)(r0 + (uint64_t)a * cs);
+    const gptr sb = (gptr)(b < M ? r0 + (uint64_t)b * cs : a_zero);
+    float va, vb;
+    if (n1 >= 4 && n1 < 12) {   // read by this wave alone: streamed past the caches
+      va = __builtin_nontemporal_load(sa + lo);
+      vb = __builtin_nontemporal_load(sb + lo);
+    } else {                    // the hop's first and last 256 samples are also the neighbouring hops' overlap
+      va = sa[lo];
+      vb = sb[lo];
+    }
+    z[n1] = fft_mk(va, vb);
+  }
+}
+
+// y[e][c0 .. c0 + 3072) of both ears: chunk 0 of the pass -> y0 ([2][1024]), chunks 1, 2 -> y12 ([2][2][1024]).
+// Wave w takes hop w = samples [c0 + 768 w, + 768).  All 256 threads call it; the caller synchronises afterwards.
+template <int M>
+__device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float *in_s, const float *hist, int c0,
+                                              fft_c32 *scratch_all, const FftTwiddles &tw, float *y0, float *y12) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform, and known to be: what follows stays in scalar registers
+  const int b0 = c0 + kFftHop * w;   // the hop's first new sample, relative to the call
+  if (b0 >= p.total) return;         // wave-uniform: the hop lies past the end of the call
+  fft_c32 *S = scratch_all + w * kFftScratch;
+  constexpr int kPairs = (M + 1) / 2;
+  // Where the 64-sample runs n = b0 - 256 + 64 n1 + [0, 64) of a channel come from (the same for every channel).
+  // b0 is a multiple of 256, so samples before the call exist only in the call's first hop and there they are exactly the
+  // runs n1 < 4 (history samples 64 n1 ..); the call's length is a multiple of 64, so "past the end" is decided per run;
+  // and the frame size is a multiple of 64 (the host takes this stage only then: fir_stage_choice), so a run never
+  // straddles a frame.  Run n1 of channel c starts at  base + c * cstride  with base / cstride = a place in the call's
+  // input / the frame size, in the history / 256, or — past the end of the call — a block of zeros / 0.  LANE n1 works
+  // that out for run n1 (one division per hop, in parallel) and keeps it; fft_fetch reads it across with v_readlane.
+  unsigned ra_lo, ra_hi, rcs;
+  const uint64_t a_zero = reinterpret_cast<uint64_t>(p.fir_zero);
+  {
+    const int fs = p.frame_size;
+    const int n1 = lane & 15;
+    const int n = b0 - (kFftN - kFftHop) + 64 * n1;
+    const int nn = n < 0 ? 0 : n;
+    const int f = nn / fs, i = nn - f * fs;
+    uint64_t ad = reinterpret_cast<uint64_t>(in_s) + 4 * (uint64_t)((int64_t)f * p.in_frame_stride + i);
+    unsigned cs = 4u * (unsigned)fs;
+    if (n < 0) {            // history sample 256 + n
+      ad = reinterpret_cast<uint64_t>(hist) + 4 * (uint64_t)(kFirHist + n);
+      cs = 4u * kFirHist;
+    } else if (n >= p.total) {
+      ad = a_zero;
+      cs = 0;
+    }
+    ra_lo = (unsigned)ad;
+    ra_hi = (unsigned)(ad >> 32);
+    rcs = cs;
+  }
+  const unsigned lo = (unsigned)lane;
+#define FFT_FETCH(pr, z) fft_fetch<M>(pr, z, ra_lo, ra_hi, rcs, a_zero, lo)
+  fft_c32 u[16], v[16], z[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) u[r] = v[r] = fft_mk(0.f, 0.f);
+  const float4 *pq = reinterpret_cast<const float4 *>(p.fir_pq);   // uniform base; the lane's share is added per load
+  FFT_FETCH(0, z);
+#pragma unroll 1
+  for (int pr = 0; pr < kPairs; ++pr) {
+    fft_c32 zn[16];
+    // the next pair's samples are in flight during this pair's transform (the last iteration re-reads its own pair
+    // and drops it: no branch, no selects)
+    FFT_FETCH(pr + 1 < kPairs ? pr + 1 : pr, zn);
+    fft_fwd_a(z, tw.tw1);
+    fft_x1_write(z, lane, S);
+    fft_wave_sync();
+    fft_x1_read(z, lane, S);
+    fft_fwd_b_tab(z, tw.tw2);
+    fft_wave_sync();
+    fft_x2_write(z, lane, S);
+    fft_wave_sync();
+    fft_x2_read(z, lane, S);
+    fft_wave_sync();
+    fft_fwd_c(z);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 c = (pq + (pr * 16 + r) * 64)[lo];
+      u[r] = fft_cmac(u[r], z[r], fft_mk(c.x, c.y));
+      v[r] = fft_cmac(v[r], z[r], fft_mk(c.z, c.w));
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = zn[r];
+  }
+  fft_mirror_write(v, lane, S);
+  fft_wave_sync();
+  fft_mirror_read_add(u, lane, S);
+  fft_wave_sync();
+  fft_inv_c(u);
+  fft_x2_write_back(u, lane, S);
+  fft_wave_sync();
+  fft_x2_read_back(u, lane, S);
+  fft_inv_b_tab(u, tw.tw2);
+  fft_wave_sync();
+  fft_x1_write_back(u, lane, S);
+  fft_wave_sync();
+  fft_x1_read_back(u, lane, S);
+  fft_inv_a(u, tw.tw1);
+  // block samples 256 .. 1023 are the hop's 768 outputs: re = left, im = right
+#pragma unroll
+  for (int n1 = 4; n1 < 16; ++n1) {
+    const int m = kFftHop * w + 64 * (n1 - 4) + lane;   // sample of the pass; a 64-run never straddles a chunk
+    const int chunk = m >> 10, n = m & 1023;
+    float *d = chunk == 0 ? y0 + n : y12 + (chunk - 1) * 1024 + n;
+    const int es = chunk == 0 ? 1024 : 2048;
+    d[0] = u[n1].x;
+    d[es] = u[n1].y;
+  }
+#undef FFT_FETCH
+}
+#endif  // __HIPCC__

@@ -118,7 +118,8 @@ def test_fir_pipeline_with_limiter(hip, m):
 
 
 def test_split_f16_stage_against_the_f32_mfma_stage(hip, monkeypatch):
-    """the default stage (three f16 MFMAs per product block on split operands, render_fir16.hpp) against
+    """the split-f16 stage (three f16 MFMAs per product block on split operands, render_fir16.hpp; the default until
+    round 3, now IAMF_HIP_FIR_F16=1) against
     the f32-MFMA stage (render_fir.hpp, IAMF_HIP_FIR_F32=1) on the same input: two independent
     evaluations of the same sums.  Both within 2^-17 of float64; their mutual difference as a histogram in
     units of 2^-24 (the f32 ulp of a value in [0.5, 1))."""
@@ -126,7 +127,9 @@ def test_split_f16_stage_against_the_f32_mfma_stage(hip, monkeypatch):
     fs, F, m, taps = 1024, 4, 16, 256
     x = np.stack([synth.gaussian(860 + s, m, F * fs, 0.12) for s in range(2)])
     h = hrir_set(8, m, taps)
+    monkeypatch.setenv("IAMF_HIP_FIR_F16", "1")
     y16 = _fir_stage_output(A, G, h, x, fs, [F], taps)
+    monkeypatch.delenv("IAMF_HIP_FIR_F16")
     monkeypatch.setenv("IAMF_HIP_FIR_F32", "1")
     y32 = _fir_stage_output(A, G, h, x, fs, [F], taps)
     monkeypatch.delenv("IAMF_HIP_FIR_F32")
@@ -142,3 +145,28 @@ def test_split_f16_stage_against_the_f32_mfma_stage(hip, monkeypatch):
         assert e16 <= 2.0 ** -19 and e32 <= 2.0 ** -19   # 1/4 of the stated float tolerance 2^-17
         assert d.max() <= 16.0, float(d.max())           # 2^-20 absolute between the two stages
         assert (d <= 4.5).mean() > 0.90 and (d <= 8.5).mean() > 0.99
+
+
+def test_fft_stage_against_the_two_mfma_stages(hip, monkeypatch):
+    """the default stage since round 3 — overlap-save in the frequency domain on the VALU (render_fir_fft.hpp: 1024-point
+    transforms, 768-sample hops, two channels per complex transform, both ears per inverse) — against the two direct-form
+    stages on the matrix cores: three independent evaluations of one specification.  All within 2^-19 of float64 at
+    |y| <= 0.5; the FFT stage's error is the f32 rounding of a 1024-point transform pair instead of a 4096-term sum."""
+    A, G = hip
+    fs, F, m, taps = 1024, 7, 16, 256      # 7 frames: two full passes of 3072 samples and a partial one
+    x = np.stack([synth.gaussian(870 + s, m, F * fs, 0.12) for s in range(2)])
+    h = hrir_set(9, m, taps)
+    yf = _fir_stage_output(A, G, h, x, fs, [3, 4], taps)
+    monkeypatch.setenv("IAMF_HIP_FIR_F16", "1")
+    y16 = _fir_stage_output(A, G, h, x, fs, [3, 4], taps)
+    monkeypatch.delenv("IAMF_HIP_FIR_F16")
+    monkeypatch.setenv("IAMF_HIP_FIR_F32", "1")
+    y32 = _fir_stage_output(A, G, h, x, fs, [3, 4], taps)
+    monkeypatch.delenv("IAMF_HIP_FIR_F32")
+    for s in range(2):
+        y64 = fir64(h, x[s]).T
+        ef, e16, e32 = (float(np.abs(y - y64).max()) for y in (yf[s], y16[s], y32[s]))
+        print("stream %d: |fft-f64| max %.3g, |f16-f64| max %.3g, |f32-f64| max %.3g, |fft-f32| max %.3g"
+              % (s, ef, e16, e32, float(np.abs(yf[s] - y32[s]).max())))
+        assert ef <= 2.0 ** -19 and e16 <= 2.0 ** -19 and e32 <= 2.0 ** -19
+        assert not np.array_equal(yf[s], y16[s])   # it really is another stage that ran

@@ -39,6 +39,7 @@ def guard():
     L = C.CDLL(so)
     L.guard_alloc.argtypes = [C.c_size_t, C.POINTER(GuardBuf)]
     L.guard_free.argtypes = [C.POINTER(GuardBuf)]
+    L.guard_upload.argtypes = [C.POINTER(GuardBuf), C.c_void_p, C.c_size_t]
     return L
 
 
@@ -51,11 +52,15 @@ def _render_from_guarded(guard, A, mx, out_ch, x, fs, **kw):
     assert guard.guard_alloc(nbytes, C.byref(g)) == 0
     try:
         assert g.ptr + nbytes == g.base + g.mapped
-        host = np.ascontiguousarray(x, dtype=np.float32)
-        stage = torch.from_numpy(host).cuda()
+        stage = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+        torch.cuda.synchronize()
+        assert guard.guard_upload(C.byref(g), C.c_void_p(stage.data_ptr()), nbytes) == 0
+        back = torch.empty_like(stage)   # what the kernel will read is what was uploaded
         rt = C.CDLL("libamdhip64.so")
         rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        assert rt.hipMemcpy(g.ptr, stage.data_ptr(), nbytes, 3) == 0   # device to device
+        assert rt.hipMemcpy(back.data_ptr(), g.ptr, nbytes, 3) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(back, stage), "guarded buffer does not hold the uploaded input"
         b = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True, **kw)
         cap = max(fs, 240) * out_ch * 2
         pcm = torch.zeros((S, cap), dtype=torch.uint8, device="cuda")
