@@ -279,7 +279,7 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
   for (int c = 0; c < OC; ++c) live[c] = FIR || DOWN || p.src_feed[c] >= 0;
   const float *fir_hist = FIR ? p.fir_hist + (int64_t)s * M * kFirHist : nullptr;
   FftTwiddles ftw;
-  if constexpr (FIR == 3) fft_load_twiddles(p.fir_tw, t, fir + kFftLdsFloats - kFftTw2Floats, ftw);
+  if constexpr (FIR == 3) fft_load_twiddles(p.fir_tw, t, fir + kFftLdsFloats - kFftTwFloats, ftw);
   // second element: constant gain (skipped by the reference when it is 1 or not positive)
   const float eg2 = (IN2 && p.in2) ? p.gains2[s] : 1.f;
   const float m_eg2 = (eg2 != 1.f && eg2 > 0.f) ? eg2 : 1.f;
@@ -379,9 +379,9 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
       if (((c0 >> 10) & 3) == 0) fir_stage16<M>(p, in_s, fir_hist, c0, fir, fir);
     }
     else if constexpr (FIR == 1) fir_stage<M>(p, in_s, fir_hist, c0, fir, fir);  // ... as four partial sums per ear
-    else if constexpr (FIR == 3) {  // both ears of this chunk and the next two: chunk 0 -> arr_p / arr_g, the others -> fir
+    else if constexpr (FIR == 3) {  // both ears of this chunk and the next two -> the waves' scratch areas
       if ((c0 >> 10) % 3 == 0) {
-        fir_stage_fft<M>(p, in_s, fir_hist, c0, reinterpret_cast<fft_c32 *>(fir), ftw, arr_p, fir + kFftHops * kFftScratch * 2);
+        fir_stage_fft<M>(p, in_s, fir_hist, c0, reinterpret_cast<fft_c32 *>(fir), ftw);
         __syncthreads();
       }
     }
@@ -397,9 +397,7 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (FIR == 3) {
         // ear c of this chunk, left by the FFT stage's last pass (render_fir_fft.hpp)
-        const int cj = (c0 >> 10) % 3;
-        const float *p0 = cj == 0 ? arr_p + c * kFChunk : fir + kFftHops * kFftScratch * 2 + (c * 2 + cj - 1) * kFChunk;
-        v = *reinterpret_cast<const float4 *>(p0 + 4 * t);
+        v = *reinterpret_cast<const float4 *>(fft_y_ptr(fir, c, 1024 * ((c0 >> 10) % 3) + 4 * t));
       } else if constexpr (FIR == 2) {
         // ear c of this chunk, left by the split-f16 stage's last pass
         const float *p0 = fir + (c * 4 + ((c0 >> 10) & 3)) * kF16Part;

@@ -192,11 +192,37 @@ FFT_HD void fft_fwd_b(fft_c32 (&z)[16], const fft_c32 (&tw2)[16]) {
 #pragma unroll
   for (int k2 = 1; k2 < 16; ++k2) z[k2] = fft_cmul(z[k2], tw2[k2]);
 }
-// the same with the twiddles read where they are used: tw2s[4 k2] (a table [k2][n3] offset by the lane's n3)
-FFT_HD void fft_fwd_b_tab(fft_c32 (&z)[16], const fft_c32 *tw2s) {
+// the same with the twiddles read where they are used: tw1s[64 k1] (a table [k1][lane] offset by the lane) and
+// tw2s[4 k2] (a table [k2][n3] offset by the lane's n3)
+// (the table reads are issued BEFORE the 16-point transform that hides their latency and pinned there: left alone, the
+// scheduler sinks every read to its use to save registers and the wave waits for each of them in turn)
+FFT_HD void fft_pin() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+FFT_HD void fft_fwd_a_tab(fft_c32 (&z)[16], const fft_c32 *tw1s) {
+  fft_c32 w[16];
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) w[k1] = tw1s[64 * k1];
+  fft_pin();
   fft_dft16<false>(z);
 #pragma unroll
-  for (int k2 = 1; k2 < 16; ++k2) z[k2] = fft_cmul(z[k2], tw2s[4 * k2]);
+  for (int k1 = 1; k1 < 16; ++k1) z[k1] = fft_cmul(z[k1], w[k1]);
+}
+FFT_HD void fft_inv_a_tab(fft_c32 (&z)[16], const fft_c32 *tw1s) {
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) z[k1] = fft_cmul_conj(z[k1], tw1s[64 * k1]);
+  fft_dft16<true>(z);
+}
+FFT_HD void fft_fwd_b_tab(fft_c32 (&z)[16], const fft_c32 *tw2s) {
+  fft_c32 w[16];
+#pragma unroll
+  for (int k2 = 1; k2 < 16; ++k2) w[k2] = tw2s[4 * k2];
+  fft_pin();
+  fft_dft16<false>(z);
+#pragma unroll
+  for (int k2 = 1; k2 < 16; ++k2) z[k2] = fft_cmul(z[k2], w[k2]);
 }
 FFT_HD void fft_inv_b_tab(fft_c32 (&z)[16], const fft_c32 *tw2s) {
 #pragma unroll
@@ -359,26 +385,26 @@ inline int fft_build_tables(const float *hrir, int m, int taps, std::vector<floa
 
 #if defined(__HIPCC__)
 // ------------------------------------------------------------------------------------------------------
-// device stage.  LDS of the variant: [4 waves][kFftScratch] complex scratch + [2 ears][2 chunks][1024] floats
-// (chunks 1 and 2 of the pass; chunk 0 goes to the limiter's arr_p / arr_g, which are dead until the chunk's own
-// window maxima are written).
+// device stage.  LDS of the variant: [4 waves][kFftScratch] complex scratch + the twiddle tables.  A wave leaves its
+// hop's 768 outputs per ear in ITS OWN scratch ([2 ears][768] floats: the scratch is idle between two passes), where the
+// limiter stages of the following three chunks read them (fft_y_ptr).
 // ------------------------------------------------------------------------------------------------------
-constexpr int kFftLdsFloats = kFftHops * kFftScratch * 2 + 2 * 2 * 1024 + 16 * 4 * 2;   // + the tw2 table
+constexpr int kFftLdsFloats = kFftHops * kFftScratch * 2 + (16 * 64 + 16 * 4) * 2;   // scratch + the twiddle tables
 
-// Lane-constant twiddles: tw1[k1] = W_1024^{lane k1} lives in registers for the whole kernel; tw2[k2] = W_64^{(lane & 3) k2}
-// (64 values per workgroup) is read from LDS where it is used — 30 registers that the accumulators need more.
-constexpr int kFftTw2Floats = 16 * 4 * 2;
+// Lane-constant twiddles, both read from LDS where they are used: tw1[k1] = W_1024^{lane k1} (a [16][64] table) and tw2[k2] =
+// W_64^{(lane & 3) k2} ([16][4]).  In registers they would be 60 of the 256 a wave has at two waves per SIMD, and the
+// accumulators, the transform in flight and the two prefetches (next pair's samples, this pair's spectra) need those.
+constexpr int kFftTwFloats = (16 * 64 + 16 * 4) * 2;
 struct FftTwiddles {
-  fft_c32 tw1[16];
-  const fft_c32 *tw2;   // LDS: [k2][n3], already offset by the lane's n3
+  const fft_c32 *tw1;   // LDS: [k1][64], already offset by the lane
+  const fft_c32 *tw2;   // LDS: [k2][4], already offset by the lane's n3
 };
-__device__ __forceinline__ void fft_load_twiddles(const float *tw, int t, float *tw2_lds, FftTwiddles &o) {
+__device__ __forceinline__ void fft_load_twiddles(const float *tw, int t, float *tw_lds, FftTwiddles &o) {
   const fft_c32 *g = reinterpret_cast<const fft_c32 *>(tw);
-  const int lane = t & 63;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) o.tw1[k] = g[k * 64 + lane];
-  if (t < 64) reinterpret_cast<fft_c32 *>(tw2_lds)[t] = g[16 * 64 + t];   // visible after the kernel's first barrier
-  o.tw2 = reinterpret_cast<const fft_c32 *>(tw2_lds) + (lane & 3);
+  fft_c32 *l = reinterpret_cast<fft_c32 *>(tw_lds);
+  for (int i = t; i < 16 * 64 + 16 * 4; i += 256) l[i] = g[i];   // visible after the kernel's first barrier
+  o.tw1 = l + (t & 63);
+  o.tw2 = l + 16 * 64 + (t & 3);
 }
 
 __device__ __forceinline__ void fft_wave_sync() {   // LDS accesses of one wave execute in order; keep the compiler from reordering them
@@ -415,11 +441,17 @@ __device__ __forceinline__ void fft_fetch(int pr, fft_c32 (&z)[16], unsigned ra_
   }
 }
 
-// y[e][c0 .. c0 + 3072) of both ears: chunk 0 of the pass -> y0 ([2][1024]), chunks 1, 2 -> y12 ([2][2][1024]).
+// where the stage left sample m (0 .. 3071, a multiple of 4) of the pass for ear e: four consecutive samples lie together
+__device__ __forceinline__ const float *fft_y_ptr(const float *scratch_all, int e, int m) {
+  const int hop = m / kFftHop;
+  return scratch_all + hop * (kFftScratch * 2) + e * kFftHop + (m - hop * kFftHop);
+}
+
+// y[e][c0 .. c0 + 3072) of both ears -> the waves' scratch areas (fft_y_ptr).
 // Wave w takes hop w = samples [c0 + 768 w, + 768).  All 256 threads call it; the caller synchronises afterwards.
 template <int M>
 __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float *in_s, const float *hist, int c0,
-                                              fft_c32 *scratch_all, const FftTwiddles &tw, float *y0, float *y12) {
+                                              fft_c32 *scratch_all, const FftTwiddles &tw) {
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform, and known to be: what follows stays in scalar registers
   const int b0 = c0 + kFftHop * w;   // the hop's first new sample, relative to the call
@@ -463,11 +495,19 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
   FFT_FETCH(0, z);
 #pragma unroll 1
   for (int pr = 0; pr < kPairs; ++pr) {
+    // In flight during this pair's transform: the next pair's samples (the last iteration re-reads its own pair and
+    // drops it: no branch, no selects) and the first HALF of this pair's spectra table (8 x 16 bytes per lane, from L2).
+    // The second half is fetched into the same registers as the first is consumed.  [Fetched where they are used, the
+    // table reads cost a full L2 round trip per pair with nothing to overlap it: the stage ran at a fifth of its
+    // instruction rate.]
     fft_c32 zn[16];
-    // the next pair's samples are in flight during this pair's transform (the last iteration re-reads its own pair
-    // and drops it: no branch, no selects)
     FFT_FETCH(pr + 1 < kPairs ? pr + 1 : pr, zn);
-    fft_fwd_a(z, tw.tw1);
+    const float4 *tq = pq + pr * 16 * 64;
+    float4 c[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) c[r] = (tq + r * 64)[lo];
+    fft_pin();   // both prefetches are issued here, ahead of the transform, and stay here
+    fft_fwd_a_tab(z, tw.tw1);
     fft_x1_write(z, lane, S);
     fft_wave_sync();
     fft_x1_read(z, lane, S);
@@ -479,10 +519,15 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
     fft_wave_sync();
     fft_fwd_c(z);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float4 c = (pq + (pr * 16 + r) * 64)[lo];
-      u[r] = fft_cmac(u[r], z[r], fft_mk(c.x, c.y));
-      v[r] = fft_cmac(v[r], z[r], fft_mk(c.z, c.w));
+    for (int r = 0; r < 8; ++r) {
+      u[r] = fft_cmac(u[r], z[r], fft_mk(c[r].x, c[r].y));
+      v[r] = fft_cmac(v[r], z[r], fft_mk(c[r].z, c[r].w));
+      c[r] = (tq + (8 + r) * 64)[lo];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      u[8 + r] = fft_cmac(u[8 + r], z[8 + r], fft_mk(c[r].x, c[r].y));
+      v[8 + r] = fft_cmac(v[8 + r], z[8 + r], fft_mk(c[r].z, c[r].w));
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) z[r] = zn[r];
@@ -500,16 +545,17 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
   fft_x1_write_back(u, lane, S);
   fft_wave_sync();
   fft_x1_read_back(u, lane, S);
-  fft_inv_a(u, tw.tw1);
-  // block samples 256 .. 1023 are the hop's 768 outputs: re = left, im = right
+  fft_inv_a_tab(u, tw.tw1);
+  // block samples 256 .. 1023 are the hop's 768 outputs: re = left, im = right.  They go to the wave's own scratch, which
+  // nobody else touches and the wave itself is done with ([2][768] floats; the last exchange has been read back above).
+  fft_wave_sync();
+  {
+    float *y = reinterpret_cast<float *>(S);
 #pragma unroll
-  for (int n1 = 4; n1 < 16; ++n1) {
-    const int m = kFftHop * w + 64 * (n1 - 4) + lane;   // sample of the pass; a 64-run never straddles a chunk
-    const int chunk = m >> 10, n = m & 1023;
-    float *d = chunk == 0 ? y0 + n : y12 + (chunk - 1) * 1024 + n;
-    const int es = chunk == 0 ? 1024 : 2048;
-    d[0] = u[n1].x;
-    d[es] = u[n1].y;
+    for (int n1 = 4; n1 < 16; ++n1) {
+      y[64 * (n1 - 4) + lane] = u[n1].x;
+      y[kFftHop + 64 * (n1 - 4) + lane] = u[n1].y;
+    }
   }
 #undef FFT_FETCH
 }

@@ -43,43 +43,54 @@ def guard():
     return L
 
 
+_GUARD = {}   # ONE guarded mapping per process, reused by every case: unmapping a range and mapping new memory at the
+              # same addresses later in the process returned stale data on this stack (the read-back below caught it), and
+              # the driver's handling of that is not what these tests are about
+
+
+def _guard_buf(guard, nbytes):
+    if "g" not in _GUARD:
+        g = GuardBuf()
+        assert guard.guard_alloc(8 << 20, C.byref(g)) == 0
+        _GUARD["g"] = g
+    g = _GUARD["g"]
+    assert nbytes <= g.mapped and nbytes % 16 == 0
+    return g, g.base + g.mapped - nbytes     # the buffer ENDS where the mapping ends
+
+
 def _render_from_guarded(guard, A, mx, out_ch, x, fs, **kw):
     """x [S][m][fs]: ONE frame per stream, tight strides, the whole input ending at the guard"""
     import torch
     S, m, _ = x.shape
     nbytes = S * m * fs * 4
-    g = GuardBuf()
-    assert guard.guard_alloc(nbytes, C.byref(g)) == 0
-    try:
-        assert g.ptr + nbytes == g.base + g.mapped
-        stage = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
-        torch.cuda.synchronize()
-        assert guard.guard_upload(C.byref(g), C.c_void_p(stage.data_ptr()), nbytes) == 0
-        back = torch.empty_like(stage)   # what the kernel will read is what was uploaded
-        rt = C.CDLL("libamdhip64.so")
-        rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        assert rt.hipMemcpy(back.data_ptr(), g.ptr, nbytes, 3) == 0
-        torch.cuda.synchronize()
-        assert torch.equal(back, stage), "guarded buffer does not hold the uploaded input"
-        b = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True, **kw)
-        cap = max(fs, 240) * out_ch * 2
-        pcm = torch.zeros((S, cap), dtype=torch.uint8, device="cuda")
-        st = torch.cuda.current_stream().cuda_stream
-        n1 = b.render(g.ptr, m * fs, m * fs, 1, pcm.data_ptr(), cap, st)
-        torch.cuda.synchronize()
-        first = pcm.cpu().numpy()
-        pcm.zero_()
-        n2 = b.flush(pcm.data_ptr(), cap, st)
-        torch.cuda.synchronize()
-        second = pcm.cpu().numpy()
-        b.close()
-        outs = []
-        for s in range(S):
-            outs.append(np.concatenate([first[s][:n1 * out_ch * 2].view(np.int16).reshape(n1, out_ch),
-                                        second[s][:n2 * out_ch * 2].view(np.int16).reshape(n2, out_ch)]))
-        return outs
-    finally:
-        assert guard.guard_free(C.byref(g)) == 0
+    g, ptr = _guard_buf(guard, nbytes)
+    stage = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+    torch.cuda.synchronize()
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert rt.hipMemcpy(ptr, stage.data_ptr(), nbytes, 3) == 0      # device to device: through the L2, like the kernels' reads
+    torch.cuda.synchronize()
+    back = torch.empty_like(stage)   # what the kernel will read is what was uploaded
+    assert rt.hipMemcpy(back.data_ptr(), ptr, nbytes, 3) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(back, stage), "guarded buffer does not hold the uploaded input"
+    b = A.Batch(S, mx, out_ch, frame_size=fs, out_format=A.FMT_S16, limiter=True, **kw)
+    cap = max(fs, 240) * out_ch * 2
+    pcm = torch.zeros((S, cap), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    n1 = b.render(ptr, m * fs, m * fs, 1, pcm.data_ptr(), cap, st)
+    torch.cuda.synchronize()
+    first = pcm.cpu().numpy()
+    pcm.zero_()
+    n2 = b.flush(pcm.data_ptr(), cap, st)
+    torch.cuda.synchronize()
+    second = pcm.cpu().numpy()
+    b.close()
+    outs = []
+    for s in range(S):
+        outs.append(np.concatenate([first[s][:n1 * out_ch * 2].view(np.int16).reshape(n1, out_ch),
+                                    second[s][:n2 * out_ch * 2].view(np.int16).reshape(n2, out_ch)]))
+    return outs
 
 
 @pytest.mark.parametrize("fs", [960, 512, 768, 256, 1024])
