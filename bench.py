@@ -675,6 +675,9 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to measure a different job than the one asked for"
                          % (args.gpus, world))
+    # rocm-smi is a program of its own: start it BEFORE this process touches the GPU (a process that has initialised the
+    # GPU must not fork + exec on this pool; under rocprofv3 the box refuses it)
+    dev_info = device_info() if rank == 0 else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
     rehearse = bool(args.rehearse_one_gpu)
@@ -796,7 +799,7 @@ def main():
             "x_realtime": round(value / 0.048, 1),
             "ranks_seen": ranks_seen, "rccl_version": rccl,
             "launched_by": os.environ.get("IAMF_LAUNCHED_BY", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
-            "device": device_info(),
+            "device": dev_info,
             "repeats": {"n": len(regions), "steps_each": args.steps, "reported": "median",
                         "ms_per_step": [round(e / args.steps * 1e3, 4) for e, _ in regions],
                         "value_min": round(total_sf / max(e for e, _ in regions) / 1e6, 2),

@@ -74,8 +74,8 @@ namespace {
 // wins (the highest channel), the last sample's surplus channels past the zeroed area.  One thread per
 // output element reproduces exactly that.  src: natural interleaving [n][ch].
 __global__ __launch_bounds__(256) void restride_kernel(const uint8_t *src, int64_t src_stream_stride, uint8_t *dst,
-                                                       int64_t dst_stream_stride, int n, int ch, int sc, int bps) {
-  const int s = blockIdx.y;
+                                                       int64_t dst_stream_stride, int n, int ch, int sc, int bps, int stream0) {
+  const int s = blockIdx.y + stream0;
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t n_out = (int64_t)n * sc + (ch > sc ? ch - sc : 0);
   if (p >= n_out) return;
@@ -186,8 +186,9 @@ struct iamf_hip_batch {
   int32_t *d_src_feed = nullptr;
   float thr = 0.f;
   int n_atk = 0, n_end = 0;
-  int64_t pos = 0;      // samples consumed per stream
-  bool flushed = false;
+  std::vector<int64_t> spos;        // samples consumed, per stream (streams advance together unless the range calls are used)
+  std::vector<uint8_t> sflushed;    // per stream: the limiter's tail has been emitted
+  bool any_rendered = false;        // the setters that must precede the first render check this
   float *d_matrix = nullptr, *d_gains = nullptr, *d_ctab = nullptr, *d_ring_y = nullptr,
         *d_ring_pm = nullptr;
   LimState *d_lim = nullptr;
@@ -267,8 +268,9 @@ int reset_state(iamf_hip_batch *b) {
     HIPCHK(hipMemset(b->d_lfe_state, 0, sizeof(float) * 4 * (size_t)ns));
     HIPCHK(hipMemset(b->d_lfe_next, 0, sizeof(float) * 2 * (size_t)ns));
   }
-  b->pos = 0;
-  b->flushed = false;
+  b->spos.assign((size_t)ns, 0);
+  b->sflushed.assign((size_t)ns, 0);
+  b->any_rendered = false;
   return IAMF_HIP_OK;
 }
 
@@ -427,7 +429,7 @@ bool wide4_path_ok(const RenderParams &p, int m) {
 }
 
 int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
-  dim3 grid((unsigned)p.n_streams);
+  dim3 grid((unsigned)p.n_launch);
   if (p.fir_taps > 0 && p.in) {  // HRTF renderer: aligned calls only (the flush goes to the generic kernel)
     if (!fast_path_ok(p)) return IAMF_HIP_ERR_UNIMPLEMENTED;
     // the FIR stage keeps input offsets of one stream as 32-bit integers
@@ -497,10 +499,20 @@ const int kLayoutCh[9][12] = {
 const int kLayoutSurround[9] = {1, 2, 5, 5, 5, 7, 7, 7, 3};
 const int kLayoutTop[9] = {0, 0, 0, 2, 4, 0, 2, 4, 2};
 
-int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
+// streams [s0, s0 + cnt) of the batch; they must stand at the same position (samples consumed so far)
+int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int s0, int cnt) {
   if (!on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
+  if (s0 < 0 || cnt <= 0 || s0 + cnt > b->cfg.n_streams) return IAMF_HIP_ERR_BAD_ARG;
+  const int64_t pos = b->spos[(size_t)s0];
+  for (int i = s0; i < s0 + cnt; ++i)
+    if (b->spos[(size_t)i] != pos || b->sflushed[(size_t)i]) return IAMF_HIP_ERR_INVALID_STATE;
+  const bool whole = s0 == 0 && cnt == b->cfg.n_streams;
+  // per-batch (not per-stream) state: the FIR history ping-pong, the LFE pre-pass blocks of 64 streams, the restride scratch
+  if (!whole && (b->fir || b->lfe)) return IAMF_HIP_ERR_UNIMPLEMENTED;
   RenderParams p;
   memset(&p, 0, sizeof(p));
+  p.stream0 = s0;
+  p.n_launch = cnt;
   p.in = a.d_in;
   p.in_stream_stride = a.in_stream_stride;
   p.in_frame_stride = a.in_frame_stride;
@@ -512,7 +524,7 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
   p.lim = b->d_lim;
   p.ring_y = b->d_ring_y;
   p.ring_pm = b->d_ring_pm;
-  p.pos0 = b->pos;
+  p.pos0 = pos;
   p.total = total;
   p.frame_size = b->cfg.frame_size;
   p.n_streams = b->cfg.n_streams;
@@ -658,15 +670,16 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total) {
   const int r = launch(p, m_eff, lds, static_cast<hipStream_t>(a.stream));
   if (r != IAMF_HIP_OK) return r;
   if (b->fir && p.in) b->fir_cur ^= 1;
-  const int64_t before = p.limiter_on ? (b->pos > kDelay ? b->pos - kDelay : 0) : b->pos;
-  b->pos += total;
-  const int64_t after = p.limiter_on ? (b->pos > kDelay ? b->pos - kDelay : 0) : b->pos;
+  const int64_t before = p.limiter_on ? (pos > kDelay ? pos - kDelay : 0) : pos;
+  for (int i = s0; i < s0 + cnt; ++i) b->spos[(size_t)i] = pos + total;
+  b->any_rendered = true;
+  const int64_t after = p.limiter_on ? (pos + total > kDelay ? pos + total - kDelay : 0) : pos + total;
   const int n_emit = (int)(after - before);
   if (restride && n_emit > 0) {
     const int64_t n_out = (int64_t)n_emit * sc + (p.out_ch > sc ? p.out_ch - sc : 0);
-    hipLaunchKernelGGL(restride_kernel, dim3((unsigned)((n_out + 255) / 256), (unsigned)p.n_streams), dim3(256), 0,
+    hipLaunchKernelGGL(restride_kernel, dim3((unsigned)((n_out + 255) / 256), (unsigned)cnt), dim3(256), 0,
                        static_cast<hipStream_t>(a.stream), b->d_nat, p.pcm_stream_stride,
-                       static_cast<uint8_t *>(a.d_pcm), a.pcm_stream_stride_bytes, n_emit, p.out_ch, sc, bps);
+                       static_cast<uint8_t *>(a.d_pcm), a.pcm_stream_stride_bytes, n_emit, p.out_ch, sc, bps, s0);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipEventRecord(b->done, static_cast<hipStream_t>(a.stream)));
@@ -987,9 +1000,9 @@ int iamf_hip_batch_set_gains(iamf_hip_batch *b, const float *eg, const float *og
   return IAMF_HIP_OK;
 }
 
-int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *a) {
+int iamf_hip_batch_render_range(iamf_hip_batch *b, const iamf_hip_render_args *a, int32_t stream0, int32_t n_streams) {
   if (!b || !a || !a->d_in || !a->d_pcm || a->n_frames < 0) return IAMF_HIP_ERR_BAD_ARG;
-  if (b->flushed) return IAMF_HIP_ERR_INVALID_STATE;
+  if (stream0 < 0 || n_streams <= 0 || stream0 + n_streams > b->cfg.n_streams) return IAMF_HIP_ERR_BAD_ARG;
   if (a->n_frames == 0) return 0;
   if (b->has2 && !a->d_in2) return IAMF_HIP_ERR_BAD_ARG;
   if (b->dmx && !a->d_dmx_frames) return IAMF_HIP_ERR_BAD_ARG;
@@ -1009,7 +1022,12 @@ int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *a) {
   const int64_t need = (total * sc + (b->cfg.out_channels > sc ? b->cfg.out_channels - sc : 0)) *
                        iamf_hip_format_bytes(b->cfg.out_format);
   if (b->cfg.n_streams > 1 && a->pcm_stream_stride_bytes < need) return IAMF_HIP_ERR_BUFFER_TOO_SMALL;
-  return render_call(b, *a, (int)total);
+  return render_call(b, *a, (int)total, stream0, n_streams);
+}
+
+int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *a) {
+  if (!b) return IAMF_HIP_ERR_BAD_ARG;
+  return iamf_hip_batch_render_range(b, a, 0, b->cfg.n_streams);
 }
 
 int iamf_hip_batch_render(iamf_hip_batch *b, const float *d_in, int64_t in_stream_stride,
@@ -1028,24 +1046,33 @@ int iamf_hip_batch_render(iamf_hip_batch *b, const float *d_in, int64_t in_strea
   return iamf_hip_batch_render_ex(b, &a);
 }
 
-int iamf_hip_batch_flush(iamf_hip_batch *b, void *d_pcm, int64_t pcm_stream_stride_bytes, void *stream) {
+int iamf_hip_batch_flush_range(iamf_hip_batch *b, void *d_pcm, int64_t pcm_stream_stride_bytes, void *stream,
+                               int32_t stream0, int32_t n_streams) {
   if (!b || !d_pcm) return IAMF_HIP_ERR_BAD_ARG;
-  if (b->flushed) return IAMF_HIP_ERR_INVALID_STATE;
+  if (stream0 < 0 || n_streams <= 0 || stream0 + n_streams > b->cfg.n_streams) return IAMF_HIP_ERR_BAD_ARG;
+  for (int i = stream0; i < stream0 + n_streams; ++i)
+    if (b->sflushed[(size_t)i]) return IAMF_HIP_ERR_INVALID_STATE;
   if (!b->cfg.limiter_enable) return 0;
   iamf_hip_render_args a;
   memset(&a, 0, sizeof(a));  // no inputs: 240 zero samples go through the limiter
   a.d_pcm = d_pcm;
   a.pcm_stream_stride_bytes = pcm_stream_stride_bytes;
   a.stream = stream;
-  const int r = render_call(b, a, kDelay);
-  if (r >= 0) b->flushed = true;
+  const int r = render_call(b, a, kDelay, stream0, n_streams);
+  if (r >= 0)
+    for (int i = stream0; i < stream0 + n_streams; ++i) b->sflushed[(size_t)i] = 1;
   return r;
+}
+
+int iamf_hip_batch_flush(iamf_hip_batch *b, void *d_pcm, int64_t pcm_stream_stride_bytes, void *stream) {
+  if (!b) return IAMF_HIP_ERR_BAD_ARG;
+  return iamf_hip_batch_flush_range(b, d_pcm, pcm_stream_stride_bytes, stream, 0, b->cfg.n_streams);
 }
 
 int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *mx, const float *g2) {
   if (b && !on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
   if (!b || !mx || !mx->mat || mx->m <= 0 || mx->m > kMaxIn || mx->n <= 0 || mx->n > kMaxOut ||
-      mx->kind == IAMF_HIP_KIND_DMX || b->pos != 0)
+      mx->kind == IAMF_HIP_KIND_DMX || b->any_rendered)
     return IAMF_HIP_ERR_BAD_ARG;
   std::vector<float> fm;
   int32_t feed[kMaxOut];
@@ -1072,7 +1099,7 @@ int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *
 
 int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *matrix, int l_in) {
   if (b && !on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
-  if (!b || !matrix || l_in <= 0 || l_in > kMaxIn || b->pos != 0 || b->dmx || b->fir) return IAMF_HIP_ERR_BAD_ARG;
+  if (!b || !matrix || l_in <= 0 || l_in > kMaxIn || b->any_rendered || b->dmx || b->fir) return IAMF_HIP_ERR_BAD_ARG;
   (void)hipFree(b->d_pre);
   b->d_pre = nullptr;
   HIPCHK(hipMalloc(&b->d_pre, sizeof(float) * (size_t)l_in * b->m));
@@ -1117,7 +1144,7 @@ int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *matrix, int l_
 
 int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *c) {
   if (b && !on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
-  if (!b || !c || b->pos != 0 || b->fir || b->d_pre) return IAMF_HIP_ERR_BAD_ARG;
+  if (!b || !c || b->any_rendered || b->fir || b->d_pre) return IAMF_HIP_ERR_BAD_ARG;
   if (c->layout < 0 || c->layout > 8 || c->n_in != kLayoutCount[c->layout] || c->n_in != b->m ||
       c->n_gain < 0 || c->n_gain > 12)
     return IAMF_HIP_ERR_BAD_ARG;

@@ -34,7 +34,7 @@ void launch_fir_m(const RenderParams &p, hipStream_t st) {
     opted.set(reinterpret_cast<const void *>(&render_fast_kernel<M, 2, 3>), 120 * 1024);
     opted.end();
   }
-  const dim3 grid((unsigned)p.n_streams);
+  const dim3 grid((unsigned)p.n_launch);
   const int stage = fir_stage_choice(p);   // as launch_fir_m of iamf_render.hip
   if (stage == 3) {
     static_assert(fast_lds_floats(2, M, 3) * 4 <= 80 * 1024, "two workgroups per CU");

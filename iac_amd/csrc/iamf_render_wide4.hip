@@ -31,9 +31,9 @@ void launch_mc(const RenderParams &p, hipStream_t st) {
     opted.end();
   }
   if (p.use_mfma)
-    hipLaunchKernelGGL((render_wide4_kernel<M, C, true, false>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((render_wide4_kernel<M, C, true, false>), dim3((unsigned)p.n_launch), dim3(256), lds, st, p);
   else
-    hipLaunchKernelGGL((render_wide4_kernel<M, C, false, false>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((render_wide4_kernel<M, C, false, false>), dim3((unsigned)p.n_launch), dim3(256), lds, st, p);
 }
 
 // scalable channel audio: M decoded channels -> demixer -> the M channels of the target layout -> C
@@ -46,7 +46,7 @@ void launch_mc_demixer(const RenderParams &p, hipStream_t st) {
     opted.set(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, true>), 80 * 1024);
     opted.end();
   }
-  hipLaunchKernelGGL((render_wide4_kernel<M, C, false, true>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((render_wide4_kernel<M, C, false, true>), dim3((unsigned)p.n_launch), dim3(256), lds, st, p);
 }
 
 // parametric down-mixer: M channels of the element's layout -> the C channels of a smaller IAMF layout
@@ -58,7 +58,7 @@ void launch_mc_downmixer(const RenderParams &p, hipStream_t st) {
     opted.set(reinterpret_cast<const void *>(&render_wide4_kernel<M, C, false, false, true>), 80 * 1024);
     opted.end();
   }
-  hipLaunchKernelGGL((render_wide4_kernel<M, C, false, false, true>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((render_wide4_kernel<M, C, false, false, true>), dim3((unsigned)p.n_launch), dim3(256), lds, st, p);
 }
 
 template <int M>

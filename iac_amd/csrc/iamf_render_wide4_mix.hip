@@ -33,9 +33,9 @@ void launch_mc(const RenderParams &p, hipStream_t st) {
     opted.end();
   }
   if (p.use_mfma)
-    hipLaunchKernelGGL((render_wide4_kernel<M, C, true, false, false, true>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((render_wide4_kernel<M, C, true, false, false, true>), dim3((unsigned)p.n_launch), dim3(256), lds, st, p);
   else
-    hipLaunchKernelGGL((render_wide4_kernel<M, C, false, false, false, true>), dim3((unsigned)p.n_streams), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((render_wide4_kernel<M, C, false, false, false, true>), dim3((unsigned)p.n_launch), dim3(256), lds, st, p);
 }
 
 template <int M>

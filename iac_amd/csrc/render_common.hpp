@@ -63,7 +63,8 @@ struct RenderParams {
   int64_t pos0;             // samples of each stream consumed before this call
   int32_t total;            // samples to process in this call
   int32_t frame_size;
-  int32_t n_streams;
+  int32_t n_streams;        // streams of the batch (the per-stream arrays' extent)
+  int32_t stream0, n_launch;  // the streams this launch renders: workgroup i takes stream stream0 + i
   int32_t n_feeds;
   int32_t out_ch;
   int32_t out_format;

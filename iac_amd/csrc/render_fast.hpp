@@ -223,7 +223,7 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
   float *mat2 = misc + 16;              // [OC][kFIn2]  second element's matrix rows (IN2 only; aliases fir)
   float *fir = misc + 16;               // [kFirLdsFloats]  HRTF staging (FIR variant only)
 
-  const int s = blockIdx.x;
+  const int s = blockIdx.x + p.stream0;   // a launch covers streams [stream0, stream0 + n_launch) of the batch
   const bool act = FIR != 1 || threadIdx.x < 256;
   const int t = FIR == 1 ? (int)(threadIdx.x & 255) : (int)threadIdx.x;  // helper waves keep indices in range
   const int wave = t >> 6;

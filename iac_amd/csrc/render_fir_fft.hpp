@@ -413,18 +413,19 @@ __device__ __forceinline__ void fft_wave_sync() {   // LDS accesses of one wave 
 }
 
 // The 16 runs of channel pair `pr` -> z (re = channel 2 pr, im = channel 2 pr + 1 or zeros).  Lane n1 < 16 of (ra_lo,
-// ra_hi, rcs) holds run n1's address for channel 0 and its channel stride in bytes (fir_stage_fft); v_readlane brings them
-// to scalar registers where they are used, so every load is (scalar base) + 4 lane and the 16 runs cost three vector
-// registers instead of 48 scalar ones.
+// ra_hi) holds run n1's address for channel 0 (fir_stage_fft); v_readlane brings it to scalar registers where it is used,
+// so every load is (scalar base) + 4 lane and the 16 runs cost two vector registers instead of 32 scalar ones; which runs
+// are history / zeros is one bit each of two scalar masks.
 template <int M>
-__device__ __forceinline__ void fft_fetch(int pr, fft_c32 (&z)[16], unsigned ra_lo, unsigned ra_hi, unsigned rcs,
-                                          uint64_t a_zero, unsigned lo) {
+__device__ __forceinline__ void fft_fetch(int pr, fft_c32 (&z)[16], unsigned ra_lo, unsigned ra_hi, unsigned zmask,
+                                          unsigned hmask, unsigned cs_in, uint64_t a_zero, unsigned lo) {
   const int a = 2 * pr, b = 2 * pr + 1;
 #pragma unroll
   for (int n1 = 0; n1 < 16; ++n1) {
     const uint64_t r0 = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)ra_hi, n1) << 32) |
                         (unsigned)__builtin_amdgcn_readlane((int)ra_lo, n1);
-    const uint64_t cs = (unsigned)__builtin_amdgcn_readlane((int)rcs, n1);
+    // channel stride of the run in bytes: the frame size in the call's input, 256 samples in the history, 0 in the zeros
+    const uint64_t cs = ((zmask >> n1) & 1u) ? 0u : (((hmask >> n1) & 1u) ? 4u * kFirHist : cs_in);
     // (addresses built from integers: say that they are GLOBAL ones, or the loads become flat loads)
     typedef const float __attribute__((address_space(1))) *gptr;
     const gptr sa = (gptr)(r0 + (uint64_t)a * cs);
@@ -465,7 +466,7 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
   // straddles a frame.  Run n1 of channel c starts at  base + c * cstride  with base / cstride = a place in the call's
   // input / the frame size, in the history / 256, or — past the end of the call — a block of zeros / 0.  LANE n1 works
   // that out for run n1 (one division per hop, in parallel) and keeps it; fft_fetch reads it across with v_readlane.
-  unsigned ra_lo, ra_hi, rcs;
+  unsigned ra_lo, ra_hi, zmask, hmask;
   const uint64_t a_zero = reinterpret_cast<uint64_t>(p.fir_zero);
   {
     const int fs = p.frame_size;
@@ -484,54 +485,62 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
     }
     ra_lo = (unsigned)ad;
     ra_hi = (unsigned)(ad >> 32);
-    rcs = cs;
+    // bit n1: run n1 is history / lies past the end of the call (the 16 flags of lanes 0 .. 15, wave-uniform)
+    hmask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(__ballot(n < 0) & 0xffffu));
+    zmask = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(__ballot(n >= 0 && n >= p.total) & 0xffffu));
+    (void)cs;
   }
+  const unsigned cs_in = 4u * (unsigned)p.frame_size;
   const unsigned lo = (unsigned)lane;
-#define FFT_FETCH(pr, z) fft_fetch<M>(pr, z, ra_lo, ra_hi, rcs, a_zero, lo)
+#define FFT_FETCH(pr, z) fft_fetch<M>(pr, z, ra_lo, ra_hi, zmask, hmask, cs_in, a_zero, lo)
   fft_c32 u[16], v[16], z[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) u[r] = v[r] = fft_mk(0.f, 0.f);
   const float4 *pq = reinterpret_cast<const float4 *>(p.fir_pq);   // uniform base; the lane's share is added per load
-  FFT_FETCH(0, z);
-#pragma unroll 1
-  for (int pr = 0; pr < kPairs; ++pr) {
-    // In flight during this pair's transform: the next pair's samples (the last iteration re-reads its own pair and
-    // drops it: no branch, no selects) and the first HALF of this pair's spectra table (8 x 16 bytes per lane, from L2).
-    // The second half is fetched into the same registers as the first is consumed.  [Fetched where they are used, the
-    // table reads cost a full L2 round trip per pair with nothing to overlap it: the stage ran at a fifth of its
-    // instruction rate.]
-    fft_c32 zn[16];
+  fft_c32 zb[16];
+  // one pair: transform za (already fetched), accumulate; the next pair's samples go to zb meanwhile
+  auto pair_step = [&](int pr, fft_c32 (&za)[16], fft_c32 (&zn)[16]) {
+    // In flight during this pair's transform: the next pair's samples (the last pair re-reads itself and drops it: no
+    // branch, no selects) and the first HALF of this pair's spectra table (8 x 16 bytes per lane, from L2).  The second
+    // half is fetched into the same registers as the first is consumed.  [Fetched where they are used, the table reads
+    // cost a full L2 round trip per pair with nothing to overlap it: the stage ran at a fifth of its instruction rate.]
     FFT_FETCH(pr + 1 < kPairs ? pr + 1 : pr, zn);
     const float4 *tq = pq + pr * 16 * 64;
     float4 c[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) c[r] = (tq + r * 64)[lo];
     fft_pin();   // both prefetches are issued here, ahead of the transform, and stay here
-    fft_fwd_a_tab(z, tw.tw1);
-    fft_x1_write(z, lane, S);
+    fft_fwd_a_tab(za, tw.tw1);
+    fft_x1_write(za, lane, S);
     fft_wave_sync();
-    fft_x1_read(z, lane, S);
-    fft_fwd_b_tab(z, tw.tw2);
+    fft_x1_read(za, lane, S);
+    fft_fwd_b_tab(za, tw.tw2);
     fft_wave_sync();
-    fft_x2_write(z, lane, S);
+    fft_x2_write(za, lane, S);
     fft_wave_sync();
-    fft_x2_read(z, lane, S);
+    fft_x2_read(za, lane, S);
     fft_wave_sync();
-    fft_fwd_c(z);
+    fft_fwd_c(za);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      u[r] = fft_cmac(u[r], z[r], fft_mk(c[r].x, c[r].y));
-      v[r] = fft_cmac(v[r], z[r], fft_mk(c[r].z, c[r].w));
+      u[r] = fft_cmac(u[r], za[r], fft_mk(c[r].x, c[r].y));
+      v[r] = fft_cmac(v[r], za[r], fft_mk(c[r].z, c[r].w));
       c[r] = (tq + (8 + r) * 64)[lo];
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      u[8 + r] = fft_cmac(u[8 + r], z[8 + r], fft_mk(c[r].x, c[r].y));
-      v[8 + r] = fft_cmac(v[8 + r], z[8 + r], fft_mk(c[r].z, c[r].w));
+      u[8 + r] = fft_cmac(u[8 + r], za[8 + r], fft_mk(c[r].x, c[r].y));
+      v[8 + r] = fft_cmac(v[8 + r], za[8 + r], fft_mk(c[r].z, c[r].w));
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = zn[r];
+  };
+  FFT_FETCH(0, z);
+  // two pairs per trip, the sample registers alternating: no copies between pairs
+#pragma unroll 1
+  for (int pr = 0; pr + 1 < kPairs; pr += 2) {
+    pair_step(pr, z, zb);
+    pair_step(pr + 1, zb, z);
   }
+  if constexpr (kPairs & 1) pair_step(kPairs - 1, z, zb);
   fft_mirror_write(v, lane, S);
   fft_wave_sync();
   fft_mirror_read_add(u, lane, S);

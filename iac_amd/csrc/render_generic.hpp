@@ -18,7 +18,7 @@ __global__ __launch_bounds__(kChunk) void render_kernel(const RenderParams p) {
   float *st = head + kHead;                   // [4]      limiter state exchange
   float *dmx_ch = st + 4;                     // [kChCount][kChunk] per-thread channel file (down-mixer only)
 
-  const int s = blockIdx.x;
+  const int s = blockIdx.x + p.stream0;   // a launch covers streams [stream0, stream0 + n_launch) of the batch
   const int t = threadIdx.x;
   const int fs = p.frame_size;
   const float thr = p.thr;

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
   float *mat = head + kWWin;              // [M][C4]     weights, input-major (VALU variant)
   float *misc = mat + C4 * M;             // [16]
 
-  const int s = blockIdx.x;
+  const int s = blockIdx.x + p.stream0;   // a launch covers streams [stream0, stream0 + n_launch) of the batch
   const int t = threadIdx.x;
   const int wave = t >> 6;
   const int lane = t & 63;

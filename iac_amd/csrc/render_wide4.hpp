@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
   uint4 *stage = reinterpret_cast<uint4 *>(arr_p);  // [4 waves][LR][S] packed PCM, over arr_p (see wide4_stage_lanes)
   static_assert(wide4_lds_floats(C, M, kExtra) <= wide4_budget_floats(C, kExtra), "LDS per workgroup");
 
-  const int s = blockIdx.x;
+  const int s = blockIdx.x + p.stream0;   // a launch covers streams [stream0, stream0 + n_launch) of the batch
   const int t = threadIdx.x;
   const int wave = t >> 6;
   const int lane = t & 63;

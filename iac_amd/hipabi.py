@@ -117,6 +117,8 @@ def lib():
                                             C.c_void_p, C.c_int64, C.c_void_p]
         L.iamf_hip_batch_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.iamf_hip_batch_reset.argtypes = [C.c_void_p]
+        L.iamf_hip_batch_render_range.argtypes = [C.c_void_p, C.POINTER(RenderArgs), C.c_int32, C.c_int32]
+        L.iamf_hip_batch_flush_range.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32]
         L.iamf_hip_format_bytes.argtypes = [C.c_int]
         L.iamf_hip_version.restype = C.c_char_p
         L.iamf_hip_batch_render_ex.argtypes = [C.c_void_p, C.POINTER(RenderArgs)]
@@ -241,6 +243,18 @@ class Batch:
         r = lib().iamf_hip_batch_render_ex(self.h, C.byref(args))
         if r < 0:
             raise IamfHipError(r, "iamf_hip_batch_render_ex")
+        return r
+
+    def render_range(self, args, stream0, n_streams):
+        r = lib().iamf_hip_batch_render_range(self.h, C.byref(args), stream0, n_streams)
+        if r < 0:
+            raise IamfHipError(r, "iamf_hip_batch_render_range")
+        return r
+
+    def flush_range(self, d_pcm, pcm_stream_stride_bytes, stream, stream0, n_streams):
+        r = lib().iamf_hip_batch_flush_range(self.h, d_pcm, pcm_stream_stride_bytes, stream, stream0, n_streams)
+        if r < 0:
+            raise IamfHipError(r, "iamf_hip_batch_flush_range")
         return r
 
     def set_second_element(self, matrix, gains=None):

@@ -286,6 +286,18 @@ typedef struct {
 /* Extended form of iamf_hip_batch_render; same return value. */
 int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *args);
 
+/* The same for the streams [stream0, stream0 + n_streams) of the batch only; the others neither advance nor emit.
+ * Buffers, strides and the per-stream arrays of `args` are still indexed by the stream's number in the batch.  The
+ * streams of the range must stand at the same position (they have consumed the same number of samples) and must not
+ * have been flushed, else IAMF_HIP_ERR_INVALID_STATE; after ranges have diverged, the whole-batch calls return that too
+ * until the positions meet again.  IAMF_HIP_ERR_UNIMPLEMENTED for a proper sub-range of a batch of kind FIR or with
+ * lfe_hoa (state that is kept per batch).  This is what lets a set of decoder handles that do NOT advance in step —
+ * a frame trimmed in one stream, a temporal unit still incomplete in another, one stream ending before the rest — share
+ * one batch (iamf_hip_decoder_group below); each reference handle is its own state machine, IAMF_decoder.c:3303-3525. */
+int iamf_hip_batch_render_range(iamf_hip_batch *b, const iamf_hip_render_args *args, int32_t stream0, int32_t n_streams);
+int iamf_hip_batch_flush_range(iamf_hip_batch *b, void *d_pcm, int64_t pcm_stream_stride_bytes, void *stream,
+                               int32_t stream0, int32_t n_streams);
+
 /* End of stream: pushes 240 zero samples through each stream's limiter and emits the withheld
  * tail (iamf_delay_buffer_handle, IAMF_decoder.c:3250-3301).  Returns sample-frames per stream. */
 int iamf_hip_batch_flush(iamf_hip_batch *b, void *d_pcm, int64_t pcm_stream_stride_bytes,
