@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -237,6 +238,10 @@ struct IAMF_Decoder {
   int pcm_stride, pcm_extra; /* channels per PCM sample-frame; surplus elements past the last frame (TV, > 12 ch) */
   int tv;           /* behaves as the reference built -DSAMSUNG_TV (iamf_hip_decoder_set_variant) */
   int lfe_hoa;      /* HOA LFE generator on: the reference built -DDISABLE_LFE_HOA=0 (ae_rdr.h:63-65) */
+  struct iamf_hip_decoder_group *group; /* the handle renders through a group's batch (iamf_decoder_group.inc) */
+  iamf_hip_batch_config cfg_sig;        /* what setup_pipeline created the batch from (mat pointer zeroed) ... */
+  const float *cfg_mat;                 /* ... and its matrix */
+  iamf_hip_demix_config dc_sig;         /* the demixer configuration, if use_demix */
   int started;      /* a configure call with data has been made: status left INIT */
   int need_reconf;  /* a new IA sequence header was met while decoding: status RECONFIGURE */
 };
@@ -871,6 +876,7 @@ static void reset_descriptors(struct IAMF_Decoder *d) {
 
 int IAMF_decoder_close(IAMF_DecoderHandle d) {
   if (!d) return IAMF_ERR_BAD_ARG;
+  if (d->group) return IAMF_ERR_INVALID_STATE; /* destroy the group first: it renders for this handle */
   free_runtime(d);
   for (int i = 0; i < d->nparam; ++i) free(d->param[i].rq);
   free(d);
@@ -1022,6 +1028,10 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   }
   if (!iamf_hip_format_bytes(cfg.out_format)) return IAMF_ERR_BAD_ARG; /* bit depth never set: IAMF_decoder.c:3726 */
   if (iamf_hip_batch_create(&cfg, &d->batch)) return IAMF_ERR_INTERNAL;
+  d->cfg_sig = cfg; /* a group of handles is formed from handles whose batches were created alike */
+  d->cfg_mat = cfg.matrix.mat;
+  d->cfg_sig.matrix.mat = 0;
+  memset(&d->dc_sig, 0, sizeof(d->dc_sig));
   if (d->sel_el[0]->amb_projection &&
       iamf_hip_batch_set_projection(d->batch, d->sel_el[0]->proj, element_in_channels(d->sel_el[0])))
     return IAMF_ERR_INTERNAL;
@@ -1058,6 +1068,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
     memset(d->layer_rec_flags, 0, sizeof(d->layer_rec_flags));
     dc.frame_offset = 0; /* LPCM has no decoder delay: demixer_set_frame_offset(0), IAMF_decoder.c:2175-2183 */
     if (iamf_hip_batch_set_demixer(d->batch, &dc)) return IAMF_ERR_INTERNAL;
+    d->dc_sig = dc;
     iamf_hip_demix_state_init(&d->dmst);
     if (e0->has_demix) iamf_hip_demix_set_info(&d->dmst, e0->demix_default_mode, e0->demix_default_w);
     d->dmx_mode = -1;
@@ -1132,6 +1143,7 @@ int IAMF_decoder_configure(IAMF_DecoderHandle d, const uint8_t *data, uint32_t s
   uint32_t pos = 0;
   int saw_data = 0, rc;
   if (!d) return IAMF_ERR_BAD_ARG;
+  if (d->group) return IAMF_ERR_INVALID_STATE;
   if (rsize) *rsize = 0;
   if (data && size > 0) {
     /* status RECEIVE (a configuration completed) or RECONFIGURE (decode met a new sequence header) ->
@@ -1383,13 +1395,12 @@ static int flush_tail(struct IAMF_Decoder *d, void *pcm) { /* iamf_delay_buffer_
   return n;
 }
 
-int IAMF_decoder_decode(IAMF_DecoderHandle d, const uint8_t *data, int32_t size, uint32_t *rsize, void *pcm) {
+/* iamf_decoder_internal_parse_OBUs (IAMF_decoder.c:2871-2995): consumes OBUs until a temporal unit is complete
+ * (*ready = 1, *rsize = bytes consumed) or the data ends (returns 0) or something is wrong (returns the error) */
+static int decode_parse(struct IAMF_Decoder *d, const uint8_t *data, int32_t size, uint32_t *rsize, int *ready) {
   uint32_t pos = 0;
-  if (!d || !pcm) return IAMF_ERR_BAD_ARG;
-  if (rsize) *rsize = 0;
-  if (!d->configured || d->need_reconf) return IAMF_ERR_INVALID_STATE; /* status != RECEIVE, :3941-3942 */
-  if (!data || size <= 0) return flush_tail(d, pcm); /* IAMF_decoder.c:3508-3519 */
-  while (pos < (uint32_t)size) { /* iamf_decoder_internal_parse_OBUs, IAMF_decoder.c:2871-2995 */
+  *ready = 0;
+  while (pos < (uint32_t)size) {
     Obu o;
     uint32_t n = obu_split(data + pos, (uint32_t)size - pos, &o);
     if (!n) break;
@@ -1422,12 +1433,25 @@ int IAMF_decoder_decode(IAMF_DecoderHandle d, const uint8_t *data, int32_t size,
           }
       if (tu_complete(d)) {
         if (rsize) *rsize = pos;
-        return render_tu(d, pcm);
+        *ready = 1;
+        return 0;
       }
     }
   }
   if (rsize) *rsize = pos;
   return 0;
+}
+
+int IAMF_decoder_decode(IAMF_DecoderHandle d, const uint8_t *data, int32_t size, uint32_t *rsize, void *pcm) {
+  int ready = 0, rc;
+  if (!d || !pcm) return IAMF_ERR_BAD_ARG;
+  if (rsize) *rsize = 0;
+  if (d->group) return IAMF_ERR_INVALID_STATE; /* a grouped handle decodes through iamf_hip_decoder_group_decode */
+  if (!d->configured || d->need_reconf) return IAMF_ERR_INVALID_STATE; /* status != RECEIVE, :3941-3942 */
+  if (!data || size <= 0) return flush_tail(d, pcm); /* IAMF_decoder.c:3508-3519 */
+  rc = decode_parse(d, data, size, rsize, &ready);
+  if (rc || !ready) return rc;
+  return render_tu(d, pcm);
 }
 
 /* extension (include/iamf_hip.h): the run-time form of the reference's DISABLE_LFE_HOA build switch */
@@ -1548,3 +1572,7 @@ int IAMF_decoder_get_last_metadata(IAMF_DecoderHandle d, int64_t *pts, IAMF_extr
   }
   return IAMF_OK;
 }
+
+#ifndef IAMF_FACADE_NO_GROUP
+#include "iamf_decoder_group.inc"
+#endif

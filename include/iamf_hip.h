@@ -372,6 +372,28 @@ int iamf_hip_decoder_set_hoa_lfe(void *decoder_handle, int enable);
  * the environment has IAMF_HIP_SAMSUNG_TV=1 when the handle is opened. */
 int iamf_hip_decoder_set_variant(void *decoder_handle, int variant);
 
+/* ------------------------------------------------------------------------------------------
+ * A group of decoder handles: callers of the reference API get the batch renderer's throughput.
+ * The reference renders one handle, one frame per call (IAMF_decoder_decode, include/IAMF_decoder.h:82-99, driver loop
+ * src/iamf_dec/IAMF_decoder.c:3303-3525).  N configured handles (IAMF_DecoderHandle of this library's IAMF_decoder.h) of ONE
+ * topology — same codec configuration, elements, output layout, bit depth and limiter settings; their mix gains,
+ * loudness and parameter streams may differ — that have not decoded yet hand their rendering to one batch:
+ *     iamf_hip_decoder_group_decode(g, data, sizes, rsizes, pcm, results)
+ * is, for every i, exactly  results[i] = IAMF_decoder_decode(handles[i], data[i], sizes[i], &rsizes[i], pcm[i])
+ * (data[i] == NULL flushes handle i; rsizes may be NULL): parsing, LPCM unpacking and the parameter timelines run per
+ * handle on `host_threads` threads (0 = up to 16), then ONE upload, one render launch over the streams that completed a
+ * temporal unit, one download.  The handles need not advance in step.  While grouped, a handle refuses
+ * IAMF_decoder_decode / _configure / _close with IAMF_ERR_INVALID_STATE; destroying the group releases the handles
+ * (which are then closed with IAMF_decoder_close as usual).  Returns IAMF_OK, or for create: IAMF_ERR_BAD_ARG (handles
+ * of different topologies), IAMF_ERR_INVALID_STATE (not configured / already decoding), IAMF_ERR_UNIMPLEMENTED (handles
+ * that resample, or the HOA LFE generator).  The group's own return value reports device failures only.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct iamf_hip_decoder_group iamf_hip_decoder_group;
+int iamf_hip_decoder_group_create(void *const *handles, int n, int host_threads, iamf_hip_decoder_group **out);
+int iamf_hip_decoder_group_decode(iamf_hip_decoder_group *g, const uint8_t *const *data, const int32_t *sizes,
+                                  uint32_t *rsizes, void *const *pcm, int32_t *results);
+void iamf_hip_decoder_group_destroy(iamf_hip_decoder_group *g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@ hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)calloc(1, 8); ret
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { (void)s; return hipSuccess; }
 
-struct iamf_hip_batch { iamf_hip_batch_config cfg; int pad_left; };
+struct iamf_hip_batch { iamf_hip_batch_config cfg; int *pad_left; /* per stream: limiter delay still to withhold */ };
 struct iamf_hip_resampler { int ch, in, out; };
 
 static const int k_ch[] = {2, 6, 8, 10, 11, 12, 14, 24, 8, 12};
@@ -68,13 +68,17 @@ int iamf_hip_get_m2m_matrix_variant(int v, int in_id, int out_id, iamf_hip_matri
 int iamf_hip_format_bytes(int f) { return f == 16 ? 2 : f == 24 ? 3 : (f == 32 || f == -32) ? 4 : 0; }
 
 int iamf_hip_batch_create(const iamf_hip_batch_config *c, iamf_hip_batch **out) {
-  if (c->frame_size <= 0 || c->out_channels <= 0 || c->out_channels > 24) return IAMF_HIP_ERR_BAD_ARG;
+  if (c->frame_size <= 0 || c->out_channels <= 0 || c->out_channels > 24 || c->n_streams <= 0) return IAMF_HIP_ERR_BAD_ARG;
   *out = (iamf_hip_batch *)calloc(1, sizeof(**out));
   (*out)->cfg = *c;
-  (*out)->pad_left = c->limiter_enable ? 240 : 0;
+  (*out)->pad_left = (int *)calloc((size_t)c->n_streams, sizeof(int));
+  for (int s = 0; s < c->n_streams; ++s) (*out)->pad_left[s] = c->limiter_enable ? 240 : 0;
   return 0;
 }
-void iamf_hip_batch_destroy(iamf_hip_batch *b) { free(b); }
+void iamf_hip_batch_destroy(iamf_hip_batch *b) {
+  if (b) free(b->pad_left);
+  free(b);
+}
 int iamf_hip_batch_set_gains(iamf_hip_batch *b, const float *a, const float *c, const float *d) {
   (void)b; (void)a; (void)c; (void)d; return 0;
 }
@@ -83,35 +87,53 @@ int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *
 }
 int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *p, int l) { (void)b; (void)p; (void)l; return 0; }
 int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *c) { (void)b; (void)c; return 0; }
-static int emit(iamf_hip_batch *b, void *pcm, int64_t cap, int n) {
-  int skip = n < b->pad_left ? n : b->pad_left;
-  b->pad_left -= skip;
+static int emit(iamf_hip_batch *b, int s, void *pcm, int64_t cap, int n) {
+  int skip = n < b->pad_left[s] ? n : b->pad_left[s];
+  b->pad_left[s] -= skip;
   n -= skip;
   const int sc = b->cfg.pcm_stride_channels > 0 ? b->cfg.pcm_stride_channels : b->cfg.out_channels;
   int64_t need = ((int64_t)n * sc + (n > 0 && b->cfg.out_channels > sc ? b->cfg.out_channels - sc : 0)) *
                  iamf_hip_format_bytes(b->cfg.out_format);
   if (need > cap) return IAMF_HIP_ERR_BAD_ARG;
-  memset(pcm, 0, (size_t)need); /* a real write: ASan checks the "device" buffer the facade sized */
+  memset((char *)pcm + (int64_t)s * cap, 0, (size_t)need); /* a real write: ASan checks the "device" buffer the facade sized */
   return n;
 }
 int iamf_hip_batch_render(iamf_hip_batch *b, const float *in, int64_t ss, int64_t fs, int32_t nf, void *pcm,
                           int64_t cap, void *st) {
   (void)in; (void)ss; (void)fs; (void)st;
-  return emit(b, pcm, cap, nf * b->cfg.frame_size);
+  int r = 0;
+  for (int s = 0; s < b->cfg.n_streams; ++s) r = emit(b, s, pcm, cap, nf * b->cfg.frame_size);
+  return r;
+}
+int iamf_hip_batch_render_range(iamf_hip_batch *b, const iamf_hip_render_args *a, int32_t s0, int32_t cnt) {
+  int n = a->n_samples ? a->n_samples : a->n_frames * b->cfg.frame_size, r = 0;
+  if (s0 < 0 || cnt <= 0 || s0 + cnt > b->cfg.n_streams) return IAMF_HIP_ERR_BAD_ARG;
+  for (int s = s0; s < s0 + cnt; ++s) {
+    const volatile float *in = (const volatile float *)a->d_in + (int64_t)s * a->in_stream_stride; /* touch what a kernel would read */
+    float acc = 0;
+    for (int64_t i = 0; i < (int64_t)b->cfg.matrix.m * b->cfg.frame_size && b->cfg.matrix.kind != IAMF_HIP_KIND_DMX; ++i) acc += in[i];
+    (void)acc;
+    if (a->d_element_ramp) acc += ((const volatile float *)a->d_element_ramp)[(int64_t)s * a->ramp_stream_stride + n - 1];
+    r = emit(b, s, a->d_pcm, a->pcm_stream_stride_bytes, n);
+    if (r < 0) return r;
+  }
+  return r;
 }
 int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *a) {
-  int n = a->n_samples ? a->n_samples : a->n_frames * b->cfg.frame_size;
-  const volatile float *in = (const volatile float *)a->d_in; /* touch what a kernel would read */
-  float acc = 0;
-  for (int64_t i = 0; i < (int64_t)b->cfg.matrix.m * b->cfg.frame_size && b->cfg.matrix.kind != IAMF_HIP_KIND_DMX; ++i) acc += in[i];
-  (void)acc;
-  return emit(b, a->d_pcm, a->pcm_stream_stride_bytes, n);
+  return iamf_hip_batch_render_range(b, a, 0, b->cfg.n_streams);
+}
+int iamf_hip_batch_flush_range(iamf_hip_batch *b, void *pcm, int64_t cap, void *st, int32_t s0, int32_t cnt) {
+  (void)st;
+  int r = 0;
+  for (int s = s0; s < s0 + cnt; ++s) {
+    int n = b->cfg.limiter_enable ? 240 - b->pad_left[s] : 0;
+    b->pad_left[s] = 0;
+    r = emit(b, s, pcm, cap, n);
+  }
+  return r;
 }
 int iamf_hip_batch_flush(iamf_hip_batch *b, void *pcm, int64_t cap, void *st) {
-  (void)st;
-  int n = b->cfg.limiter_enable ? 240 - b->pad_left : 0;
-  b->pad_left = 0;
-  return emit(b, pcm, cap, n);
+  return iamf_hip_batch_flush_range(b, pcm, cap, st, 0, b->cfg.n_streams);
 }
 int iamf_hip_resampler_create(int ns, int ch, int in, int out, iamf_hip_resampler **r) {
   (void)ns;

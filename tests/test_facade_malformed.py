@@ -155,3 +155,55 @@ def test_two_concatenated_sequences_reconfigure_cleanly(driver, tmp_path):
     # sequence 1: 3 frames minus the limiter's 240-sample delay (its tail is lost at the reconfiguration,
     # as in the reference); sequence 2: both frames of the new size, delay re-emitted by the final flush
     assert out[-1] == "total %d configs 2" % (3 * FS - min(240, 3 * FS) + 2 * 2 * FS)
+
+
+# ---- the group of handles (iamf_decoder_group.inc) under the same sanitizers ----
+GBIN = os.path.join(STUB, "build", "group_driver")
+
+
+@pytest.fixture(scope="module")
+def group_driver():
+    os.makedirs(os.path.join(STUB, "build"), exist_ok=True)
+    srcs = [os.path.join(ROOT, "iac_amd", "csrc", "iamf_decoder_facade.c"), os.path.join(ROOT, "iac_amd", "csrc", "iamf_decoder_group.inc"),
+            os.path.join(STUB, "device_stub.c"), os.path.join(STUB, "group_driver.c")]
+    if not os.path.exists(GBIN) or any(os.path.getmtime(x) > os.path.getmtime(GBIN) for x in srcs):
+        subprocess.check_call(["gcc", "-g", "-O1", "-std=gnu11", "-fsanitize=address,undefined",
+                               "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+                               "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include"] +
+                              [x for x in srcs if x.endswith(".c")] + ["-lm", "-lpthread", "-o", GBIN])
+    return GBIN
+
+
+def run_group(gdriver, tmp_path, stream, n, threads, layout="0", bits=16):
+    p = os.path.join(str(tmp_path), "g.iamf")
+    open(p, "wb").write(stream)
+    r = subprocess.run([gdriver, p, layout, str(bits), str(n), str(threads)], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    return r.stdout.strip().splitlines()
+
+
+@pytest.mark.parametrize("n,threads", [(1, 1), (5, 3), (13, 0)])
+def test_group_of_handles_out_of_step_matches_the_single_handle_totals(driver, group_driver, tmp_path, n, threads):
+    """N handles on one stream, starved in different rounds and finishing at different times: every handle must emit
+    what a handle alone emits (here: the sample count; the PCM itself is checked on the GPU, tests/test_gpu_group.py)"""
+    frames = [stereo_frame(seed=1), stereo_frame(trim=(3, 0), seed=2), stereo_frame(seed=3), stereo_frame(trim=(0, 5), seed=4),
+              stereo_frame(seed=5), stereo_frame(trim=(FS, 0), seed=6), stereo_frame(seed=7)]
+    s = descriptors() + b"".join(frames)
+    single = run(driver, tmp_path, s)
+    want = int(single[-1].split()[1])
+    out = run_group(group_driver, tmp_path, s, n, threads)
+    assert "group_create 0" in out
+    # a grouped handle refuses IAMF_decoder_decode / _close (IAMF_ERR_INVALID_STATE = -5)
+    assert "single_decode_while_grouped -5 close -5" in out
+    totals = [int(l.split()[2]) for l in out if l.startswith("total h")]
+    assert totals == [want] * n, (totals, want)
+
+
+def test_group_with_a_hostile_trim_goes_on_like_the_single_handle(driver, group_driver, tmp_path):
+    s = descriptors() + stereo_frame(seed=1) + stereo_frame(trim=(1 << 40, 0), seed=2) + stereo_frame(seed=3)
+    want = int(run(driver, tmp_path, s)[-1].split()[1])
+    out = run_group(group_driver, tmp_path, s, 4, 2)
+    assert [int(l.split()[2]) for l in out if l.startswith("total h")] == [want] * 4
+    assert "decode -1 rsize" in "\n".join(out)   # handle 0 reported IAMF_ERR_BAD_ARG for that unit
