@@ -105,6 +105,28 @@ def measured_traffic(kernel_tag, sf_per_step, workload=None):
     return best
 
 
+def cpu_share():
+    """(threads to use, how that was decided): the cores this process may run on, capped by the container's CPU quota
+    (cgroup v2 cpu.max / v1 cfs quota) when there is one.  The box's nproc is reported beside it."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None and quota < aff:
+        return max(1, int(round(quota))), "cgroup cpu quota %.1f of %d schedulable cores" % (quota, aff)
+    return aff, "sched_getaffinity (no cgroup cpu quota)"
+
+
 def cpu_baseline(workload, fs, seconds_target=12.0):
     """The oracle (oracle/liboracle.so: scalar C port of the reference loops) timed on this box's
     host cores on a bounded sample of the same workload: one stream per thread."""
@@ -128,13 +150,13 @@ def cpu_baseline(workload, fs, seconds_target=12.0):
     n1 = one_stream(0)
     t1 = time.perf_counter() - t0
     single = n1 / t1 / 1e6
-    cores = len(os.sched_getaffinity(0))   # every core this process may run on; the box's nproc is in the line too
-    reps = max(1, min(int(seconds_target / max(t1, 1e-4)), 4096))   # ~seconds_target of wall time on `cores` threads
+    cores, cores_basis = cpu_share()
+    reps = max(1, min(int(seconds_target / max(t1, 1e-4)), 256))   # ~seconds_target of wall time on `cores` threads
     t0 = time.perf_counter()
     with cf.ThreadPoolExecutor(cores) as ex:   # ctypes drops the GIL for the whole C call
         total = sum(ex.map(one_stream, range(cores * reps)))
     tm = time.perf_counter() - t0
-    return {"value": round(total / tm / 1e6, 3), "unit": "Msamples/s", "cores": cores, "nproc": os.cpu_count(), "kind": "port",
+    return {"value": round(total / tm / 1e6, 3), "unit": "Msamples/s", "cores": cores, "cores_basis": cores_basis, "nproc": os.cpu_count(), "kind": "port",
             "single_core_value": round(single, 3),
             "sample": "%d streams x %d frames x %d samples of %s through oracle/ (scalar C port of "
                       "the reference loops), one stream per thread" % (cores * reps, frames, fs, workload)}
@@ -191,14 +213,14 @@ def reference_baseline(workload, fs, seconds_target=12.0):
         if n1 <= 0:
             return None
         single = n1 / t1 / 1e6
-        cores = len(os.sched_getaffinity(0))
-        reps = max(1, min(int(seconds_target / max(t1, 1e-4)), 4096))   # ~seconds_target of wall time
+        cores, cores_basis = cpu_share()
+        reps = max(1, min(int(seconds_target / max(t1, 1e-4)), 256))   # ~seconds_target of wall time
         t0 = time.perf_counter()
         with cf.ThreadPoolExecutor(cores) as ex:   # ctypes drops the GIL for the whole C call
             res = list(ex.map(one_stream, range(cores * reps)))
         tm = time.perf_counter() - t0
         total = sum(r[0] for r in res)
-        return {"value": round(total / tm / 1e6, 3), "unit": "Msamples/s", "cores": cores, "nproc": os.cpu_count(),
+        return {"value": round(total / tm / 1e6, 3), "unit": "Msamples/s", "cores": cores, "cores_basis": cores_basis, "nproc": os.cpu_count(),
                 "kind": "reference", "single_core_value": round(single, 3),
                 "sample": "%d decoder handles x %d frames x %d samples of %s through IAMF_decoder_decode of the "
                           "reference itself (oracle/_ref/libiamf_ref.so: LPCM .iamf stream -> PCM), one handle per "
@@ -206,6 +228,103 @@ def reference_baseline(workload, fs, seconds_target=12.0):
     except Exception as e:   # anything missing on this box: fall back to the port
         sys.stderr.write("reference baseline unavailable (%s)\n" % e)
         return None
+
+
+def facade_rates(fs, n_group=64, frames=96):
+    """What a caller of the reference's OWN API gets (VERDICT r2 missing #1): the same synthetic LPCM .iamf stream (TOA ->
+    binaural, 16-bit) decoded (a) by one IAMF_DecoderHandle, one IAMF_decoder_decode per temporal unit, and (b) by a group
+    of `n_group` handles, one iamf_hip_decoder_group_decode per round of temporal units (include/iamf_hip.h).  Host OBU
+    parsing, LPCM unpacking, the uploads and the download are all inside: PCIe-inclusive rates, never `value`."""
+    import ctypes as C
+
+    import iamf_writer as W
+    import synth
+    import iac_amd
+    L = C.CDLL(iac_amd.lib_path())
+    L.IAMF_decoder_open.restype = C.c_void_p
+    L.IAMF_decoder_close.argtypes = [C.c_void_p]
+    L.IAMF_decoder_configure.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.IAMF_decoder_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_uint32), C.c_void_p]
+    L.IAMF_decoder_output_layout_set_binaural.argtypes = [C.c_void_p]
+    L.IAMF_decoder_set_bit_depth.argtypes = [C.c_void_p, C.c_uint32]
+    L.iamf_hip_decoder_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.iamf_hip_decoder_group_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.iamf_hip_decoder_group_destroy.argtypes = [C.c_void_p]
+    L.iamf_hip_decoder_group_destroy.restype = None
+    in_ch = 16
+    x = W.quantize(np.clip(synth.hot(4242, in_ch, frames * fs), -1, 1 - 2 ** -15).astype(np.float32), 16)
+    pd = lambda pid: W.param_definition(pid, 48000, mode=1)
+    stream = W.sequence_header(1) + W.codec_config_lpcm(0, fs, 16, 48000)
+    stream += W.audio_element_ambisonics_mono(1, 0, in_ch, list(range(in_ch)))
+    stream += W.mix_presentation(1, [dict(eid=1, pdef=pd(100), default_q78=0)], dict(pdef=pd(101), default_q78=0), [("binaural",)])
+    for f in range(frames):
+        stream += W.temporal_delimiter()
+        stream += W.audio_frames([(i, W.lpcm_bytes(x[i:i + 1, f * fs:(f + 1) * fs], 16)) for i in range(in_ch)])
+    buf = C.create_string_buffer(stream, len(stream))
+    base = C.addressof(buf)
+
+    def handle():
+        d = L.IAMF_decoder_open()
+        L.IAMF_decoder_set_bit_depth(d, 16)
+        L.IAMF_decoder_output_layout_set_binaural(d)
+        rs = C.c_uint32(0)
+        assert L.IAMF_decoder_configure(d, base, len(stream), C.byref(rs)) == 0
+        return d, rs.value
+
+    # (a) one handle
+    d, used = handle()
+    pcm = C.create_string_buffer(2 * 6144 * 2)
+    rs = C.c_uint32(0)
+    total, t0 = 0, time.perf_counter()
+    while used < len(stream):
+        n = L.IAMF_decoder_decode(d, base + used, len(stream) - used, C.byref(rs), pcm)
+        assert n >= 0
+        total += n
+        used += rs.value
+        if not rs.value:
+            break
+    total += max(0, L.IAMF_decoder_decode(d, None, 0, C.byref(rs), pcm))
+    t_single = time.perf_counter() - t0
+    L.IAMF_decoder_close(d)
+    single = total / t_single / 1e6
+    # (b) a group
+    hs, used0 = [], 0
+    for _ in range(n_group):
+        d, used0 = handle()
+        hs.append(d)
+    harr = (C.c_void_p * n_group)(*hs)
+    g = C.c_void_p()
+    assert L.iamf_hip_decoder_group_create(harr, n_group, 0, C.byref(g)) == 0
+    pcms = [C.create_string_buffer(2 * 6144 * 2) for _ in range(n_group)]
+    parr = (C.c_void_p * n_group)(*[C.addressof(p_) for p_ in pcms])
+    data, sizes, rsz, res = (C.c_uint64 * n_group)(), (C.c_int32 * n_group)(), (C.c_uint32 * n_group)(), (C.c_int32 * n_group)()
+    vd, vs, vr, vres = (np.frombuffer(a_, dtype=t_) for a_, t_ in ((data, np.uint64), (sizes, np.int32), (rsz, np.uint32), (res, np.int32)))
+    used = np.full(n_group, used0, dtype=np.int64)
+    total, rounds, t0 = 0, 0, time.perf_counter()
+    while int(used.min()) < len(stream):
+        vd[:] = (base + used).astype(np.uint64)
+        vs[:] = (len(stream) - used).astype(np.int32)
+        assert L.iamf_hip_decoder_group_decode(g, data, sizes, rsz, parr, res) == 0
+        assert int(vres.min()) >= 0
+        total += int(vres.sum())
+        used += vr.astype(np.int64)
+        rounds += 1
+        if int(vr.min()) == 0:
+            break
+    vd[:] = 0
+    vs[:] = 0
+    assert L.iamf_hip_decoder_group_decode(g, data, sizes, rsz, parr, res) == 0
+    total += int(np.maximum(vres, 0).sum())
+    t_group = time.perf_counter() - t0
+    L.iamf_hip_decoder_group_destroy(g)
+    for d in hs:
+        L.IAMF_decoder_close(d)
+    return {"workload": "TOA -> binaural, 16-bit LPCM .iamf, %d frames of %d samples per handle, through the reference's API"
+                        % (frames, fs),
+            "single_handle_msamples_s": round(single, 2), "single_handle_us_per_call": round(t_single / (frames + 1) * 1e6, 1),
+            "group_handles": n_group, "group_msamples_s": round(total / t_group / 1e6, 2),
+            "group_ms_per_round": round(t_group / max(rounds + 1, 1) * 1e3, 3),
+            "note": "host OBU parsing + LPCM unpack + H2D + render + D2H per call: PCIe-inclusive, never `value`"}
 
 
 SIGNALS = {"hot": "hot (sigma 0.25 + 1.5 bursts)", "quiet": "quiet (sigma 0.05)",
@@ -631,6 +750,7 @@ def parse_args(argv=None):
                     help="N>1: gather packed PCM to rank 0 over RCCL once after the last step (default, the "
                          "job's one exchange), after every step (overlapped with the next render), or never")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-facade", action="store_true", help="skip the IAMF_decoder.h facade rates (single handle / group of 64)")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the oracle check of one more launch of the timed geometry (the `verified` entry)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
@@ -886,6 +1006,13 @@ def main():
                      "h2m_proj": " [the mono-mode stream: without the de-mapping stage]",
                      "h2m_lfe": " [the default reference build: LFE generator compiled out]"}
             out["cpu_baseline"]["sample"] += notes.get(kind, "")
+            if args.workload == "toa_binaural_limiter_s16" and not args.no_facade:
+                try:
+                    fr = facade_rates(fs)
+                    fr["reference_single_core_msamples_s"] = out["cpu_baseline"].get("single_core_value")
+                    out["facade"] = fr
+                except Exception as e:   # noqa: BLE001 - a side measurement never fails the bench
+                    out["facade"] = {"error": str(e)[:200]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

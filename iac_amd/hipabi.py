@@ -146,6 +146,22 @@ def lib():
         L.iamf_hip_dmx_set_mode_weight.argtypes = [C.POINTER(DmxState), C.c_int, C.c_int]
         L.iamf_hip_dmx_coefficients.argtypes = [C.POINTER(DmxState), FP]
         L.iamf_hip_dmx_coefficients.restype = None
+        L.iamf_hip_shard_split.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.iamf_hip_shard_create.argtypes = [C.POINTER(BatchConfig), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        L.iamf_hip_shard_destroy.argtypes = [C.c_void_p]
+        L.iamf_hip_shard_destroy.restype = None
+        L.iamf_hip_shard_devices.argtypes = [C.c_void_p]
+        L.iamf_hip_shard_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.iamf_hip_shard_batch.argtypes = [C.c_void_p, C.c_int]
+        L.iamf_hip_shard_batch.restype = C.c_void_p
+        L.iamf_hip_shard_render_stream.argtypes = [C.c_void_p, C.c_int]
+        L.iamf_hip_shard_render_stream.restype = C.c_void_p
+        L.iamf_hip_shard_render.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_int32,
+                                            C.POINTER(C.c_void_p), C.c_int64]
+        L.iamf_hip_shard_flush.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int64]
+        L.iamf_hip_shard_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_int64]
+        L.iamf_hip_shard_sync.argtypes = [C.c_void_p]
+        L.iamf_hip_shard_rccl_version.restype = C.c_char_p
         _lib = L
     return _lib
 

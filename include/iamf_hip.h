@@ -373,6 +373,41 @@ int iamf_hip_decoder_set_hoa_lfe(void *decoder_handle, int enable);
 int iamf_hip_decoder_set_variant(void *decoder_handle, int variant);
 
 /* ------------------------------------------------------------------------------------------
+ * One node, several GPUs, from C (BASELINE north_star: "independent IAMF streams shard embarrassingly
+ * across the 8 GPUs of one node with RCCL over xGMI only for the final batched gather").  All state of the path is per
+ * decoder handle in the reference (IAMF_decoder_private.h:342-345, audio_effect_peak_limiter.h:48-73), so the streams
+ * of a job are split into contiguous blocks, one batch per device, no exchange while rendering.  A shard owns, per
+ * device: the batch, a HIP stream for rendering, a second one for the gather, and a host thread that issues that
+ * device's launches.  RCCL is loaded with dlopen at the first gather (the library does not link it; a host without it
+ * gets IAMF_HIP_ERR_UNIMPLEMENTED from the gather and can still render).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct iamf_hip_shard iamf_hip_shard;
+/* block of streams of device `index` of `n_devices`: sizes differ by at most one, the larger blocks first */
+int iamf_hip_shard_split(int n_streams, int n_devices, int index, int *first, int *count);
+/* cfg->n_streams = streams of the whole job; devices = n_devices distinct HIP device ordinals (NULL = 0 .. n_devices - 1) */
+int iamf_hip_shard_create(const iamf_hip_batch_config *cfg, const int *devices, int n_devices, iamf_hip_shard **out);
+void iamf_hip_shard_destroy(iamf_hip_shard *s);
+int iamf_hip_shard_devices(const iamf_hip_shard *s);
+int iamf_hip_shard_info(const iamf_hip_shard *s, int index, int *device, int *first, int *count);
+/* the batch of device `index` (for the per-stream setters: make that device current first) and its render stream */
+iamf_hip_batch *iamf_hip_shard_batch(iamf_hip_shard *s, int index);
+void *iamf_hip_shard_render_stream(iamf_hip_shard *s, int index);
+/* iamf_hip_batch_render / _flush on every device at once: d_in[i] / d_pcm[i] are device i's buffers (its block of streams,
+ * strides as for the batch).  Returns sample-frames emitted per stream.  Asynchronous on the devices' render streams. */
+int iamf_hip_shard_render(iamf_hip_shard *s, const float *const *d_in, int64_t in_stream_stride, int64_t in_frame_stride,
+                          int32_t n_frames, void *const *d_pcm, int64_t pcm_stream_stride_bytes);
+int iamf_hip_shard_flush(iamf_hip_shard *s, void *const *d_pcm, int64_t pcm_stream_stride_bytes);
+/* The job's one exchange: every device's PCM regions (pcm_stream_stride_bytes per stream) -> d_dst on device
+ * `root_index`, stream s of the job at d_dst + s * dst_stream_stride_bytes (the two strides must be equal).  ncclSend /
+ * ncclRecv in one group on the gather streams, behind the last render: it overlaps the next iamf_hip_shard_render, which
+ * in turn waits for it before overwriting the buffers it reads.  iamf_hip_shard_sync waits for everything. */
+int iamf_hip_shard_gather(iamf_hip_shard *s, int root_index, void *d_dst, int64_t dst_stream_stride_bytes,
+                          void *const *d_pcm, int64_t pcm_stream_stride_bytes);
+int iamf_hip_shard_sync(iamf_hip_shard *s);
+/* "major.minor.patch" of the RCCL found on this host, "" if none (static storage) */
+const char *iamf_hip_shard_rccl_version(void);
+
+/* ------------------------------------------------------------------------------------------
  * A group of decoder handles: callers of the reference API get the batch renderer's throughput.
  * The reference renders one handle, one frame per call (IAMF_decoder_decode, include/IAMF_decoder.h:82-99, driver loop
  * src/iamf_dec/IAMF_decoder.c:3303-3525).  N configured handles (IAMF_DecoderHandle of this library's IAMF_decoder.h) of ONE

@@ -87,6 +87,44 @@ def test_shard_streams_partitions():
         assert max(sizes) - min(sizes) <= 1
 
 
+def test_c_shard_split_is_the_python_shard_streams():
+    """iamf_hip_shard_split (C, what the multi-device entry uses) and iac_amd.sharding.shard_streams (what bench.py's ranks
+    use) must cut a job the same way; no GPU needed for either"""
+    import ctypes as C
+
+    import iac_amd as A
+    from iac_amd.sharding import shard_streams
+    L = A.lib()
+    for n, w in ((4096, 8), (10, 3), (5, 8), (512, 1), (4097, 8), (8, 8)):
+        for r in range(w):
+            f, c = C.c_int(-1), C.c_int(-1)
+            assert L.iamf_hip_shard_split(n, w, r, C.byref(f), C.byref(c)) == 0
+            lo, hi = shard_streams(n, w, r)
+            assert (f.value, f.value + c.value) == (lo, hi), (n, w, r)
+    f, c = C.c_int(), C.c_int()
+    assert L.iamf_hip_shard_split(10, 0, 0, C.byref(f), C.byref(c)) == -1
+    assert L.iamf_hip_shard_split(10, 2, 2, C.byref(f), C.byref(c)) == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="no-GPU behaviour")
+def test_shard_create_validates_and_fails_loudly_without_gpu():
+    import ctypes as C
+
+    import iac_amd as A
+    L = A.lib()
+    cfg = A.BatchConfig()
+    cfg.n_streams, cfg.frame_size, cfg.sample_rate, cfg.out_channels, cfg.out_format = 8, 1024, 48000, 2, 16
+    cfg.matrix = A.get_h2m_matrix(3, A.SS["BINAURAL"])
+    cfg.limiter_enable, cfg.limiter_threshold_db = 1, -1.0
+    h = C.c_void_p()
+    assert L.iamf_hip_shard_create(C.byref(cfg), None, 0, C.byref(h)) == -1      # no devices asked for
+    assert L.iamf_hip_shard_create(C.byref(cfg), None, 16, C.byref(h)) == -1     # more devices than streams
+    assert L.iamf_hip_shard_create(C.byref(cfg), None, 1, C.byref(h)) == -100    # IAMF_HIP_ERR_DEVICE: no GPU here
+    assert not h.value
+    assert L.iamf_hip_shard_devices(None) == 0
+    assert isinstance(L.iamf_hip_shard_rccl_version(), bytes)                   # "" or a version; loading it needs no GPU
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
