@@ -69,6 +69,7 @@ WORKLOADS = {
 }
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA, dense (155 TF measured)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / f16 MFMA, dense
+F32_VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: vector f32 (packed FMA), dense
 FIR_TAPS = 256
 
 
@@ -668,25 +669,40 @@ class Workload:
              "algorithmic_bytes_per_sample_frame": self.bytes_per_sf,
              "frac_of_measured_copy_6290": round(achieved / 6290.0, 4)}
         dtype = "f32"
-        if self.kind == "fir":   # compute-bound: price against the dense MFMA peak of the type the stage multiplies in
-            flop_sf = 2 * self.in_ch * 2 * FIR_TAPS
-            tf = flop_sf * self.sf_per_step / (kernel_ms * 1e-3) / 1e12
-            f32_stage = bool(os.environ.get("IAMF_HIP_FIR_F32"))
-            peak = F32_MFMA_PEAK_TFLOPS if f32_stage else F16_MFMA_PEAK_TFLOPS
-            r.update({"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                      "frac": round(tf / peak, 4), "algorithmic_flop_per_sample_frame": flop_sf,
-                      "hbm_gbs": round(achieved, 1)})
-            if f32_stage:
-                dtype = "f32 (f32 MFMA)"
-            else:   # render_fir16.hpp: three f16 MFMAs per block of products, 288 of 256 taps multiplied
-                issued = tf * 3 * 288 / 256
-                eff_peak = peak / 3 * 256 / 288   # what the 3-MFMA split scheme can deliver as convolution flops
-                dtype = "f32 via split f16 (hi/lo halves, three f16 MFMAs, f32 accumulate)"
-                r.update({"issued_tflops": round(issued, 1), "frac_issued": round(issued / peak, 4),
-                          "effective_peak": round(eff_peak, 1), "frac_of_effective_peak": round(tf / eff_peak, 4),
-                          "note": "power-limited: the same instruction stream on all-zero data runs 1.5x faster at 2.1 instead "
-                                  "of 1.4 GHz (profiles/r02_fir16/); effective_peak = 2.5 PF / 3 MFMAs per product block x 256/288 useful taps "
-                                  "(DESIGN.md 4.2); IAMF_HIP_FIR_F32=1 runs the f32-MFMA stage"})
+        if self.kind == "fir":
+            # Three stages, one specification (render_fir.hpp).  Default: overlap-save FFT on the VALU (render_fir_fft.hpp):
+            # ~770 flop per sample-frame -> the stage is no longer the bound by count; the kernel's bound is HBM (68 B per
+            # sample-frame, as for the matrix form).  Reported against BOTH: 8 TB/s (`frac`) and the f32 vector peak for the
+            # flops the algorithm issues (`valu`).  IAMF_HIP_FIR_F16 / _F32 select the direct-form MFMA stages (r2).
+            flop_direct = 2 * self.in_ch * 2 * FIR_TAPS
+            f32_stage, f16_stage = bool(os.environ.get("IAMF_HIP_FIR_F32")), bool(os.environ.get("IAMF_HIP_FIR_F16"))
+            rate = self.sf_per_step / (kernel_ms * 1e-3)
+            if not (f32_stage or f16_stage):
+                pairs = (self.in_ch + 1) // 2
+                n, hop = 1024, 768
+                flop_fft = (pairs + 1) * 5 * n * 10 + pairs * 2 * 8 * n      # (pairs + 1) transforms + 2 complex MACs per bin and pair
+                flop_sf = flop_fft / hop
+                tf = flop_sf * rate / 1e12
+                dtype = "f32 (overlap-save FFT on the VALU, f32 accumulate)"
+                r.update({"valu": {"achieved_tflops": round(tf, 2), "peak_tflops": F32_VALU_PEAK_TFLOPS,
+                                   "frac": round(tf / F32_VALU_PEAK_TFLOPS, 4), "flop_per_sample_frame": round(flop_sf, 1),
+                                   "note": "1024-point transforms, 768-sample hops, two channels per complex transform"},
+                          "direct_form_equivalent_tflops": round(flop_direct * rate / 1e12, 1),
+                          "direct_form_flop_per_sample_frame": flop_direct,
+                          "note": "bound = HBM (68 B per sample-frame): the FFT stage issues %.0f flop per sample-frame where the "
+                                  "direct form needs %d; measured limiter: latency at 2 waves per SIMD (DESIGN.md 4.2)" % (flop_sf, flop_direct)})
+            else:
+                tf = flop_direct * rate / 1e12
+                peak = F32_MFMA_PEAK_TFLOPS if f32_stage else F16_MFMA_PEAK_TFLOPS
+                r.update({"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                          "frac": round(tf / peak, 4), "algorithmic_flop_per_sample_frame": flop_direct,
+                          "hbm_gbs": round(achieved, 1)})
+                if f32_stage:
+                    dtype = "f32 (f32 MFMA)"
+                else:   # render_fir16.hpp: three f16 MFMAs per block of products, 288 of 256 taps multiplied
+                    issued = tf * 3 * 288 / 256
+                    dtype = "f32 via split f16 (hi/lo halves, three f16 MFMAs, f32 accumulate)"
+                    r.update({"issued_tflops": round(issued, 1), "frac_issued": round(issued / peak, 4)})
         return r, dtype
 
 
@@ -940,6 +956,12 @@ def main():
             "value_first_allocation": first_alloc["value"] if first_alloc else round(value, 2),
             "first_allocation": first_alloc or {"note": "the search kept the first allocations: value is the unsearched rate"},
         }
+        try:   # the C-side multi-device entry (include/iamf_hip.h iamf_hip_shard_*) finds its RCCL by dlopen
+            out["c_abi_shard"] = {"rccl_version": A.lib().iamf_hip_shard_rccl_version().decode() or None,
+                                  "note": "iamf_hip_shard_create / _render / _gather: one process, one batch + host thread + two "
+                                          "streams per device; exercised on one device by tests/test_gpu_shard.py"}
+        except Exception as e:   # noqa: BLE001
+            out["c_abi_shard"] = {"error": str(e)[:120]}
         if wl.kind == "fir":
             out["config"]["parity"] = "unpinned (HRTF arithmetic is not in the reference tree)"
         if rehearse:

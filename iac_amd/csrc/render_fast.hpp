@@ -178,9 +178,10 @@ __host__ __device__ constexpr int fast_lds_floats(int oc, int m, int fir = 0) {
   // The limiter's curve table (9651 entries at 48 kHz) stays in global memory.  The matrix variant
   // stages, per chunk, the window of it the chunk can reach without a trigger plus the head that
   // follows a trigger (2 * kFWin floats): 37 KiB of LDS for a stereo layout, four workgroups per CU.
-  // The HRTF variant reads the table from global memory (it has no input prefetch that an in-loop
-  // load could drain).
-  return oc * kFRing + 2 * kFRing + kFRing / 16 + 2 * kFChunk + (fir ? 0 : 2 * kFWin) + ((oc * m + 15) & ~15) + 16 +
+  // The MFMA HRTF variants read the table from global memory; the FFT one (fir == 3) stages the window like the
+  // matrix variant: a hot programme walks the limiter chain in most chunks, and every table look-up of the walk
+  // was an L2 round trip.
+  return oc * kFRing + 2 * kFRing + kFRing / 16 + 2 * kFChunk + ((fir && fir != 3) ? 0 : 2 * kFWin) + ((oc * m + 15) & ~15) + 16 +
          (fir == 3 ? kFftLdsFloats : (fir == 2 ? kF16LdsFloats : (fir ? kFirLdsFloats : 16 /* second element's matrix rows */)));
 }
 
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
   float *arr_g = arr_p + kFChunk;       // [1024]    gains from the limiter wave
   float *win = arr_g + kFChunk;         // [kFWin]   ctab[min(n_st + i, n_end)] (not in the HRTF variant)
   float *head = win + kFWin;            // [kFWin]   ctab[i]                     (not in the HRTF variant)
-  float *mat = win + (FIR ? 0 : 2 * kFWin);  // [OC*M]  feed-major matrix rows of the OC slots
+  constexpr bool kTab = FIR == 0 || FIR == 3;   // the limiter-table window and head are staged in LDS
+  float *mat = win + (kTab ? 2 * kFWin : 0);  // [OC*M]  feed-major matrix rows of the OC slots
   float *misc = mat + ((OC * M + 15) & ~15);  // [16]
   float *mat2 = misc + 16;              // [OC][kFIn2]  second element's matrix rows (IN2 only; aliases fir)
   float *fir = misc + 16;               // [kFirLdsFloats]  HRTF staging (FIR variant only)
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
     // leaves the running maximum unchanged
     ring_suf[rp] = sfx;
     if ((t & 15) == 0) ring_bm[rp >> 4] = sfx;
-    if constexpr (!FIR)
+    if constexpr (kTab)
       for (int i = t; i < kFWin; i += 256) head[i] = p.ctab[i < n_end ? i : n_end];
     if (!FIR && !DOWN && t < OC * M) {
       const int c = t / M, m = t - c * M;
@@ -352,9 +354,9 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
   // Fetched BEFORE the chunk's PCM stores are issued and written to LDS BEFORE the next input
   // prefetch is issued: vector-memory operations retire in order, so a wait for these values at
   // any later point would drain the stores / the prefetch as well.
-  float wv[FIR ? 1 : 5];
+  float wv[kTab ? 5 : 1];
   auto fetch_window = [&](int n0) {
-    if constexpr (!FIR) {
+    if constexpr (kTab) {
 #pragma unroll
       for (int r = 0; r < 5; ++r) {
         const int i = n0 + t + 256 * r;
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
       }
     }
   };
-  fetch_window(n_st);
+  if constexpr (!FIR) fetch_window(n_st);
 
   for (int c0 = 0; c0 < p.total; c0 += kFChunk) {
     const int cnt = p.total - c0 < kFChunk ? p.total - c0 : kFChunk;  // multiple of 64
@@ -384,6 +386,8 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
         fir_stage_fft<M>(p, in_s, fir_hist, c0, reinterpret_cast<fft_c32 *>(fir), ftw);
         __syncthreads();
       }
+      fetch_window(n_st);   // this chunk's table window: in flight while the stage's output is read back (not held
+                            // across the stage, whose registers are all spoken for)
     }
     float4 yd[DOWN ? OC : 1];
     if constexpr (DOWN) {
@@ -471,6 +475,11 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
 
     // ---- table window -> LDS, then the prefetch of the next chunk's input: the last vector-memory
     //      loads issued before the limiter work, so they stay in flight under everything below ----
+    if constexpr (FIR == 3) {
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+        if (t + 256 * r < kFWin) win[t + 256 * r] = wv[r];
+    }
     if constexpr (!FIR) {
 #pragma unroll
       for (int r = 0; r < 5; ++r)
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
     //      — so a chunk with a few isolated trigger runs costs a few short walks, not one walk to its end.
     const int n_chunk = n_st;  // what the staged table window is based on
     auto look = [&](int ci) {  // before the chunk's first trigger: the window; after one: the head
-      if constexpr (FIR) {
+      if constexpr (!kTab) {
         return p.ctab[ci];
       } else {
         const int d = ci - n_chunk;
@@ -605,7 +614,8 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
       if (bs >= nblk) break;
     }
 
-    if (c0 + kFChunk < p.total) fetch_window(n_st);  // for the next chunk, ahead of the stores
+    if constexpr (!FIR)
+      if (c0 + kFChunk < p.total) fetch_window(n_st);  // for the next chunk, ahead of the stores
 
     // ---- emit 4 delayed samples * gain as interleaved PCM ----
     const int64_t j0 = gk - kDelay;

@@ -384,6 +384,13 @@ inline int fft_build_tables(const float *hrir, int m, int taps, std::vector<floa
 #endif
 
 #if defined(__HIPCC__)
+// IAMF_FFT_EXP: timing-only elimination builds (WRONG results), tools/fft_exp.sh:
+//   1 = no spectra-table loads (the accumulation multiplies by a constant)   2 = the next pair's samples are not fetched
+//   3 = no LDS exchanges (the register stages run on whatever they hold)     4 = the stage returns at once
+//   5 = no accumulation at all (transforms only)
+#ifndef IAMF_FFT_EXP
+#define IAMF_FFT_EXP 0
+#endif
 // ------------------------------------------------------------------------------------------------------
 // device stage.  LDS of the variant: [4 waves][kFftScratch] complex scratch + the twiddle tables.  A wave leaves its
 // hop's 768 outputs per ear in ITS OWN scratch ([2 ears][768] floats: the scratch is idle between two passes), where the
@@ -441,6 +448,12 @@ __device__ __forceinline__ void fft_fetch(int pr, fft_c32 (&z)[16], unsigned ra_
     z[n1] = fft_mk(va, vb);
   }
 }
+// A use of all 16 registers that costs nothing: the compiler puts the wait for the loads that fill them in front of it.
+__device__ __forceinline__ void fft_touch(fft_c32 (&z)[16]) {
+  asm volatile(""
+               : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7]), "+v"(z[8]),
+                 "+v"(z[9]), "+v"(z[10]), "+v"(z[11]), "+v"(z[12]), "+v"(z[13]), "+v"(z[14]), "+v"(z[15]));
+}
 
 // where the stage left sample m (0 .. 3071, a multiple of 4) of the pass for ear e: four consecutive samples lie together
 __device__ __forceinline__ const float *fft_y_ptr(const float *scratch_all, int e, int m) {
@@ -453,10 +466,11 @@ __device__ __forceinline__ const float *fft_y_ptr(const float *scratch_all, int 
 template <int M>
 __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float *in_s, const float *hist, int c0,
                                               fft_c32 *scratch_all, const FftTwiddles &tw) {
-  const int t = threadIdx.x, lane = t & 63;
+  const int t = threadIdx.x, lane = t & 63, lane_ = lane;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform, and known to be: what follows stays in scalar registers
   const int b0 = c0 + kFftHop * w;   // the hop's first new sample, relative to the call
   if (b0 >= p.total) return;         // wave-uniform: the hop lies past the end of the call
+  if (IAMF_FFT_EXP == 4) return;
   fft_c32 *S = scratch_all + w * kFftScratch;
   constexpr int kPairs = (M + 1) / 2;
   // Where the 64-sample runs n = b0 - 256 + 64 n1 + [0, 64) of a channel come from (the same for every channel).
@@ -498,49 +512,68 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
   for (int r = 0; r < 16; ++r) u[r] = v[r] = fft_mk(0.f, 0.f);
   const float4 *pq = reinterpret_cast<const float4 *>(p.fir_pq);   // uniform base; the lane's share is added per load
   fft_c32 zb[16];
-  // one pair: transform za (already fetched), accumulate; the next pair's samples go to zb meanwhile
-  auto pair_step = [&](int pr, fft_c32 (&za)[16], fft_c32 (&zn)[16]) {
-    // In flight during this pair's transform: the next pair's samples (the last pair re-reads itself and drops it: no
-    // branch, no selects) and the first HALF of this pair's spectra table (8 x 16 bytes per lane, from L2).  The second
-    // half is fetched into the same registers as the first is consumed.  [Fetched where they are used, the table reads
-    // cost a full L2 round trip per pair with nothing to overlap it: the stage ran at a fifth of its instruction rate.]
-    FFT_FETCH(pr + 1 < kPairs ? pr + 1 : pr, zn);
+  // One pair: transform za (fetched a whole pair earlier), accumulate, then fetch the pair after next into the same
+  // registers.  Vector-memory loads return IN ORDER per wave, so a short load issued behind a long one waits for it: with
+  // the sample fetch (HBM, microseconds under load) at the top of the step, the second half of the spectra table (L2)
+  // queued behind it and every pair paid an HBM round trip (tools/fft_exp.sh: removing the fetch halved the kernel's
+  // time).  Order now: table half 1 -> transform -> accumulate half 1 / table half 2 -> accumulate half 2 -> samples of
+  // pair p + 2.  The table reads only ever queue behind a fetch that is a whole step old.
+  auto pair_step = [&](int pr, fft_c32 (&za)[16]) {
+    // an opaque copy of the lane index per step: the dozen LDS base addresses derived from it (exchange layouts, twiddle
+    // rows) are recomputed here — a few instructions — instead of living in registers across the loop, where they were
+    // the ones spilled (and a reload from scratch waits with vmcnt(0), i.e. for the sample fetch in flight)
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));
+    const fft_c32 *tw1 = tw.tw1 - lane_ + lane, *tw2 = tw.tw2 - (lane_ & 3) + (lane & 3);
     const float4 *tq = pq + pr * 16 * 64;
     float4 c[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) c[r] = (tq + r * 64)[lo];
-    fft_pin();   // both prefetches are issued here, ahead of the transform, and stay here
-    fft_fwd_a_tab(za, tw.tw1);
-    fft_x1_write(za, lane, S);
-    fft_wave_sync();
-    fft_x1_read(za, lane, S);
-    fft_fwd_b_tab(za, tw.tw2);
-    fft_wave_sync();
-    fft_x2_write(za, lane, S);
-    fft_wave_sync();
-    fft_x2_read(za, lane, S);
-    fft_wave_sync();
+    for (int r = 0; r < 8; ++r) c[r] = IAMF_FFT_EXP == 1 ? make_float4(0.5f, 0.25f, 0.125f, 0.0625f) : (tq + r * 64)[lo];
+    fft_pin();   // issued here, ahead of the transform, and stays here
+    fft_fwd_a_tab(za, tw1);
+    if (IAMF_FFT_EXP != 3) {
+      fft_x1_write(za, lane, S);
+      fft_wave_sync();
+      fft_x1_read(za, lane, S);
+    }
+    fft_fwd_b_tab(za, tw2);
+    if (IAMF_FFT_EXP != 3) {
+      fft_wave_sync();
+      fft_x2_write(za, lane, S);
+      fft_wave_sync();
+      fft_x2_read(za, lane, S);
+      fft_wave_sync();
+    }
     fft_fwd_c(za);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       u[r] = fft_cmac(u[r], za[r], fft_mk(c[r].x, c[r].y));
       v[r] = fft_cmac(v[r], za[r], fft_mk(c[r].z, c[r].w));
-      c[r] = (tq + (8 + r) * 64)[lo];
+      c[r] = IAMF_FFT_EXP == 1 ? make_float4(0.5f, 0.25f, 0.125f, 0.0625f) : (tq + (8 + r) * 64)[lo];
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       u[8 + r] = fft_cmac(u[8 + r], za[8 + r], fft_mk(c[r].x, c[r].y));
       v[8 + r] = fft_cmac(v[8 + r], za[8 + r], fft_mk(c[r].z, c[r].w));
     }
+    fft_pin();
+    // za is free: the samples of the pair after next (past the last pair: the last one again, dropped; no branch)
+    if (IAMF_FFT_EXP != 2) FFT_FETCH(pr + 2 < kPairs ? pr + 2 : kPairs - 1, za);
+    fft_pin();
   };
   FFT_FETCH(0, z);
+  FFT_FETCH(kPairs > 1 ? 1 : 0, zb);
+  // Enter the loop in the state its back edge has — one fetch (32 loads) in flight, the step's own registers arrived:
+  // with both fetches pending (64 loads, more than the wait counter counts) the compiler put s_waitcnt vmcnt(0) at the
+  // loop's head, which in steady state waits for the fetch issued a moment earlier: an HBM round trip per pair.
+  fft_touch(z);
   // two pairs per trip, the sample registers alternating: no copies between pairs
 #pragma unroll 1
   for (int pr = 0; pr + 1 < kPairs; pr += 2) {
-    pair_step(pr, z, zb);
-    pair_step(pr + 1, zb, z);
+    pair_step(pr, z);
+    pair_step(pr + 1, zb);
   }
-  if constexpr (kPairs & 1) pair_step(kPairs - 1, z, zb);
+  if constexpr (kPairs & 1) pair_step(kPairs - 1, z);
   fft_mirror_write(v, lane, S);
   fft_wave_sync();
   fft_mirror_read_add(u, lane, S);
