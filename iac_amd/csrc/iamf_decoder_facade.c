@@ -1172,6 +1172,41 @@ int IAMF_decoder_configure(IAMF_DecoderHandle d, const uint8_t *data, uint32_t s
   }
   if (rsize) *rsize = pos;
   if (data && rsize && !saw_data) return IAMF_ERR_BUFFER_TOO_SMALL; /* IAMF_decoder.c:2778,3923-3930 */
+  if (!(data && size > 0) && d->configured && d->tv && !d->need_reconf) {
+    /* The -DSAMSUNG_TV build's run-time output-layout switch (IAMF_decoder.c:3837-3881): configure without descriptors
+     * after IAMF_decoder_output_layout_set_*.  The reference re-opens the RENDERERS (and the resampler) for the new
+     * layout and re-initialises the limiter — its 240 delayed samples are gone, the next frame withholds 240 again —
+     * while the decoders, the parameter database and the stream time go on: everything that belongs to them is kept
+     * across the rebuild of the pipeline. */
+    const uint64_t ts = d->timestamp;
+    const int dmx_mode = d->dmx_mode, use_demix = d->use_demix;
+    const iamf_hip_demix_state dmst = d->dmst;
+    const uint32_t rec_flags = d->rec_flags;
+    const int rec_n = d->rec_n;
+    int32_t rec_ch[12];
+    float rec_gain[12];
+    uint32_t lrf[MAX_LAYERS];
+    float lrg[MAX_LAYERS][12];
+    memcpy(rec_ch, d->rec_ch, sizeof(rec_ch));
+    memcpy(rec_gain, d->rec_gain, sizeof(rec_gain));
+    memcpy(lrf, d->layer_rec_flags, sizeof(lrf));
+    memcpy(lrg, d->layer_rec_gain, sizeof(lrg));
+    rc = setup_pipeline(d);
+    if (rc == IAMF_OK) {
+      d->timestamp = ts;
+      d->dmx_mode = dmx_mode;
+      memcpy(d->layer_rec_flags, lrf, sizeof(lrf));
+      memcpy(d->layer_rec_gain, lrg, sizeof(lrg));
+      if (use_demix && d->use_demix) { /* the demixer is part of the stream decoder, which is not re-opened */
+        d->dmst = dmst;
+        d->rec_flags = rec_flags;
+        d->rec_n = rec_n;
+        memcpy(d->rec_ch, rec_ch, sizeof(rec_ch));
+        memcpy(d->rec_gain, rec_gain, sizeof(rec_gain));
+      }
+    }
+    return rc;
+  }
   rc = setup_pipeline(d);
   return rc;
 }

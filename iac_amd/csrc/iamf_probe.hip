@@ -113,3 +113,49 @@ extern "C" int iamf_hip_pick_buffer_pair(int n_streams, int chunks, int rows, in
   return rc;
 }
 
+// ---- self-test of w4_quot (render_common.hpp): every f32 numerator against the IEEE division, on the device ----
+namespace {
+__device__ __forceinline__ float st_quot(float n, float d, float r, bool &ok) {   // the same three operations
+  const float an = __builtin_fabsf(n);
+  ok = ok && an >= 0x1p-100f && an < 0x1p126f;
+  const float q = n * r;
+  const float e = __builtin_fmaf(-d, q, n);
+  return __builtin_fmaf(e, r, q);
+}
+__global__ __launch_bounds__(256) void shared_divisor_sweep_kernel(float d, unsigned long long *out) {
+  const float r = 1.0f / d;
+  unsigned long long in_range = 0, bad_in = 0, bad_out = 0;
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;   // 2^20 threads x 2^12 numerators each
+  for (uint32_t i = 0; i < 4096u; ++i) {
+    const uint32_t u = (i << 20) | t;
+    const float n = __uint_as_float(u);
+    bool ok = true;
+    const float f = st_quot(n, d, r, ok), g = n / d;
+    const bool same = __float_as_uint(f) == __float_as_uint(g);
+    in_range += ok;
+    bad_in += ok && !same;
+    bad_out += !ok && !same && !(g != g && f != f);
+  }
+  atomicAdd(&out[0], in_range);
+  atomicAdd(&out[1], bad_in);
+  atomicAdd(&out[2], bad_out);
+}
+}  // namespace
+
+extern "C" int iamf_hip_selftest_shared_divisor(float divisor, uint64_t counts[3]) {
+  if (!counts || !(divisor > 0.f)) return IAMF_HIP_ERR_BAD_ARG;
+  unsigned long long *d_out = nullptr;
+  if (hipMalloc(&d_out, 3 * sizeof(unsigned long long)) != hipSuccess) return IAMF_HIP_ERR_DEVICE;
+  int rc = IAMF_HIP_OK;
+  if (hipMemset(d_out, 0, 3 * sizeof(unsigned long long)) != hipSuccess) rc = IAMF_HIP_ERR_DEVICE;
+  if (rc == IAMF_HIP_OK) {
+    hipLaunchKernelGGL(shared_divisor_sweep_kernel, dim3(4096), dim3(256), 0, nullptr, divisor, d_out);
+    unsigned long long h[3] = {0, 0, 0};
+    if (hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) rc = IAMF_HIP_ERR_DEVICE;
+    counts[0] = h[0];
+    counts[1] = h[1];
+    counts[2] = h[2];
+  }
+  (void)hipFree(d_out);
+  return rc;
+}

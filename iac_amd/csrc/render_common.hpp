@@ -154,6 +154,23 @@ __device__ __forceinline__ float to_scaled(float x, float scale, float lo, float
   return rintf(x);  // v_rndne_f32: ties to even, like lrintf in the default rounding mode
 }
 
+// Quotients that share a divisor (the demixer of scalable channel audio divides 8 numerators each by delta, beta and
+// gamma of the frame: demixer.c:205-214,255-267,357-366).  With r = RN(1 / d) — ONE IEEE division per divisor —
+//     q = n * r;  e = fma(-d, q, n);  q' = fma(e, r, q)
+// is the correctly rounded n / d, bit for bit, for every f32 numerator with 2^-100 <= |n| < 2^126 and every divisor the
+// demixing modes can produce (1, 0.707f, 0.866f: IAMF_utils.c:236-240); outside that range the residual e underflows or
+// q overflows, and -0 comes out as +0.  Proven by an exhaustive sweep of all 2^32 numerators per divisor ON THE DEVICE
+// (iamf_hip_selftest_shared_divisor, tests/test_gpu_wide4.py) and on the host.  w4_quot returns q' and clears *ok for a
+// numerator outside the range; the caller then redoes its divisions the slow way (a wave-uniform, rare branch: digital
+// silence takes it).  Three instructions per quotient instead of the ~10 of an IEEE division.
+__device__ __forceinline__ float w4_quot(float n, float d, float r, bool &ok) {
+  const float an = __builtin_fabsf(n);
+  ok = ok && an >= 0x1p-100f && an < 0x1p126f;
+  const float q = n * r;
+  const float e = __builtin_fmaf(-d, q, n);
+  return __builtin_fmaf(e, r, q);
+}
+
 // which HRTF stage a FIR call runs (host): 3 = overlap-save FFT (default), 2 = split-f16 MFMA, 1 = f32 MFMA
 inline int fir_stage_choice(const RenderParams &p) {
   if (getenv("IAMF_HIP_FIR_F32")) return 1;

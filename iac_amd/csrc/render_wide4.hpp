@@ -149,15 +149,28 @@ __device__ __forceinline__ void w4_demix(const RenderParams &p, float4 (&x)[M],
     ch[kChL3] = make_float4((float)((double)l.x - cx), (float)((double)l.y - cy), (float)((double)l.z - cz), (float)((double)l.w - cw));
     ch[kChR3] = make_float4((float)((double)r.x - cx), (float)((double)r.y - cy), (float)((double)r.z - cz), (float)((double)r.w - cw));
   }
+  // The 24 divisions of a lane and chunk have three divisors.  Eight numerators per divisor: quotients through the
+  // divisor's reciprocal (w4_quot, render_common.hpp: bit-identical to the IEEE division in its proven range), and the
+  // IEEE divisions themselves only if some numerator of the wave lies outside that range (wave-uniform branch).
+  auto div8 = [](float4 &o0, float4 &o1, const float4 n0, const float4 n1, const float d) {
+    const float r = 1.0f / d;
+    bool ok = true;
+    o0 = make_float4(w4_quot(n0.x, d, r, ok), w4_quot(n0.y, d, r, ok), w4_quot(n0.z, d, r, ok), w4_quot(n0.w, d, r, ok));
+    o1 = make_float4(w4_quot(n1.x, d, r, ok), w4_quot(n1.y, d, r, ok), w4_quot(n1.z, d, r, ok), w4_quot(n1.w, d, r, ok));
+    if (!__all(ok)) {
+      o0 = make_float4(n0.x / d, n0.y / d, n0.z / d, n0.w / d);
+      o1 = make_float4(n1.x / d, n1.y / d, n1.z / d, n1.w / d);
+    }
+  };
   if (steps & 4) {  // S3to5 (:186-230)
     const float4 a = ch[kChL3], b = ch[kChL7], c = ch[kChR3], d = ch[kChR7];
-    ch[kChSL5] = make_float4((a.x - b.x) / delta, (a.y - b.y) / delta, (a.z - b.z) / delta, (a.w - b.w) / delta);
-    ch[kChSR5] = make_float4((c.x - d.x) / delta, (c.y - d.y) / delta, (c.z - d.z) / delta, (c.w - d.w) / delta);
+    div8(ch[kChSL5], ch[kChSR5], make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w),
+         make_float4(c.x - d.x, c.y - d.y, c.z - d.z, c.w - d.w), delta);
   }
   if (steps & 8) {  // S5to7 (:236-284)
     const float4 a = ch[kChSL5], b = ch[kChSL7], c = ch[kChSR5], d = ch[kChSR7];
-    ch[kChBL7] = make_float4((a.x - b.x * alpha) / beta, (a.y - b.y * alpha) / beta, (a.z - b.z * alpha) / beta, (a.w - b.w * alpha) / beta);
-    ch[kChBR7] = make_float4((c.x - d.x * alpha) / beta, (c.y - d.y * alpha) / beta, (c.z - d.z * alpha) / beta, (c.w - d.w * alpha) / beta);
+    div8(ch[kChBL7], ch[kChBR7], make_float4(a.x - b.x * alpha, a.y - b.y * alpha, a.z - b.z * alpha, a.w - b.w * alpha),
+         make_float4(c.x - d.x * alpha, c.y - d.y * alpha, c.z - d.z * alpha, c.w - d.w * alpha), beta);
   }
   if (steps & 16) {  // TF2toT2 (:290-335)
     const float4 a = ch[kChTL], b = ch[kChSL5], c = ch[kChTR], d = ch[kChSR5];
@@ -167,8 +180,8 @@ __device__ __forceinline__ void w4_demix(const RenderParams &p, float4 (&x)[M],
   }
   if (steps & 32) {  // T2toT4 (:340-377)
     const float4 a = ch[kChHL], b = ch[kChHFL], c = ch[kChHR], d = ch[kChHFR];
-    ch[kChHBL] = make_float4((a.x - b.x) / gamma, (a.y - b.y) / gamma, (a.z - b.z) / gamma, (a.w - b.w) / gamma);
-    ch[kChHBR] = make_float4((c.x - d.x) / gamma, (c.y - d.y) / gamma, (c.z - d.z) / gamma, (c.w - d.w) / gamma);
+    div8(ch[kChHBL], ch[kChHBR], make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w),
+         make_float4(c.x - d.x, c.y - d.y, c.z - d.z, c.w - d.w), gamma);
   }
   // the target layout's channels in playback order; the layouts of M channels are the only candidates
   const int layout = p.demix_layout;

@@ -358,6 +358,13 @@ int iamf_hip_pick_buffer_pair(int n_streams, int chunks, int rows, int pieces, c
                               int n_in, int64_t in_stream_stride_bytes, void *const *d_out_candidates, int n_out,
                               int64_t out_stream_stride_bytes, void *stream, int *best_in, int *best_out, float *ms);
 
+/* Self-test (diagnostic): the demixer's quotients through a shared reciprocal (q = n r, e = fma(-d, q, n), q' = fma(e, r,
+ * q); iac_amd/csrc/render_common.hpp w4_quot) against the IEEE division n / d for ALL 2^32 f32 numerators, on the
+ * device.  counts[0] = numerators inside the range the kernels use the fast form for (2^-100 <= |n| < 2^126), counts[1] =
+ * those of them whose quotient differs in any bit (must be 0), counts[2] = numerators outside the range that differ
+ * (the kernels divide those the IEEE way).  Synchronous. */
+int iamf_hip_selftest_shared_divisor(float divisor, uint64_t counts[3]);
+
 /* ------------------------------------------------------------------------------------------
  * Decoder facade extension.  The reference chooses at BUILD time whether scene-based elements feed
  * the LFE of the output layout (-DDISABLE_LFE_HOA=0; default: compiled out, ae_rdr.h:63-65).  This

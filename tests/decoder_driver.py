@@ -86,3 +86,56 @@ def decode_stream(ref, stream_bytes, layout, bit_depth=16, out_rate=0, loudness=
     return out.copy(), rets
 
 
+def decode_stream_switching(ref, stream_bytes, layouts, switch_after, bit_depth=16, pcm_channels=12):
+    """As decode_stream, but the output layout is changed while decoding: after `switch_after[i]` decode calls that
+    returned a frame, IAMF_decoder_output_layout_set_* (layouts[i + 1]) + IAMF_decoder_configure(h, NULL, 0, NULL) — the
+    run-time switch of the reference's -DSAMSUNG_TV build (IAMF_decoder.c:3819-3881).  Returns (list of per-call PCM
+    arrays [n][pcm_channels], rets incl. the configure results as ('cfg', rc))."""
+    ref.IAMF_decoder_open.restype = C.c_void_p
+    ref.IAMF_decoder_close.argtypes = [C.c_void_p]
+    ref.IAMF_decoder_configure.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    ref.IAMF_decoder_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_uint32), C.c_void_p]
+    ref.IAMF_decoder_output_layout_set_sound_system.argtypes = [C.c_void_p, C.c_int]
+    ref.IAMF_decoder_output_layout_set_binaural.argtypes = [C.c_void_p]
+    ref.IAMF_decoder_set_bit_depth.argtypes = [C.c_void_p, C.c_uint32]
+    ref.IAMF_decoder_set_pts.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
+
+    def set_layout(d, layout):
+        if layout[0] == "ss":
+            return ref.IAMF_decoder_output_layout_set_sound_system(d, layout[1])
+        return ref.IAMF_decoder_output_layout_set_binaural(d)
+
+    d = ref.IAMF_decoder_open()
+    ref.IAMF_decoder_set_bit_depth(d, bit_depth)
+    set_layout(d, layouts[0])
+    ref.IAMF_decoder_set_pts(d, 0, 90000)
+    rsize = C.c_uint32(0)
+    assert ref.IAMF_decoder_configure(d, stream_bytes, len(stream_bytes), C.byref(rsize)) == 0
+    used = rsize.value
+    bps = bit_depth // 8
+    ch = pcm_channels
+    pcm = C.create_string_buffer(bps * 6144 * 6 * 24)
+    chunks, rets, frames, li = [], [], 0, 0
+    dt = {16: np.int16, 32: np.int32}[bit_depth]
+    while used < len(stream_bytes):
+        rsize.value = 0
+        rest = stream_bytes[used:]
+        n = ref.IAMF_decoder_decode(d, rest, len(rest), C.byref(rsize), pcm)
+        assert n >= 0, n
+        if n > 0:
+            chunks.append(np.frombuffer(pcm.raw[:n * ch * bps], dtype=dt).reshape(n, ch).copy())
+            rets.append(n)
+            frames += 1
+            if li < len(switch_after) and frames == switch_after[li]:
+                li += 1
+                set_layout(d, layouts[li])
+                rets.append(("cfg", ref.IAMF_decoder_configure(d, None, 0, None)))
+        used += rsize.value
+        if not rsize.value:
+            break
+    n = ref.IAMF_decoder_decode(d, None, 0, C.byref(rsize), pcm)
+    if n > 0:
+        chunks.append(np.frombuffer(pcm.raw[:n * ch * bps], dtype=dt).reshape(n, ch).copy())
+    rets.append(n)
+    ref.IAMF_decoder_close(d)
+    return chunks, rets

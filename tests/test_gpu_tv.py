@@ -97,3 +97,19 @@ def test_batch_pcm_stride_12(out, fmt, bps):
         got = outs[12][1][s][:want.size].reshape(-1, bps)
         assert np.array_equal(got, want), (out, s)
         assert (outs[12][1][s][want.size:want.size + 8] == 0xEE).all()   # nothing written past it
+
+
+@pytest.mark.parametrize("name", sorted(T.SWITCH_CASES))
+def test_run_time_layout_switch_matches_the_samsung_tv_reference(lib, golden, name):
+    """IAMF_decoder_output_layout_set_* + IAMF_decoder_configure(h, NULL, 0, NULL) between two frames: the -DSAMSUNG_TV
+    build re-opens the renderers in place and re-initialises the limiter (IAMF_decoder.c:3819-3881) while the stream time
+    and the parameter timelines go on.  PCM and every return value against the reference built that way."""
+    import e2e_cases as E
+    from decoder_driver import decode_stream_switching
+    c = T.SWITCH_CASES[name]
+    stream = E.build(c["stream"])[0]
+    chunks, rets = decode_stream_switching(_TV(lib), stream, c["layouts"], c["after"], bit_depth=E.CASES[c["stream"]].get("bit_depth", 16))
+    g = golden.npz("tv")
+    assert [r[1] if isinstance(r, tuple) else r for r in rets] == list(g[name + "_rets"]), name
+    assert [len(x) for x in chunks] == list(g[name + "_lens"])
+    assert np.array_equal(np.concatenate(chunks, axis=0), g[name]), name

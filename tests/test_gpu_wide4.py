@@ -352,3 +352,24 @@ def test_wide4_mixing_variant(hip, bed, out, second, m2, proj):
             assert np.array_equal(got[s], want), (bed, out, s)
         else:
             assert np.abs(got[s].astype(np.int32) - want.astype(np.int32)).max() <= 1, (bed, out, s)
+
+
+def test_shared_divisor_quotients_are_the_ieee_quotients_for_every_numerator(hip):
+    """The wide4 demixer divides 8 numerators each by delta, beta and gamma of the frame (demixer.c:205-214,255-267,
+    357-366) through the divisor's reciprocal: q = n r, e = fma(-d, q, n), q' = fma(e, r, q).  Swept on the device over ALL
+    2^32 numerators for every divisor a demixing mode can produce (IAMF_utils.c:236-240: 1, 0.707f, 0.866f): inside the
+    range the kernel uses it for (2^-100 <= |n| < 2^126) not one quotient differs from n / d in any bit; outside it some
+    do (underflowing residual, overflow, -0), which is why the kernel divides those the IEEE way."""
+    import ctypes as C
+    A, _ = hip
+    L = A.lib()
+    L.iamf_hip_selftest_shared_divisor.argtypes = [C.c_float, C.POINTER(C.c_uint64)]
+    outside_bad = 0
+    for d in (1.0, 0.707, 0.866, 0.5, 0.70710678):
+        c = (C.c_uint64 * 3)()
+        assert L.iamf_hip_selftest_shared_divisor(C.c_float(d), c) == 0
+        n_in, bad_in, bad_out = int(c[0]), int(c[1]), int(c[2])
+        assert n_in == 2 * (226 << 23), (d, n_in)          # 226 binades x 2^23 significands x 2 signs
+        assert bad_in == 0, (d, bad_in)
+        outside_bad += bad_out
+    assert outside_bad > 0      # the guard is not decoration

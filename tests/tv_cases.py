@@ -53,3 +53,15 @@ def decode_kwargs(name):
     c = case(name)
     return dict(bit_depth=c.get("bit_depth", 16), out_rate=c.get("out_rate", 0), loudness=c.get("loudness", 0.0),
                 limiter=c.get("limiter", True), threshold=c.get("threshold", -1.0), pcm_channels=12)
+
+
+# Run-time output-layout switches of the -DSAMSUNG_TV build (IAMF_decoder.c:3819-3881): IAMF_decoder_output_layout_set_*
+# + IAMF_decoder_configure(h, NULL, 0, NULL) between two frames.  name -> (stream case, layouts in turn, frames decoded
+# before each switch)
+SWITCH_CASES = {
+    "switch_l714_J_to_A": dict(stream="l714_A_s16", layouts=[("ss", 9), ("ss", 0)], after=[3]),
+    "switch_l714_A_to_J_to_B": dict(stream="l714_A_s16", layouts=[("ss", 0), ("ss", 9), ("ss", 1)], after=[2, 5]),
+    "switch_toa_H_to_binaural": dict(stream="toa_H_s16", layouts=[("ss", 7), ("binaural",)], after=[2]),
+    "switch_scalable_C_to_A": dict(stream="scalable_C_s16", layouts=[("ss", 2), ("ss", 0)], after=[3]),
+    "switch_dmx_C_to_J": dict(stream="l714_C_dmx", layouts=[("ss", 2), ("ss", 9)], after=[2]),
+}
