@@ -354,8 +354,8 @@ def kernel_tag(kind, in_ch, out_ch):
                 "render_wide4_kernel<%d, %d, false, false, true") % (in_ch, out_ch)
     if kind == "demix":
         return "render_wide4_kernel<%d, %d, false, true" % (in_ch, out_ch)
-    if kind == "fir":
-        return "render_fast_kernel<%d, 2, 2" % in_ch
+    if kind == "fir":   # stage 3 = overlap-save FFT (default), 2 = split-f16 MFMA, 1 = f32 MFMA
+        return "render_fast_kernel<%d, 2, %d" % (in_ch, 1 if os.environ.get("IAMF_HIP_FIR_F32") else (2 if os.environ.get("IAMF_HIP_FIR_F16") else 3))
     if kind == "h2m_lfe":   # render_wide4_kernel<.., LFE>, behind the generator's two kernels (render_lfe.hpp)
         return "render_wide4_kernel<%d, %d, true, false, false, false, true" % (in_ch, out_ch)
     if out_ch <= 2:

@@ -567,6 +567,8 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
   // with both fetches pending (64 loads, more than the wait counter counts) the compiler put s_waitcnt vmcnt(0) at the
   // loop's head, which in steady state waits for the fetch issued a moment earlier: an HBM round trip per pair.
   fft_touch(z);
+  fft_touch(zb);   // (both: a fetch still pending at the loop's head from the prologue — into registers the allocator
+                   //  gave it there — makes the head's wait a vmcnt(0) for every trip; this one is paid once per hop)
   // two pairs per trip, the sample registers alternating: no copies between pairs
 #pragma unroll 1
   for (int pr = 0; pr + 1 < kPairs; pr += 2) {

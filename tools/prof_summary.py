@@ -88,6 +88,28 @@ def main():
         summary["sample_frames_per_launch"] = sf
         for v in pmc.values():
             v["hbm_bytes_per_sample_frame"] = v["hbm_bytes_per_launch"] / sf
+    if len(sys.argv) > 6 and os.path.exists(sys.argv[6]):
+        # the unprofiled run of the same command on the same box: its line, the card's read-out, and what the profile says
+        # the roofline fraction is (algorithmic bytes / the rocprof timed-region average / 8 TB/s)
+        try:
+            b = json.load(open(sys.argv[6]))
+            summary["device"] = b.get("device")
+            summary["bench_line"] = {"value": b.get("value"), "kernel_ms": b["roofline"].get("kernel_ms"), "frac": b["roofline"].get("frac"),
+                                     "streams_per_gpu": b["config"].get("streams_per_gpu"), "verified": (b.get("verified") or {}).get("ok"),
+                                     "max_lsb": (b.get("verified") or {}).get("max_lsb")}
+            alg = b["roofline"].get("algorithmic_bytes_per_launch")
+            for k, t in summary.get("timed_region", {}).items():
+                if alg and b["roofline"].get("kernel", "")[:44] in k:
+                    t["roofline_frac_from_this_profile"] = round(alg / (t["avg_ns"] * 1e-9) / 8e12, 4)
+        except Exception as e:   # noqa: BLE001
+            summary["bench_line"] = {"error": str(e)}
+        # the traced command's own line (HIP events under the profiler): the profiler costs the kernels 5-13 % on this pool
+        try:
+            tl = [x for x in open(src + ".trace.log") if x.startswith("{")][-1]
+            t = json.loads(tl)
+            summary["traced_run_line"] = {"value": t.get("value"), "kernel_ms": t["roofline"].get("kernel_ms"), "frac": t["roofline"].get("frac")}
+        except Exception:   # noqa: BLE001
+            pass
     with open(out + "_pmc.json", "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
     print(json.dumps(summary, indent=1, sort_keys=True))
