@@ -100,9 +100,11 @@ def measured_traffic(kernel_tag, sf_per_step, workload=None):
             d = json.load(open(f))
         except Exception:
             continue
-        for name, v in d.get("pmc", {}).items():
-            if kernel_tag in name and "hbm_bytes_per_sample_frame" in v:
-                best = (v["hbm_bytes_per_sample_frame"] * sf_per_step, os.path.basename(f))
+        tags = kernel_tag if isinstance(kernel_tag, tuple) else (kernel_tag,)   # a step of several kernels: all of them
+        hit = [v["hbm_bytes_per_sample_frame"] for t in tags for name, v in d.get("pmc", {}).items()
+               if t in name and "hbm_bytes_per_sample_frame" in v]
+        if len(hit) == len(tags):
+            best = (sum(hit) * sf_per_step, os.path.basename(f))
     return best
 
 
@@ -354,8 +356,13 @@ def kernel_tag(kind, in_ch, out_ch):
                 "render_wide4_kernel<%d, %d, false, false, true") % (in_ch, out_ch)
     if kind == "demix":
         return "render_wide4_kernel<%d, %d, false, true" % (in_ch, out_ch)
-    if kind == "fir":   # stage 3 = overlap-save FFT (default), 2 = split-f16 MFMA, 1 = f32 MFMA
-        return "render_fast_kernel<%d, 2, %d" % (in_ch, 1 if os.environ.get("IAMF_HIP_FIR_F32") else (2 if os.environ.get("IAMF_HIP_FIR_F16") else 3))
+    if kind == "fir":
+        # default: the overlap-save FFT stage as a kernel of its own (the dominant one) + the two-channel matrix kernel over
+        # its output; IAMF_HIP_FIR_FUSED: the same stage inside the limiter kernel (3); _F16 / _F32: the MFMA stages (2 / 1)
+        for env, st in (("IAMF_HIP_FIR_F32", 1), ("IAMF_HIP_FIR_F16", 2), ("IAMF_HIP_FIR_FUSED", 3)):
+            if os.environ.get(env):
+                return "render_fast_kernel<%d, 2, %d" % (in_ch, st)
+        return ("fir_fft_kernel<%d>" % in_ch, "render_fast_kernel<2, 2, 0, false, false")
     if kind == "h2m_lfe":   # render_wide4_kernel<.., LFE>, behind the generator's two kernels (render_lfe.hpp)
         return "render_wide4_kernel<%d, %d, true, false, false, false, true" % (in_ch, out_ch)
     if out_ch <= 2:
@@ -665,10 +672,14 @@ class Workload:
              "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
              "traffic_source": traffic[1] if traffic else None,
              "algorithmic_bytes_per_launch": self.bytes_per_sf * self.sf_per_step,
-             "kernel": self.ktag, "kernel_ms": round(kernel_ms, 4),
+             "kernel": self.ktag if isinstance(self.ktag, str) else self.ktag[0], "kernel_ms": round(kernel_ms, 4),
              "algorithmic_bytes_per_sample_frame": self.bytes_per_sf,
              "frac_of_measured_copy_6290": round(achieved / 6290.0, 4)}
         dtype = "f32"
+        if not isinstance(self.ktag, str):
+            r["kernels"] = list(self.ktag)
+            r["kernel_ms_spans"] = ("the %d kernels of one call, back to back on the stream (HIP events around the call); their "
+                                    "separate durations: profiles/*_%s_pmc.json" % (len(self.ktag), self.name))
         if self.kind == "fir":
             # Three stages, one specification (render_fir.hpp).  Default: overlap-save FFT on the VALU (render_fir_fft.hpp):
             # ~770 flop per sample-frame -> the stage is no longer the bound by count; the kernel's bound is HBM (68 B per
@@ -689,8 +700,10 @@ class Workload:
                                    "note": "1024-point transforms, 768-sample hops, two channels per complex transform"},
                           "direct_form_equivalent_tflops": round(flop_direct * rate / 1e12, 1),
                           "direct_form_flop_per_sample_frame": flop_direct,
-                          "note": "bound = HBM (68 B per sample-frame): the FFT stage issues %.0f flop per sample-frame where the "
-                                  "direct form needs %d; measured limiter: latency at 2 waves per SIMD (DESIGN.md 4.2)" % (flop_sf, flop_direct)})
+                          "note": "bound = HBM by count (68 B per sample-frame + 16 for y between the two kernels): the FFT stage "
+                                  "issues %.0f flop per sample-frame where the direct form needs %d; what limits it as measured: "
+                                  "the stage kernel's VALU issue at 2 waves per SIMD (~240 VGPRs) and the limiter kernel's chain "
+                                  "(DESIGN.md 4.2c)" % (flop_sf, flop_direct)})
             else:
                 tf = flop_direct * rate / 1e12
                 peak = F32_MFMA_PEAK_TFLOPS if f32_stage else F16_MFMA_PEAK_TFLOPS

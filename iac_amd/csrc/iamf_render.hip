@@ -46,6 +46,7 @@
 
 extern "C" int iamf_hip_fir_m2b_has(int m);                                           // iamf_render_fir_m2b.hip
 extern "C" int iamf_hip_fir_m2b_launch(const void *params, int m, hipStream_t st);    // iamf_render_fir_m2b.hip
+extern "C" int iamf_hip_fir_m2b_launch_fft(const void *params, int m, hipStream_t st);  // iamf_render_fir_m2b.hip
 extern "C" int iamf_hip_wide4_has_mix(int m, int c);                                  // iamf_render_wide4_mix.hip
 extern "C" int iamf_hip_wide4_mix_launch(const void *params, int m, hipStream_t st);  // iamf_render_wide4_mix.hip
 extern "C" int iamf_hip_wide4_has_lfe(int m, int c);                                  // iamf_render_wide4_lfe.hip
@@ -216,6 +217,10 @@ struct iamf_hip_batch {
   void *d_fir_h16 = nullptr;    // split-f16 filter tables (render_fir16.hpp)
   float *d_fir_pq = nullptr, *d_fir_tw = nullptr;   // spectra and twiddles of the FFT stage (render_fir_fft.hpp)
   float *d_fir_zero = nullptr;                      // 64 zero floats for that stage
+  float *d_fir_y = nullptr;                         // [n_streams][2][total] f32: its output when it runs as its own kernel
+  size_t fir_y_floats = 0;
+  float *d_fir_id = nullptr;                        // 2 x 2 identity + slot map for the limiter / pack kernel behind it
+  int32_t *d_fir_id_feed = nullptr;
   float fir_inv_scale = 1.f;
   int fir_cur = 0;
   // HOA LFE generator (render_lfe.hpp)
@@ -300,6 +305,12 @@ void launch_fir_m(const RenderParams &p, dim3 grid, hipStream_t st) {
   } else {
     hipLaunchKernelGGL((render_fast_kernel<M, 2, 1>), grid, dim3(512), sizeof(float) * (size_t)fast_lds_floats(2, M, 1), st, p);
   }
+}
+
+template <int M>
+void launch_fft_m(const RenderParams &p, hipStream_t st) {   // render_fir_fft.hpp: fir_fft_kernel
+  const dim3 g((unsigned)((p.total + kFftSpan - 1) / kFftSpan), (unsigned)p.n_launch);
+  hipLaunchKernelGGL((fir_fft_kernel<M>), g, dim3(256), sizeof(float) * (size_t)kFftLdsFloats, st, p, p.fir_y, 2 * (int64_t)p.total);
 }
 
 template <int M>
@@ -434,6 +445,36 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
     if (!fast_path_ok(p)) return IAMF_HIP_ERR_UNIMPLEMENTED;
     // the FIR stage keeps input offsets of one stream as 32-bit integers
     if (((int64_t)(p.total / p.frame_size) + 1) * p.in_frame_stride >= (int64_t)1 << 31) return IAMF_HIP_ERR_BAD_ARG;
+    if (fir_stage_choice(p) == 4) {
+      // (1) the FFT stage for every hop of every stream -> y in HBM (overlap-save blocks are independent: one grid); (2)
+      // gains, limiter, pack = the two-channel matrix kernel with the identity over y (one "frame" of `total` samples per
+      // stream).  1024 streams x 64 frames: 1.5 ms (vector ALU) + 0.6 ms (the limiter's chain, four workgroups a CU).
+      // Tried and dropped, both bit-exact: slices of STREAMS with the limiter kernel of one slice beside the stage of the
+      // next on a second stream (23.8 against 33.2 Gsamples/s: the limiter kernel takes 0.6 ms for 256 streams as for
+      // 1024), and slices of TIME the same way (31.1: four resident limiter workgroups and two stage workgroups each want
+      // all 512 VGPRs of a SIMD lane, so the two kernels take turns instead of overlapping).
+      switch (m) {
+        case 1: launch_fft_m<1>(p, st); break;
+        case 4: launch_fft_m<4>(p, st); break;
+        case 9: launch_fft_m<9>(p, st); break;
+        case 16: launch_fft_m<16>(p, st); break;
+        default:
+          if (!iamf_hip_fir_m2b_launch_fft(&p, m, st)) return IAMF_HIP_ERR_UNIMPLEMENTED;
+      }
+      HIPCHK(hipGetLastError());
+      RenderParams q = p;
+      q.in = p.fir_y;                               // planar [2][total]: channel stride = "frame size" = total
+      q.in_stream_stride = 2 * (int64_t)p.total;
+      q.in_frame_stride = 2 * (int64_t)p.total;
+      q.frame_size = p.total;
+      q.matrix = p.fir_id_matrix;
+      q.src_feed = p.fir_id_feed;
+      q.n_feeds = 2;
+      q.fir_taps = 0;
+      q.fir_hist = q.fir_hist_next = nullptr;
+      launch_fast_m<2>(q, grid, st);
+      return hipGetLastError() == hipSuccess ? IAMF_HIP_OK : IAMF_HIP_ERR_DEVICE;
+    }
     switch (m) {
       case 1: launch_fir_m<1>(p, grid, st); break;
       case 4: launch_fir_m<4>(p, grid, st); break;
@@ -608,6 +649,22 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int
     p.fir_pq = b->d_fir_pq;
     p.fir_tw = b->d_fir_tw;
     p.fir_zero = b->d_fir_zero;
+    if (a.d_in && b->d_fir_pq && (b->cfg.frame_size & 63) == 0 && !getenv("IAMF_HIP_FIR_FUSED") && !getenv("IAMF_HIP_FIR_F16") &&
+        !getenv("IAMF_HIP_FIR_F32")) {
+      // the FFT stage's output of this call, [n_streams][2][total] (grows with the largest call seen)
+      const size_t need = (size_t)b->cfg.n_streams * 2 * (size_t)total;
+      if (need > b->fir_y_floats) {
+        HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(a.stream)));
+        (void)hipFree(b->d_fir_y);
+        b->d_fir_y = nullptr;
+        b->fir_y_floats = 0;
+        HIPCHK(hipMalloc(&b->d_fir_y, sizeof(float) * need));
+        b->fir_y_floats = need;
+      }
+      p.fir_y = b->d_fir_y;
+      p.fir_id_matrix = b->d_fir_id;
+      p.fir_id_feed = b->d_fir_id_feed;
+    }
   }
   if (b->lfe && a.d_in && total > 0) {
     // HOA LFE generator: feed-forward part in parallel, the recurrence one lane per stream, both on the
@@ -926,6 +983,13 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
       CREATE_CHK(hipMemcpy(b->d_fir_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
       CREATE_CHK(hipMalloc(&b->d_fir_zero, 64 * sizeof(float)));
       CREATE_CHK(hipMemset(b->d_fir_zero, 0, 64 * sizeof(float)));
+      const float id[4] = {1.f, 0.f, 0.f, 1.f};
+      int32_t idf[kMaxOut];
+      for (int i = 0; i < kMaxOut; ++i) idf[i] = i < 2 ? i : -1;
+      CREATE_CHK(hipMalloc(&b->d_fir_id, sizeof(id)));
+      CREATE_CHK(hipMemcpy(b->d_fir_id, id, sizeof(id), hipMemcpyHostToDevice));
+      CREATE_CHK(hipMalloc(&b->d_fir_id_feed, sizeof(idf)));
+      CREATE_CHK(hipMemcpy(b->d_fir_id_feed, idf, sizeof(idf), hipMemcpyHostToDevice));
     }
   }
   CREATE_CHK(hipMalloc(&b->d_dmx_tab, sizeof(dmx_tab)));
@@ -974,6 +1038,9 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_fir_pq);
   (void)hipFree(b->d_fir_tw);
   (void)hipFree(b->d_fir_zero);
+  (void)hipFree(b->d_fir_y);
+  (void)hipFree(b->d_fir_id);
+  (void)hipFree(b->d_fir_id_feed);
   (void)hipFree(b->d_lfe_state);
   (void)hipFree(b->d_lfe_next);
   (void)hipFree(b->d_lfe_u);

@@ -35,8 +35,8 @@ void launch_fir_m(const RenderParams &p, hipStream_t st) {
     opted.end();
   }
   const dim3 grid((unsigned)p.n_launch);
-  const int stage = fir_stage_choice(p);   // as launch_fir_m of iamf_render.hip
-  if (stage == 3) {
+  const int stage = fir_stage_choice(p);   // as launch_fir_m of iamf_render.hip (4 is handled by the caller)
+  if (stage == 3 || stage == 4) {
     static_assert(fast_lds_floats(2, M, 3) * 4 <= 80 * 1024, "two workgroups per CU");
     hipLaunchKernelGGL((render_fast_kernel<M, 2, 3>), grid, dim3(256), sizeof(float) * (size_t)fast_lds_floats(2, M, 3), st, p);
   } else if (stage == 2) {
@@ -47,7 +47,27 @@ void launch_fir_m(const RenderParams &p, hipStream_t st) {
   }
 }
 
+template <int M>
+void launch_fft_m(const RenderParams &p, hipStream_t st) {   // as in iamf_render.hip
+  const dim3 g((unsigned)((p.total + kFftSpan - 1) / kFftSpan), (unsigned)p.n_launch);
+  hipLaunchKernelGGL((fir_fft_kernel<M>), g, dim3(256), sizeof(float) * (size_t)kFftLdsFloats, st, p, p.fir_y, 2 * (int64_t)p.total);
+}
+
 }  // namespace
+
+// the FFT stage alone (fir_fft_kernel); returns 1 if launched
+extern "C" __attribute__((visibility("hidden"))) int iamf_hip_fir_m2b_launch_fft(const void *params, int m, hipStream_t st) {
+  RenderParams p;
+  memcpy(&p, params, sizeof(p));
+  switch (m) {
+    case 2: launch_fft_m<2>(p, st); return 1;
+    case 6: launch_fft_m<6>(p, st); return 1;
+    case 8: launch_fft_m<8>(p, st); return 1;
+    case 10: launch_fft_m<10>(p, st); return 1;
+    case 12: launch_fft_m<12>(p, st); return 1;
+    default: return 0;
+  }
+}
 
 extern "C" __attribute__((visibility("hidden"))) int iamf_hip_fir_m2b_has(int m) {
   return m == 2 || m == 6 || m == 8 || m == 10 || m == 12;

@@ -127,6 +127,9 @@ struct RenderParams {
   const float *fir_pq;      // device: spectra tables of the FFT stage [pairs][16][64] x 4 floats (render_fir_fft.hpp) or nullptr
   const float *fir_tw;      // device: its twiddles [16][64] + [16][4] complex
   const float *fir_zero;    // device: 64 zero floats (what that stage loads for runs past the end of a call)
+  float *fir_y;             // device scratch [n_streams][2][total]: the FFT stage's output when it runs as a kernel of its own
+  const float *fir_id_matrix;   // device: the 2 x 2 identity (feed-major) and its slot map, for the limiter / pack kernel behind it
+  const int32_t *fir_id_feed;
 };
 
 // IAChannel ids (reference IAMF_types.h:61-90; L5/R5 alias L7/R7)
@@ -172,9 +175,13 @@ __device__ __forceinline__ float w4_quot(float n, float d, float r, bool &ok) {
 }
 
 // which HRTF stage a FIR call runs (host): 3 = overlap-save FFT (default), 2 = split-f16 MFMA, 1 = f32 MFMA
+// 4 = the FFT stage as a kernel of its own + the two-channel matrix kernel behind it (default); IAMF_HIP_FIR_FUSED=1 keeps
+// the FFT stage inside render_fast_kernel<M, 2, 3> (one pass over HBM, but the hops of a stream run one pass after the other
+// and the limiter stages at two workgroups per CU: 29 instead of the split's rate)
 inline int fir_stage_choice(const RenderParams &p) {
   if (getenv("IAMF_HIP_FIR_F32")) return 1;
   if (getenv("IAMF_HIP_FIR_F16") && p.fir_h16) return 2;
-  if (p.fir_pq && p.fir_tw && p.fir_zero && (p.frame_size & 63) == 0) return 3;   // its input runs of 64 must not straddle frames
+  if (p.fir_pq && p.fir_tw && p.fir_zero && (p.frame_size & 63) == 0)   // its input runs of 64 must not straddle frames
+    return (p.fir_y && p.fir_id_matrix && !getenv("IAMF_HIP_FIR_FUSED")) ? 4 : 3;
   return p.fir_h16 ? 2 : 1;
 }

@@ -463,9 +463,10 @@ __device__ __forceinline__ const float *fft_y_ptr(const float *scratch_all, int 
 
 // y[e][c0 .. c0 + 3072) of both ears -> the waves' scratch areas (fft_y_ptr).
 // Wave w takes hop w = samples [c0 + 768 w, + 768).  All 256 threads call it; the caller synchronises afterwards.
+// gy != nullptr: the outputs go to global memory instead, planar [2 ears][p.total] for this stream (fir_fft_kernel).
 template <int M>
 __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float *in_s, const float *hist, int c0,
-                                              fft_c32 *scratch_all, const FftTwiddles &tw) {
+                                              fft_c32 *scratch_all, const FftTwiddles &tw, float *gy = nullptr) {
   const int t = threadIdx.x, lane = t & 63, lane_ = lane;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform, and known to be: what follows stays in scalar registers
   const int b0 = c0 + kFftHop * w;   // the hop's first new sample, relative to the call
@@ -593,7 +594,16 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
   // block samples 256 .. 1023 are the hop's 768 outputs: re = left, im = right.  They go to the wave's own scratch, which
   // nobody else touches and the wave itself is done with ([2][768] floats; the last exchange has been read back above).
   fft_wave_sync();
-  {
+  if (gy) {   // (wave-uniform) 64 consecutive floats per store instruction; the call's length is a multiple of 64
+#pragma unroll
+    for (int n1 = 4; n1 < 16; ++n1) {
+      const int m = b0 + 64 * (n1 - 4);
+      if (m < p.total) {
+        __builtin_nontemporal_store(u[n1].x, gy + m + lane);
+        __builtin_nontemporal_store(u[n1].y, gy + p.total + m + lane);
+      }
+    }
+  } else {
     float *y = reinterpret_cast<float *>(S);
 #pragma unroll
     for (int n1 = 4; n1 < 16; ++n1) {
@@ -602,5 +612,31 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
     }
   }
 #undef FFT_FETCH
+}
+
+// The stage as a kernel of its own (round 3, what the batch launches for kind FIR): overlap-save blocks are independent —
+// a hop needs its 1024 input samples and nothing of its neighbours' results — so there is no reason to run them behind one
+// another inside a per-stream workgroup.  Grid (passes of 3072 samples, streams): a workgroup = four waves = four hops; y goes
+// to HBM as planar f32 [stream][2][total], and the limiter / pack of the SAME call is the plain two-channel matrix kernel
+// (render_fast_kernel<2, 2>, identity matrix, four workgroups per CU) over that.  Costs 16 B per sample-frame of extra HBM
+// traffic (y written and read once) and wins back what the fused kernel lost by running the limiter stages at two
+// workgroups per CU and the hops of a stream one pass after the other.
+#ifndef IAMF_FFT_OCC
+#define IAMF_FFT_OCC 2   // workgroups per CU the stage kernel is compiled for (tools/fft_exp.sh: 3 = 168 registers)
+#endif
+template <int M>
+__global__ __launch_bounds__(256, IAMF_FFT_OCC) void fir_fft_kernel(const RenderParams p, float *gy, int64_t gy_stream_stride) {
+  extern __shared__ float fft_lds[];
+  const int s = blockIdx.y + p.stream0, t = threadIdx.x;
+  FftTwiddles tw;
+  fft_load_twiddles(p.fir_tw, t, fft_lds + kFftHops * kFftScratch * 2, tw);
+  __syncthreads();
+  const float *in_s = p.in + (int64_t)s * p.in_stream_stride;
+  const float *hist = p.fir_hist + (int64_t)s * M * kFirHist;
+  fir_stage_fft<M>(p, in_s, hist, kFftSpan * (int)blockIdx.x, reinterpret_cast<fft_c32 *>(fft_lds), tw, gy + (int64_t)s * gy_stream_stride);
+  if (blockIdx.x == 0) {   // input history for the next call: the last 256 samples of [old history | this call's input]
+    float *hn = p.fir_hist_next + (int64_t)s * M * kFirHist;
+    for (int ch = 0; ch < M; ++ch) hn[ch * kFirHist + t] = fir_input(p, in_s, hist, ch, p.total - kFirHist + t);
+  }
 }
 #endif  // __HIPCC__

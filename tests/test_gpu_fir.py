@@ -157,6 +157,13 @@ def test_fft_stage_against_the_two_mfma_stages(hip, monkeypatch):
     x = np.stack([synth.gaussian(870 + s, m, F * fs, 0.12) for s in range(2)])
     h = hrir_set(9, m, taps)
     yf = _fir_stage_output(A, G, h, x, fs, [3, 4], taps)
+    # the same stage fused into the limiter kernel (IAMF_HIP_FIR_FUSED=1) instead of running as a kernel of its own in
+    # front of the two-channel matrix kernel: the same arithmetic, the same floats
+    monkeypatch.setenv("IAMF_HIP_FIR_FUSED", "1")
+    yfused = _fir_stage_output(A, G, h, x, fs, [3, 4], taps)
+    monkeypatch.delenv("IAMF_HIP_FIR_FUSED")
+    for s in range(2):
+        assert np.array_equal(yf[s], yfused[s]), s
     monkeypatch.setenv("IAMF_HIP_FIR_F16", "1")
     y16 = _fir_stage_output(A, G, h, x, fs, [3, 4], taps)
     monkeypatch.delenv("IAMF_HIP_FIR_F16")
@@ -170,3 +177,23 @@ def test_fft_stage_against_the_two_mfma_stages(hip, monkeypatch):
               % (s, ef, e16, e32, float(np.abs(yf[s] - y32[s]).max())))
         assert ef <= 2.0 ** -19 and e16 <= 2.0 ** -19 and e32 <= 2.0 ** -19
         assert not np.array_equal(yf[s], y16[s])   # it really is another stage that ran
+
+
+@pytest.mark.parametrize("calls", [[24, 3, 37], [10, 10]])
+def test_many_streams_long_calls_hot_programme(hip, calls):
+    """64 streams, calls of 24 / 3 / 37 frames (eight passes of the stage kernel, one, and a partial last one), a programme
+    the limiter works on: the oracle's limiter + pack run on the stage's own output must reproduce the PCM bit for bit —
+    the stage kernel and the two-channel matrix kernel behind it see the same y."""
+    A, G = hip
+    fs, m, taps, S = 1024, 16, 256, 64
+    F = sum(calls)
+    x = np.stack([synth.hot(930 + s, m, F * fs, sigma=0.2, burst_amp=1.2, burst_phase=300 + 37 * s, burst_period=2500)
+                  for s in range(S)])
+    h = hrir_set(11, m, taps)
+    kw = dict(frame_size=fs, limiter=True, flush=True, frames_per_call=calls, fir_taps=taps)
+    got = G.hip_render(A.fir_matrix(h), 2, x, fmt=A.FMT_S16, **kw)
+    y_dev = G.hip_render(A.fir_matrix(h), 2, x, fmt=A.FMT_F32, threshold_db=60.0, **kw)
+    for s in (0, 31, 63):
+        z, _ = O.limiter_run(np.ascontiguousarray(y_dev[s].T), [fs] * F)
+        assert np.array_equal(got[s], O.pack(z, 16)), s
+        assert np.abs(y_dev[s]).max() > 1.0

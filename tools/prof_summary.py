@@ -17,13 +17,18 @@ import os
 import sys
 
 
+def ours(name):
+    """the kernels of the hot path (render_*_kernel, and the HRTF stage's fir_fft_kernel)"""
+    return "render" in name or "fir_fft" in name
+
+
 def main():
     src, out = sys.argv[1], sys.argv[2]
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     summary = {}
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
-        keep = [r for r in rows if "render" in r["Name"] or "iamf" in r["Name"]]
+        keep = [r for r in rows if ours(r["Name"]) or "iamf" in r["Name"]]
         keep += [r for r in rows if r not in keep][:4]
         with open(out + "_kernel_stats.csv", "w") as f:
             w = csv.DictWriter(f, fieldnames=rows[0].keys())
@@ -33,7 +38,7 @@ def main():
                 r["Name"] = r["Name"][:120]
                 w.writerow(r)
         for r in keep:
-            if "render" in r["Name"]:
+            if ours(r["Name"]):
                 summary.setdefault("kernels", {})[r["Name"][:80]] = {
                     "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": int(r["MinNs"]),
                     "max_ns": int(r["MaxNs"])}
@@ -44,7 +49,7 @@ def main():
     if steps and traces:
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(traces[0])):
-            if "render" in r["Kernel_Name"]:
+            if ours(r["Kernel_Name"]):
                 per[r["Kernel_Name"][:80]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         for k, v in per.items():
             v.sort()
@@ -65,7 +70,7 @@ def main():
         agg = collections.defaultdict(list)
         meta = {}
         for r in csv.DictReader(open(files[0])):
-            if "render" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+            if ours(r["Kernel_Name"]) and r["Counter_Name"] == ctr:
                 agg[r["Kernel_Name"][:80]].append(float(r["Counter_Value"]))
                 meta[r["Kernel_Name"][:80]] = {"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]),
                                                "lds_block_bytes": int(r["LDS_Block_Size"]),
@@ -98,9 +103,15 @@ def main():
                                      "streams_per_gpu": b["config"].get("streams_per_gpu"), "verified": (b.get("verified") or {}).get("ok"),
                                      "max_lsb": (b.get("verified") or {}).get("max_lsb")}
             alg = b["roofline"].get("algorithmic_bytes_per_launch")
-            for k, t in summary.get("timed_region", {}).items():
-                if alg and b["roofline"].get("kernel", "")[:44] in k:
-                    t["roofline_frac_from_this_profile"] = round(alg / (t["avg_ns"] * 1e-9) / 8e12, 4)
+            tags = b["roofline"].get("kernels") or [b["roofline"].get("kernel", "")]
+            hit = [t for k, t in summary.get("timed_region", {}).items() if any(tag[:44] in k for tag in tags)]
+            if alg and len(hit) == len(tags):
+                if len(hit) == 1:
+                    hit[0]["roofline_frac_from_this_profile"] = round(alg / (hit[0]["avg_ns"] * 1e-9) / 8e12, 4)
+                else:   # a step of several kernels (HRTF: the stage kernel + the limiter kernel): the step = their sum
+                    tot = sum(t["avg_ns"] for t in hit)
+                    summary["step_of_several_kernels"] = {"kernels": tags, "sum_avg_ns": tot,
+                                                          "roofline_frac_from_this_profile": round(alg / (tot * 1e-9) / 8e12, 4)}
         except Exception as e:   # noqa: BLE001
             summary["bench_line"] = {"error": str(e)}
         # the traced command's own line (HIP events under the profiler): the profiler costs the kernels 5-13 % on this pool

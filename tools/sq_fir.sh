@@ -3,15 +3,17 @@ R=$GRAFT_REPO_ROOT
 w=toa_hrtf256_limiter_s16
 for pm in "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD" "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_LDS"; do
   tag=$(echo $pm | cut -c1-18 | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $pm -d $R/gpurun_out/sq4/$tag -o t --output-format csv -- python3 $R/bench.py --workload $w --no-cpu-baseline --frames 64 --steps 3 --warmup 1 --streams 1024 --placement-tries 1 --no-verify --repeats 1 > $R/gpurun_out/sq4/$tag.log 2>&1 || echo fail $tag
+  rocprofv3 --kernel-trace --pmc $pm -d $R/gpurun_out/sq4/$tag -o t --output-format csv -- python3 $R/bench.py --workload $w --no-cpu-baseline --frames 64 --steps 3 --warmup 1 --streams 1024 --placement-tries 1 --no-verify --no-facade --repeats 1 > $R/gpurun_out/sq4/$tag.log 2>&1 || echo fail $tag
 done
 python3 - <<'PY'
 import csv,glob,collections,os
 R=os.environ['GRAFT_REPO_ROOT']
-acc=collections.defaultdict(float); n=collections.Counter()
+acc=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(collections.Counter)
 for f in glob.glob(f'{R}/gpurun_out/sq4/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'render_fast' in r['Kernel_Name']:
-            acc[r['Counter_Name']]+=float(r['Counter_Value']); n[r['Counter_Name']]+=1
-print({k: round(v/max(n[k],1)/1e6,2) for k,v in sorted(acc.items())})
+        for tag in ('fir_fft_kernel', 'render_fast'):   # the stage kernel and the limiter kernel behind it
+            if tag in r['Kernel_Name']:
+                acc[tag][r['Counter_Name']]+=float(r['Counter_Value']); n[tag][r['Counter_Name']]+=1
+for tag in acc:
+    print(tag, {k: round(v/max(n[tag][k],1)/1e6,2) for k,v in sorted(acc[tag].items())}, '(millions per launch)')
 PY
