@@ -30,6 +30,7 @@ from .hipabi import (  # noqa: F401
     dmx_matrix,
     fir_matrix,
     IamfHipError,
+    LpcmLayout,
     Matrix,
     build,
     get_h2m_matrix,
@@ -37,4 +38,5 @@ from .hipabi import (  # noqa: F401
     layout_channels,
     lib,
     lib_path,
+    lpcm_unpack,
 )

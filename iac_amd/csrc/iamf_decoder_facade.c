@@ -223,6 +223,7 @@ struct IAMF_Decoder {
   /* packets of the temporal unit being assembled */
   uint8_t *pkt[2][MAX_SUBSTREAMS];
   uint32_t pkt_len[2][MAX_SUBSTREAMS];
+  uint32_t pkt_cap[2][MAX_SUBSTREAMS]; /* bytes allocated: a packet buffer only ever grows (no allocator call per frame) */
   int pkt_have[2][MAX_SUBSTREAMS];
   uint64_t tu_trim_start, tu_trim_end;
   uint64_t timestamp; /* stream time of the next frame, samples */
@@ -823,6 +824,7 @@ static void free_runtime(struct IAMF_Decoder *d) {
     for (int s = 0; s < MAX_SUBSTREAMS; ++s) {
       free(d->pkt[e][s]);
       d->pkt[e][s] = 0;
+      d->pkt_cap[e][s] = 0;
       d->pkt_have[e][s] = 0;
     }
   }
@@ -1455,10 +1457,14 @@ static int decode_parse(struct IAMF_Decoder *d, const uint8_t *data, int32_t siz
         for (int s = 0; s < d->sel_el[e]->nsub; ++s)
           if (d->sel_el[e]->sub_ids[s] == sid) {
             uint32_t len = o.payload_size - r.pos;
-            uint8_t *b = (uint8_t *)realloc(d->pkt[e][s], len ? len : 1);
-            if (!b) return IAMF_ERR_ALLOC_FAIL;
+            uint8_t *b = d->pkt[e][s];
+            if (!b || len > d->pkt_cap[e][s]) {
+              b = (uint8_t *)realloc(b, len ? len : 1);
+              if (!b) return IAMF_ERR_ALLOC_FAIL;
+              d->pkt[e][s] = b;
+              d->pkt_cap[e][s] = len ? len : 1;
+            }
             memcpy(b, o.payload + r.pos, len);
-            d->pkt[e][s] = b;
             d->pkt_len[e][s] = len;
             d->pkt_have[e][s] = 1;
             if (e == 0 && s == 0) {

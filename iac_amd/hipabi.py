@@ -59,6 +59,11 @@ class RenderArgs(C.Structure):
                 ("d_demix_frames", C.c_void_p), ("demix_sample0", C.c_int32)]
 
 
+class LpcmLayout(C.Structure):   # iamf_hip_lpcm_layout
+    _fields_ = [("sample_bytes", C.c_int32), ("little_endian", C.c_int32), ("channels", C.c_int32), ("frame_size", C.c_int32),
+                ("src_offset", C.c_int32 * 32), ("src_step", C.c_int32 * 32)]
+
+
 class DemixConfig(C.Structure):
     _fields_ = [("layout", C.c_int32), ("n_in", C.c_int32), ("chs_in", C.c_int32 * 12), ("n_gain", C.c_int32),
                 ("gain_ch", C.c_int32 * 12), ("gain", C.c_float * 12), ("frame_offset", C.c_uint32)]
@@ -132,6 +137,8 @@ def lib():
                                                  C.c_void_p]
         L.iamf_hip_resampler_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.iamf_hip_batch_set_projection.argtypes = [C.c_void_p, FP, C.c_int]
+        L.iamf_hip_lpcm_unpack.argtypes = [C.POINTER(LpcmLayout), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                           C.c_int64, C.c_int32, C.c_void_p]
         L.iamf_hip_batch_set_demixer.argtypes = [C.c_void_p, C.POINTER(DemixConfig)]
         L.iamf_hip_demix_state_init.argtypes = [C.POINTER(DemixState)]
         L.iamf_hip_demix_state_init.restype = None
@@ -201,6 +208,16 @@ def fir_matrix(hrir):
     m.mat = h.ctypes.data_as(FP)
     m._keep = h
     return m
+
+
+def lpcm_unpack(layout, d_raw, raw_stream_stride, d_first_count, d_out, out_stream_stride, n_streams, stream=None,
+                first_count_stride=2):
+    """iamf_hip_lpcm_unpack on device pointers (ints); raises IamfHipError on a negative return"""
+    r = lib().iamf_hip_lpcm_unpack(C.byref(layout), d_raw, raw_stream_stride, d_first_count, first_count_stride, d_out,
+                                   out_stream_stride, n_streams, stream)
+    if r < 0:
+        raise IamfHipError(r, "iamf_hip_lpcm_unpack")
+    return r
 
 
 def layout_channels(out_id):

@@ -16,6 +16,7 @@
 #ifndef IAMF_HIP_H
 #define IAMF_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -415,6 +416,44 @@ int iamf_hip_shard_sync(iamf_hip_shard *s);
 const char *iamf_hip_shard_rccl_version(void);
 
 /* ------------------------------------------------------------------------------------------
+ * LPCM sub-stream packets -> planar f32 element PCM, on the device.
+ * Replaces, for a batch of streams, the reference's LPCM decoder (src/iamf_dec/pcm/IAMF_pcm_decoder.c:64-83, 133-149:
+ * sample = integer / 2^(bits-1); 16 / 24 / 32 bit; little-endian, or big-endian with the reference's own byte order for
+ * 24 bit, bitstream.c:204-208) and the re-ordering from audio-layer order to the renderer's channel order behind it
+ * (IAMF_decoder.c:2230-2260).  The caller uploads each stream's packets as they are in the bitstream into a raw region
+ * of `raw_stream_stride` bytes per stream, at offsets of its choosing, and describes where output channel c finds its
+ * samples: sample i of channel c = the `sample_bytes` bytes at  src_offset[c] + (first + i) * src_step[c]  (src_step = bytes
+ * from one sample of the channel to the next: sample_bytes for a mono sub-stream, twice that for a coupled one);
+ * src_offset[c] < 0 = a channel no sub-stream carries: silence.  d_first_count: on the device, per stream two int32,
+ * `first_count_stride` int32 from one stream's pair to the next (2 for a packed array; raw_stream_stride / 4 for pairs
+ * kept at the head of each stream's raw region, so that one upload carries both): the first sample to take (a trimmed
+ * start, iamf_frame_trim IAMF_decoder.c:1361-1381) and the number of samples to write (0: the stream is left alone);
+ * first + count <= frame_size is the caller's to guarantee.  Output:
+ * d_out[stream * out_stream_stride + c * frame_size + i], i < count.  Asynchronous on `stream`.
+ * Returns IAMF_HIP_OK, IAMF_HIP_ERR_BAD_ARG (a layout that could read outside a stream's raw region, frame_size not a
+ * multiple of 4, ...) or IAMF_HIP_ERR_DEVICE.
+ * ---------------------------------------------------------------------------------------- */
+#define IAMF_HIP_LPCM_MAX_CHANNELS 32
+typedef struct iamf_hip_lpcm_layout {
+  int32_t sample_bytes;    /* 2, 3, 4 */
+  int32_t little_endian;   /* 0: big-endian (codec config sample_format_flags, IAMF_pcm_decoder.c:52-60) */
+  int32_t channels;        /* rows written per stream */
+  int32_t frame_size;      /* floats per row */
+  int32_t src_offset[IAMF_HIP_LPCM_MAX_CHANNELS];
+  int32_t src_step[IAMF_HIP_LPCM_MAX_CHANNELS];
+} iamf_hip_lpcm_layout;
+int iamf_hip_lpcm_unpack(const iamf_hip_lpcm_layout *layout, const void *d_raw, int64_t raw_stream_stride,
+                         const int32_t *d_first_count, int64_t first_count_stride, float *d_out, int64_t out_stream_stride,
+                         int32_t n_streams, void *stream);
+
+/* Host -> device by a kernel that reads pinned host memory (hipHostMalloc) over PCIe, 16 bytes per lane: the bytes of a
+ * hipMemcpyAsync without leaving the compute queue, for callers that put a small upload between kernels (a pinned
+ * hipMemcpyAsync costs ~9 us per call and the hand-over between copy engine and compute queue ~12 us each way on
+ * MI355X; the kernel moves 8 MB as fast as the engine).  Both pointers 16-byte aligned, `bytes` a multiple of 16.
+ * IAMF_HIP_OK, IAMF_HIP_ERR_BAD_ARG or IAMF_HIP_ERR_DEVICE. */
+int iamf_hip_upload_by_kernel(const void *h_pinned, void *d_dst, size_t bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * A group of decoder handles: callers of the reference API get the batch renderer's throughput.
  * The reference renders one handle, one frame per call (IAMF_decoder_decode, include/IAMF_decoder.h:82-99, driver loop
  * src/iamf_dec/IAMF_decoder.c:3303-3525).  N configured handles (IAMF_DecoderHandle of this library's IAMF_decoder.h) of ONE
@@ -422,8 +461,9 @@ const char *iamf_hip_shard_rccl_version(void);
  * loudness and parameter streams may differ — that have not decoded yet hand their rendering to one batch:
  *     iamf_hip_decoder_group_decode(g, data, sizes, rsizes, pcm, results)
  * is, for every i, exactly  results[i] = IAMF_decoder_decode(handles[i], data[i], sizes[i], &rsizes[i], pcm[i])
- * (data[i] == NULL flushes handle i; rsizes may be NULL): parsing, LPCM unpacking and the parameter timelines run per
- * handle on `host_threads` threads (0 = up to 16), then ONE upload, one render launch over the streams that completed a
+ * (data[i] == NULL flushes handle i; rsizes may be NULL): parsing and the parameter timelines run per handle on
+ * `host_threads` threads (0 = up to 16), which also copy each handle's LPCM packets, as they are, into pinned staging; then
+ * ONE upload, the device unpacks (iamf_hip_lpcm_unpack above), one render launch over the streams that completed a
  * temporal unit, one download.  The handles need not advance in step.  While grouped, a handle refuses
  * IAMF_decoder_decode / _configure / _close with IAMF_ERR_INVALID_STATE; destroying the group releases the handles
  * (which are then closed with IAMF_decoder_close as usual).  Returns IAMF_OK, or for create: IAMF_ERR_BAD_ARG (handles
@@ -432,6 +472,10 @@ const char *iamf_hip_shard_rccl_version(void);
  * ---------------------------------------------------------------------------------------- */
 typedef struct iamf_hip_decoder_group iamf_hip_decoder_group;
 int iamf_hip_decoder_group_create(void *const *handles, int n, int host_threads, iamf_hip_decoder_group **out);
+/* where the group's calls spent their time so far, seconds: [0] host parsing + packet staging (the thread pool), [1] enqueueing
+ * the uploads, the unpack and render launches and the download, [2] waiting for the device, [3] handing every handle its PCM;
+ * *rounds (may be NULL) = calls of iamf_hip_decoder_group_decode.  IAMF_OK or IAMF_ERR_BAD_ARG. */
+int iamf_hip_decoder_group_times(const iamf_hip_decoder_group *g, double *seconds4, int64_t *rounds);
 int iamf_hip_decoder_group_decode(iamf_hip_decoder_group *g, const uint8_t *const *data, const int32_t *sizes,
                                   uint32_t *rsizes, void *const *pcm, int32_t *results);
 void iamf_hip_decoder_group_destroy(iamf_hip_decoder_group *g);

@@ -24,6 +24,7 @@ hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t st) {
   (void)k; (void)st; memcpy(d, s, n); return hipSuccess;
 }
+hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st) { (void)st; memset(d, v, n); return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)calloc(1, 8); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
@@ -134,6 +135,31 @@ int iamf_hip_batch_flush_range(iamf_hip_batch *b, void *pcm, int64_t cap, void *
 }
 int iamf_hip_batch_flush(iamf_hip_batch *b, void *pcm, int64_t cap, void *st) {
   return iamf_hip_batch_flush_range(b, pcm, cap, st, 0, b->cfg.n_streams);
+}
+int iamf_hip_upload_by_kernel(const void *h, void *d, size_t n, void *st) {
+  (void)st;
+  if (!h || !d || !n || (n & 15)) return IAMF_HIP_ERR_BAD_ARG;
+  memcpy(d, h, n);
+  return IAMF_HIP_OK;
+}
+/* the device unpacker's reads and writes, byte for byte, so that ASan sees the group's raw rows and layout */
+int iamf_hip_lpcm_unpack(const iamf_hip_lpcm_layout *lay, const void *d_raw, int64_t raw_stride, const int32_t *fc, int64_t fcs,
+                         float *out, int64_t out_stride, int32_t n, void *st) {
+  (void)st;
+  if (!lay || !d_raw || !fc || !out || n <= 0 || lay->channels <= 0 || lay->channels > IAMF_HIP_LPCM_MAX_CHANNELS) return IAMF_HIP_ERR_BAD_ARG;
+  for (int s = 0; s < n; ++s)
+    for (int c = 0; c < lay->channels; ++c)
+      for (int i = 0; i < fc[s * fcs + 1]; ++i) {
+        float v = 0.f;
+        if (lay->src_offset[c] >= 0) {
+          const uint8_t *p = (const uint8_t *)d_raw + (int64_t)s * raw_stride + lay->src_offset[c] + (int64_t)(fc[s * fcs] + i) * lay->src_step[c];
+          int acc = 0;
+          for (int k = 0; k < lay->sample_bytes; ++k) acc += p[k];
+          v = (float)acc;
+        }
+        out[(int64_t)s * out_stride + (int64_t)c * lay->frame_size + i] = v;
+      }
+  return IAMF_HIP_OK;
 }
 int iamf_hip_resampler_create(int ns, int ch, int in, int out, iamf_hip_resampler **r) {
   (void)ns;
