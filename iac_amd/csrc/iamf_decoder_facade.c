@@ -219,7 +219,7 @@ struct IAMF_Decoder {
   float rec_gain[12];
   uint32_t layer_rec_flags[MAX_LAYERS]; /* latest recon-gain block, per layer (ctx->conf_s[i].recon_gain) */
   float layer_rec_gain[MAX_LAYERS][12];
-  iamf_hip_demix_frame *d_demix;
+  iamf_hip_demix_frame *h_demix; /* pinned */
   /* packets of the temporal unit being assembled */
   uint8_t *pkt[2][MAX_SUBSTREAMS];
   uint32_t pkt_len[2][MAX_SUBSTREAMS];
@@ -228,10 +228,13 @@ struct IAMF_Decoder {
   uint64_t tu_trim_start, tu_trim_end;
   uint64_t timestamp; /* stream time of the next frame, samples */
   /* buffers */
-  float *h_in[2], *d_in[2], *h_ramp[3], *d_ramp[3], *d_mid, *d_res;
+  /* pinned host memory that the kernels read and write directly (a frame is 64 KB in, 4 KB out: over PCIe inside the
+   * one render launch, instead of three copies around it — each ~9 us of call and ~12 us of engine hand-over) */
+  float *h_in[2], *h_ramp[3], *d_mid, *d_res;
+  float gain_set[2]; /* element / output constant gains the batch holds (iamf_hip_batch_set_gains synchronises: only on change) */
   float *tmp; /* [MAX_SUBSTREAMS * 2][frame_size] unpack scratch */
-  iamf_hip_dmx_frame *d_dmx;
-  void *d_pcm;
+  iamf_hip_dmx_frame *h_dmx; /* pinned */
+  void *h_pcm; /* pinned: the render kernels write it, decode copies the caller's share out */
   size_t pcm_cap;
   hipStream_t stream;
   int flushed;
@@ -819,8 +822,7 @@ static void free_runtime(struct IAMF_Decoder *d) {
   d->rs = 0;
   for (int e = 0; e < 2; ++e) {
     if (d->h_in[e]) (void)hipHostFree(d->h_in[e]);
-    if (d->d_in[e]) (void)hipFree(d->d_in[e]);
-    d->h_in[e] = d->d_in[e] = 0;
+    d->h_in[e] = 0;
     for (int s = 0; s < MAX_SUBSTREAMS; ++s) {
       free(d->pkt[e][s]);
       d->pkt[e][s] = 0;
@@ -830,20 +832,19 @@ static void free_runtime(struct IAMF_Decoder *d) {
   }
   for (int i = 0; i < 3; ++i) {
     if (d->h_ramp[i]) (void)hipHostFree(d->h_ramp[i]);
-    if (d->d_ramp[i]) (void)hipFree(d->d_ramp[i]);
-    d->h_ramp[i] = d->d_ramp[i] = 0;
+    d->h_ramp[i] = 0;
   }
   free(d->tmp);
   d->tmp = 0;
   if (d->d_mid) (void)hipFree(d->d_mid);
   if (d->d_res) (void)hipFree(d->d_res);
-  if (d->d_dmx) (void)hipFree(d->d_dmx);
-  if (d->d_demix) (void)hipFree(d->d_demix);
-  d->d_demix = 0;
-  if (d->d_pcm) (void)hipFree(d->d_pcm);
+  if (d->h_dmx) (void)hipHostFree(d->h_dmx);
+  if (d->h_demix) (void)hipHostFree(d->h_demix);
+  d->h_demix = 0;
+  if (d->h_pcm) (void)hipHostFree(d->h_pcm);
   d->d_mid = d->d_res = 0;
-  d->d_dmx = 0;
-  d->d_pcm = 0;
+  d->h_dmx = 0;
+  d->h_pcm = 0;
   if (d->stream) (void)hipStreamDestroy(d->stream);
   d->stream = 0;
   d->configured = 0;
@@ -1076,7 +1077,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
     d->dmx_mode = -1;
     for (int i = 0; i < d->nparam; ++i)
       if (e0->has_demix && d->param[i].id == e0->demix_pid) d->demix_p = &d->param[i];
-    if (hipMalloc((void **)&d->d_demix, sizeof(iamf_hip_demix_frame)) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+    if (hipHostMalloc((void **)&d->h_demix, sizeof(iamf_hip_demix_frame), 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
   }
   if (p->nel == 2 && d->sel_el[1]->amb_projection) return IAMF_ERR_UNIMPLEMENTED;
   if (p->nel == 2) {
@@ -1119,16 +1120,15 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   if (!d->tmp) return IAMF_ERR_ALLOC_FAIL;
   for (int e = 0; e < p->nel; ++e) {
     size_t bytes = sizeof(float) * (size_t)element_in_channels(d->sel_el[e]) * d->frame_size;
-    if (hipHostMalloc((void **)&d->h_in[e], bytes, 0) != hipSuccess || hipMalloc((void **)&d->d_in[e], bytes) != hipSuccess)
-      return IAMF_ERR_ALLOC_FAIL;
+    if (hipHostMalloc((void **)&d->h_in[e], bytes, 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+    memset(d->h_in[e], 0, bytes);
   }
   for (int i = 0; i < 3; ++i)
-    if (hipHostMalloc((void **)&d->h_ramp[i], sizeof(float) * d->frame_size, 0) != hipSuccess ||
-        hipMalloc((void **)&d->d_ramp[i], sizeof(float) * d->frame_size) != hipSuccess)
-      return IAMF_ERR_ALLOC_FAIL;
-  if (hipMalloc((void **)&d->d_dmx, sizeof(iamf_hip_dmx_frame)) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+    if (hipHostMalloc((void **)&d->h_ramp[i], sizeof(float) * d->frame_size, 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+  if (hipHostMalloc((void **)&d->h_dmx, sizeof(iamf_hip_dmx_frame), 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
   d->pcm_cap = (size_t)4 * ((size_t)d->info.max_frame_size * d->pcm_stride + d->pcm_extra);
-  if (hipMalloc(&d->d_pcm, d->pcm_cap) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+  if (hipHostMalloc(&d->h_pcm, d->pcm_cap, 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+  d->gain_set[0] = d->gain_set[1] = 1.f; /* what iamf_hip_batch_create starts with */
   if (resample) {
     int cap = iamf_hip_resampler_out_capacity(d->rs, (int)d->frame_size) + 512;
     if (hipMalloc((void **)&d->d_mid, sizeof(float) * d->frame_size * d->out_channels) != hipSuccess ||
@@ -1231,6 +1231,36 @@ static float lpcm_sample(const struct IAMF_Decoder *d, const uint8_t *p) { /* pc
   }
 }
 
+/* n samples of one channel, `step` bytes apart, -> f32: lpcm_sample with the format decided once per row (the per-sample
+ * form cost 1.5-3 ns a sample, most of a single-handle call once the copies around the launch were gone) */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__) && !defined(__SANITIZE_ADDRESS__)
+__attribute__((target_clones("avx2", "default"), optimize("O3")))
+#endif
+static void lpcm_row(const struct IAMF_Decoder *d, const uint8_t *p, int step, int n, float *out) {
+  if (d->sample_size == 16 && d->little_endian) {
+    if (step == 2) {
+      for (int i = 0; i < n; ++i) {
+        int16_t v;
+        memcpy(&v, p + 2 * (size_t)i, 2);
+        out[i] = v / (float)(1 << 15);
+      }
+    } else {
+      for (int i = 0; i < n; ++i) {
+        int16_t v;
+        memcpy(&v, p + (size_t)i * step, 2);
+        out[i] = v / (float)(1 << 15);
+      }
+    }
+  } else if (d->sample_size == 16) {
+    for (int i = 0; i < n; ++i) {
+      const uint8_t *q = p + (size_t)i * step;
+      out[i] = (int16_t)(q[1] | (q[0] << 8)) / (float)(1 << 15);
+    }
+  } else {
+    for (int i = 0; i < n; ++i) out[i] = lpcm_sample(d, p + (size_t)i * step);
+  }
+}
+
 /* substreams -> planar f32 in the order the renderer expects; returns samples per channel */
 static int unpack_element(struct IAMF_Decoder *d, int ei) {
   const Element *e = d->sel_el[ei];
@@ -1255,8 +1285,7 @@ static int unpack_element(struct IAMF_Decoder *d, int ei) {
     const int n = (int)(d->pkt_len[ei][s] / (uint32_t)(w * bps));
     if (ns < 0) ns = n;
     if (n != ns || n > fs) return IAMF_ERR_INVALID_PACKET;
-    for (int i = 0; i < n; ++i)
-      for (int k = 0; k < w; ++k) tmp[(size_t)(c + k) * fs + i] = lpcm_sample(d, d->pkt[ei][s] + (size_t)(i * w + k) * bps);
+    for (int k = 0; k < w; ++k) lpcm_row(d, d->pkt[ei][s] + (size_t)k * bps, w * bps, n, tmp + (size_t)(c + k) * fs);
     c += w;
   }
   if (ns < 0) return IAMF_ERR_INVALID_PACKET; /* no sub-stream at all: nothing fixed the sample count */
@@ -1315,8 +1344,6 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     const int ch = element_in_channels(d->sel_el[e]);
     if (s0)
       for (int c = 0; c < ch; ++c) memmove(d->h_in[e] + (size_t)c * fs, d->h_in[e] + (size_t)c * fs + s0, sizeof(float) * keep);
-    if (hipMemcpyAsync(d->d_in[e], d->h_in[e], sizeof(float) * ch * fs, hipMemcpyHostToDevice, d->stream) != hipSuccess)
-      return IAMF_ERR_INTERNAL;
   }
   /* mix gains of this frame */
   {
@@ -1332,39 +1359,39 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
         ramp[i] = 0;
         cgain[i] = 1.f;
       }
-      if (!ramp[i]) /* element 1 takes its constant through the ramp: x * positive constant is the same product */
+      if (!ramp[i] && i == 1) /* element 1 takes its constant through the ramp: x * positive constant is the same product */
         for (int k = 0; k < keep; ++k) d->h_ramp[i][k] = cgain[i];
-      if (hipMemcpyAsync(d->d_ramp[i], d->h_ramp[i], sizeof(float) * keep, hipMemcpyHostToDevice, d->stream) != hipSuccess)
-        return IAMF_ERR_INTERNAL;
     }
   }
-  a.d_in = d->d_in[0];
+  a.d_in = d->h_in[0];
   a.in_stream_stride = a.in_frame_stride = (int64_t)element_in_channels(d->sel_el[0]) * fs;
   if (d->sel->nel > 1) {
-    a.d_in2 = d->d_in[1];
+    a.d_in2 = d->h_in[1];
     a.in2_stream_stride = a.in2_frame_stride = (int64_t)d->sel_el[1]->channels * fs;
   }
   /* constant gains go through iamf_frame_gain's rule (only if != 1 and > 0); ramps unconditionally */
   {
     float eg = ramp[0] ? 1.f : cgain[0], og = ramp[2] ? 1.f : cgain[2];
-    if (iamf_hip_batch_set_gains(d->batch, &eg, &og, 0)) return IAMF_ERR_INTERNAL;
-    if (ramp[0]) a.d_element_ramp = d->d_ramp[0];
-    if (ramp[2]) a.d_output_ramp = d->d_ramp[2];
-    if (d->sel->nel > 1) a.d_element2_ramp = d->d_ramp[1]; /* element 1: constant or ramp, both exact */
+    if (eg != d->gain_set[0] || og != d->gain_set[1]) {
+      if (iamf_hip_batch_set_gains(d->batch, &eg, &og, 0)) return IAMF_ERR_INTERNAL;
+      d->gain_set[0] = eg;
+      d->gain_set[1] = og;
+    }
+    if (ramp[0]) a.d_element_ramp = d->h_ramp[0];
+    if (ramp[2]) a.d_output_ramp = d->h_ramp[2];
+    if (d->sel->nel > 1) a.d_element2_ramp = d->h_ramp[1]; /* element 1: constant or ramp, both exact */
   }
   a.ramp_stream_stride = fs;
   if (d->use_dmx) { /* IAMF_decoder.c:2574-2583 */
-    iamf_hip_dmx_frame fr;
-    fr.offset = 0;
-    iamf_hip_dmx_coefficients(&d->dmx, fr.prev);
+    iamf_hip_dmx_frame *fr = d->h_dmx;
+    fr->offset = 0;
+    iamf_hip_dmx_coefficients(&d->dmx, fr->prev);
     if (d->dmx_mode > -1) iamf_hip_dmx_set_mode_weight(&d->dmx, d->dmx_mode, -1);
-    iamf_hip_dmx_coefficients(&d->dmx, fr.cur);
-    if (hipMemcpyAsync(d->d_dmx, &fr, sizeof(fr), hipMemcpyHostToDevice, d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
-    a.d_dmx_frames = d->d_dmx;
+    iamf_hip_dmx_coefficients(&d->dmx, fr->cur);
+    a.d_dmx_frames = fr;
   }
   if (d->use_demix) { /* iamf_stream_scale_decoder_demix, IAMF_decoder.c:2324-2349 */
     const Element *e0 = d->sel_el[0];
-    iamf_hip_demix_frame fr;
     if (e0->layer[d->demix_layer].recon_flag) { /* demixer_set_recon_gain, demixer.c:620-634 */
       const uint32_t lf = d->layer_rec_flags[d->demix_layer];
       const int cnt = popcount32(lf);
@@ -1375,16 +1402,15 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
       for (int i = 0; i < cnt && i < 12; ++i) d->rec_gain[i] = d->layer_rec_gain[d->demix_layer][i];
     }
     if (d->dmx_mode > -1) iamf_hip_demix_set_info(&d->dmst, d->dmx_mode, -1);
-    iamf_hip_demix_frame_fill(&d->dmst, d->rec_n, d->rec_ch, d->rec_gain, &fr);
-    if (hipMemcpyAsync(d->d_demix, &fr, sizeof(fr), hipMemcpyHostToDevice, d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
-    a.d_demix_frames = d->d_demix;
+    iamf_hip_demix_frame_fill(&d->dmst, d->rec_n, d->rec_ch, d->rec_gain, d->h_demix);
+    a.d_demix_frames = d->h_demix;
     a.demix_sample0 = s0;
   }
   a.n_frames = 1;
   a.n_samples = keep < fs ? keep : 0;
   a.stream = d->stream;
   if (!d->rs) {
-    a.d_pcm = d->d_pcm;
+    a.d_pcm = d->h_pcm;
     a.pcm_stream_stride_bytes = (int64_t)d->pcm_cap;
     n = iamf_hip_batch_render_ex(d->batch, &a);
   } else { /* render (f32) -> resample -> loudness / limiter / pack */
@@ -1396,12 +1422,11 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     n2 = iamf_hip_resampler_process(d->rs, d->d_mid, (int64_t)fs * d->out_channels, n, d->d_res,
                                     (int64_t)(iamf_hip_resampler_out_capacity(d->rs, fs) + 512) * d->out_channels, d->stream);
     if (n2 < 0) return IAMF_ERR_INTERNAL;
-    n = n2 ? iamf_hip_batch_render(d->batch3, d->d_res, 0, d->out_channels, n2, d->d_pcm, (int64_t)d->pcm_cap, d->stream) : 0;
+    n = n2 ? iamf_hip_batch_render(d->batch3, d->d_res, 0, d->out_channels, n2, d->h_pcm, (int64_t)d->pcm_cap, d->stream) : 0;
   }
   if (n < 0) return IAMF_ERR_INTERNAL;
-  if (n > 0 && hipMemcpyAsync(pcm, d->d_pcm, ((size_t)n * d->pcm_stride + d->pcm_extra) * bytes, hipMemcpyDeviceToHost, d->stream) != hipSuccess)
-    return IAMF_ERR_INTERNAL;
   if (hipStreamSynchronize(d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
+  if (n > 0) memcpy(pcm, d->h_pcm, ((size_t)n * d->pcm_stride + d->pcm_extra) * bytes);
   params_time_elapse(d, (uint64_t)keep); /* IAMF_decoder.c:3471: the mixed frame's length */
   d->timestamp += fs;
   d->last_frame = (uint32_t)n;
@@ -1415,7 +1440,7 @@ static int flush_tail(struct IAMF_Decoder *d, void *pcm) { /* iamf_delay_buffer_
   d->flushed = 1;
   if (!d->rs) {
     if (!d->limiter_on) return 0;
-    n = iamf_hip_batch_flush(d->batch, d->d_pcm, (int64_t)d->pcm_cap, d->stream);
+    n = iamf_hip_batch_flush(d->batch, d->h_pcm, (int64_t)d->pcm_cap, d->stream);
   } else {
     const int cap = iamf_hip_resampler_flush_capacity(d->rs);
     const int extra = d->limiter_on ? 240 : 0;
@@ -1423,12 +1448,11 @@ static int flush_tail(struct IAMF_Decoder *d, void *pcm) { /* iamf_delay_buffer_
     if (hipMemsetAsync(d->d_res, 0, sizeof(float) * (cap + extra) * d->out_channels, d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
     n2 = iamf_hip_resampler_flush(d->rs, d->d_res, (int64_t)(cap + extra) * d->out_channels, d->stream);
     if (n2 < 0) return IAMF_ERR_INTERNAL;
-    n = (n2 + extra) ? iamf_hip_batch_render(d->batch3, d->d_res, 0, d->out_channels, n2 + extra, d->d_pcm, (int64_t)d->pcm_cap, d->stream) : 0;
+    n = (n2 + extra) ? iamf_hip_batch_render(d->batch3, d->d_res, 0, d->out_channels, n2 + extra, d->h_pcm, (int64_t)d->pcm_cap, d->stream) : 0;
   }
   if (n < 0) return IAMF_ERR_INTERNAL;
-  if (n > 0 && hipMemcpyAsync(pcm, d->d_pcm, ((size_t)n * d->pcm_stride + d->pcm_extra) * bytes, hipMemcpyDeviceToHost, d->stream) != hipSuccess)
-    return IAMF_ERR_INTERNAL;
   if (hipStreamSynchronize(d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
+  if (n > 0) memcpy(pcm, d->h_pcm, ((size_t)n * d->pcm_stride + d->pcm_extra) * bytes);
   return n;
 }
 
