@@ -759,6 +759,9 @@ def device_info():
     """What rocm-smi says about this rank's card (memory vendor and clocks): the render kernels' rate differs by
     ~13 % between MI355X devices, and this is what can be read in-band about the one measured."""
     import subprocess
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any("ROCPROF" in k.upper() for k in os.environ):
+        # the profiler's preloaded library has initialised the GPU before this process started: no fork + exec here
+        return {"skipped": "under rocprofv3 (see the unprofiled run's read-out)"}
     try:
         out = subprocess.run(["rocm-smi", "--showclocks", "--showmemvendor", "--showtemp", "--showpower",
                               "--showcomputepartition", "--showmemorypartition", "--json"],
