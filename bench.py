@@ -396,7 +396,7 @@ class Workload:
         self.hrir = self.proj = self.mx = None
         if kind == "fir":
             rng = np.random.default_rng(5)
-            hr = (rng.standard_normal((2, in_ch, FIR_TAPS)) * np.exp(-np.arange(FIR_TAPS) / 40.0) * args.hrir_scale).astype(np.float32)
+            hr = (rng.standard_normal((2, in_ch, FIR_TAPS)) * np.exp(-np.arange(FIR_TAPS) / 40.0) * getattr(args, "hrir_scale", HRIR_SCALE_R2)).astype(np.float32)
             mx = A.fir_matrix(hr)
             self.hrir = hr
         elif kind == "dmx":
