@@ -216,7 +216,9 @@ struct iamf_hip_batch {
   float *d_fir_hist[2] = {nullptr, nullptr};
   void *d_fir_h16 = nullptr;    // split-f16 filter tables (render_fir16.hpp)
   float *d_fir_pq = nullptr, *d_fir_tw = nullptr;   // spectra and twiddles of the FFT stage (render_fir_fft.hpp)
-  float *d_fir_zero = nullptr;                      // 64 zero floats for that stage
+  float *d_fir_zero = nullptr;                      // m * frame size zero floats for that stage
+  float *d_fir_pre[2] = {nullptr, nullptr};         // the history at the input's channel stride (RenderParams::fir_pre), or null
+  size_t fir_pre_bytes = 0;
   float *d_fir_y = nullptr;                         // [n_streams][2][total] f32: its output when it runs as its own kernel
   size_t fir_y_floats = 0;
   float *d_fir_id = nullptr;                        // 2 x 2 identity + slot map for the limiter / pack kernel behind it
@@ -268,6 +270,8 @@ int reset_state(iamf_hip_batch *b) {
     const size_t hb = sizeof(float) * (size_t)ns * b->m * 256;
     HIPCHK(hipMemset(b->d_fir_hist[0], 0, hb));
     HIPCHK(hipMemset(b->d_fir_hist[1], 0, hb));
+    for (float *q : b->d_fir_pre)
+      if (q) HIPCHK(hipMemset(q, 0, b->fir_pre_bytes));
   }
   if (b->lfe) {  // lfefilter_init zeroes both histories (h2m_rdr.c:1210-1211)
     HIPCHK(hipMemset(b->d_lfe_state, 0, sizeof(float) * 4 * (size_t)ns));
@@ -310,7 +314,10 @@ void launch_fir_m(const RenderParams &p, dim3 grid, hipStream_t st) {
 template <int M>
 void launch_fft_m(const RenderParams &p, hipStream_t st) {   // render_fir_fft.hpp: fir_fft_kernel
   const dim3 g((unsigned)((p.total + kFftSpan - 1) / kFftSpan), (unsigned)p.n_launch);
-  hipLaunchKernelGGL((fir_fft_kernel<M>), g, dim3(256), sizeof(float) * (size_t)kFftLdsFloats, st, p, p.fir_y, 2 * (int64_t)p.total);
+  if ((M & 1) == 0 && p.fir_pre && p.fir_pre_next && !getenv("IAMF_HIP_FIR_GENERAL_FETCH"))
+    hipLaunchKernelGGL((fir_fft_kernel<M, (M & 1) == 0>), g, dim3(256), sizeof(float) * (size_t)kFftLdsFloats, st, p, p.fir_y, 2 * (int64_t)p.total);
+  else
+    hipLaunchKernelGGL((fir_fft_kernel<M, false>), g, dim3(256), sizeof(float) * (size_t)kFftLdsFloats, st, p, p.fir_y, 2 * (int64_t)p.total);
 }
 
 template <int M>
@@ -649,6 +656,8 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int
     p.fir_pq = b->d_fir_pq;
     p.fir_tw = b->d_fir_tw;
     p.fir_zero = b->d_fir_zero;
+    p.fir_pre = b->d_fir_pre[b->fir_cur];
+    p.fir_pre_next = b->d_fir_pre[b->fir_cur ^ 1];
     if (a.d_in && b->d_fir_pq && (b->cfg.frame_size & 63) == 0 && !getenv("IAMF_HIP_FIR_FUSED") && !getenv("IAMF_HIP_FIR_F16") &&
         !getenv("IAMF_HIP_FIR_F32")) {
       // the FFT stage's output of this call, [n_streams][2][total] (grows with the largest call seen)
@@ -981,8 +990,17 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
       CREATE_CHK(hipMemcpy(b->d_fir_pq, pq.data(), pq.size() * sizeof(float), hipMemcpyHostToDevice));
       CREATE_CHK(hipMalloc(&b->d_fir_tw, tw.size() * sizeof(float)));
       CREATE_CHK(hipMemcpy(b->d_fir_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
-      CREATE_CHK(hipMalloc(&b->d_fir_zero, 64 * sizeof(float)));
-      CREATE_CHK(hipMemset(b->d_fir_zero, 0, 64 * sizeof(float)));
+      const size_t zf = (size_t)(mx.m > 0 ? mx.m : 1) * (size_t)(cfg->frame_size > 64 ? cfg->frame_size : 64);
+      CREATE_CHK(hipMalloc(&b->d_fir_zero, zf * sizeof(float)));
+      CREATE_CHK(hipMemset(b->d_fir_zero, 0, zf * sizeof(float)));
+      if (cfg->frame_size >= 1024 && cfg->frame_size % 256 == 0 && mx.m % 2 == 0) {   // fir_fft_kernel<M, true>
+        const int g = cfg->frame_size / 256;
+        b->fir_pre_bytes = sizeof(float) * (size_t)((ns + g - 1) / g) * mx.m * cfg->frame_size;
+        for (float *&q : b->d_fir_pre) {
+          CREATE_CHK(hipMalloc(&q, b->fir_pre_bytes));
+          CREATE_CHK(hipMemset(q, 0, b->fir_pre_bytes));
+        }
+      }
       const float id[4] = {1.f, 0.f, 0.f, 1.f};
       int32_t idf[kMaxOut];
       for (int i = 0; i < kMaxOut; ++i) idf[i] = i < 2 ? i : -1;
@@ -1038,6 +1056,8 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_fir_pq);
   (void)hipFree(b->d_fir_tw);
   (void)hipFree(b->d_fir_zero);
+  (void)hipFree(b->d_fir_pre[0]);
+  (void)hipFree(b->d_fir_pre[1]);
   (void)hipFree(b->d_fir_y);
   (void)hipFree(b->d_fir_id);
   (void)hipFree(b->d_fir_id_feed);

@@ -126,7 +126,13 @@ struct RenderParams {
   float fir_inv_scale;      // 1 / (filter scale * input scale) of those tables
   const float *fir_pq;      // device: spectra tables of the FFT stage [pairs][16][64] x 4 floats (render_fir_fft.hpp) or nullptr
   const float *fir_tw;      // device: its twiddles [16][64] + [16][4] complex
-  const float *fir_zero;    // device: 64 zero floats (what that stage loads for runs past the end of a call)
+  const float *fir_zero;    // device: zero floats, M * frame size of them (what that stage loads for runs past the end of a
+                            // call, at the input's channel stride)
+  // the same history as fir_hist at the INPUT's channel stride, for fir_fft_kernel's two-base fetch (frame size a multiple
+  // of 256 and >= 1024, M even): stream s, channel c, sample j of the last 256 at
+  //   ((s / G) * M + c) * frame_size + (s % G) * 256 + j,   G = frame_size / 256   (G streams share the rows of a slab)
+  const float *fir_pre;
+  float *fir_pre_next;
   float *fir_y;             // device scratch [n_streams][2][total]: the FFT stage's output when it runs as a kernel of its own
   const float *fir_id_matrix;   // device: the 2 x 2 identity (feed-major) and its slot map, for the limiter / pack kernel behind it
   const int32_t *fir_id_feed;

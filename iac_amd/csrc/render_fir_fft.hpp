@@ -40,6 +40,9 @@
 #define FFT_HD __host__ __device__ __forceinline__
 #endif
 
+#ifndef IAMF_FFT_X2_LDS
+#define IAMF_FFT_X2_LDS 0            // 1: exchange 2 through LDS (the first form; kept for A/B builds, tools/fft_exp.sh)
+#endif
 constexpr int kFftN = 1024;          // FFT size
 constexpr int kFftHop = 768;         // new samples per hop; kFftN - kFftHop = 256 >= taps
 constexpr int kFftHops = 4;          // hops per pass = waves per workgroup
@@ -61,26 +64,34 @@ FFT_HD fft_c32 fft_mk(float re, float im) {
 // register.  Written as inline asm because the compiler builds the broadcast pairs and the swapped operand as values of
 // their own (for loop-invariant twiddles it even hoists them: 60 registers, which it then spills).
 #if defined(__HIP_DEVICE_COMPILE__)
+// (Both instructions of a product in ONE asm statement: between two statements the compiler's hazard recogniser puts an
+// s_nop — it takes op_sel_hi of a packed-f32 instruction for the 16-bit "dst_sel" forwarding hazard of gfx940 — which cost
+// 70 issue slots per pair of channels.)
 // a * b = (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
 __device__ __forceinline__ fft_c32 fft_cmul(fft_c32 a, fft_c32 b) {
-  fft_c32 t, d;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                                      // (a.x b.x, a.x b.y)
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));  // (-a.y b.y, a.y b.x) + t
+  fft_c32 d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"                                              // (a.x b.x, a.x b.y)
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"               // + (-a.y b.y, a.y b.x)
+      : "=&v"(d)
+      : "v"(a), "v"(b));
   return d;
 }
 // a * conj(b) = (a.x b.x + a.y b.y, -a.x b.y + a.y b.x)
 __device__ __forceinline__ fft_c32 fft_cmul_conj(fft_c32 a, fft_c32 b) {
-  fft_c32 t, d;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                          // (a.x b.x, -a.x b.y)
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(t));           // (a.y b.y, a.y b.x) + t
+  fft_c32 d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"                                 // (a.x b.x, -a.x b.y)
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"                              // + (a.y b.y, a.y b.x)
+      : "=&v"(d)
+      : "v"(a), "v"(b));
   return d;
 }
 // acc + a * b
 __device__ __forceinline__ fft_c32 fft_cmac(fft_c32 acc, fft_c32 a, fft_c32 b) {
-  fft_c32 t, d;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(b), "v"(acc));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));
-  return d;
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+      : "+v"(acc)
+      : "v"(a), "v"(b));
+  return acc;
 }
 // a + w d and a - w d with w = -i (INV = false) or +i (INV = true):  -i d = (d.y, -d.x)
 template <bool INV>
@@ -241,6 +252,62 @@ FFT_HD void fft_x2_read(fft_c32 (&z)[16], int lane, P S) {          // into L2: 
 #pragma unroll
   for (int r = 0; r < 16; ++r) z[r] = S[fft_e2(k1, r >> 2, r & 3, j)];
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// Exchange 2 without LDS.  It is a 4 x 4 transpose inside every quad of lanes — lane (k1, n3) holds z[4 g + j], lane
+// (k1, j) wants z[4 g + n3] — i.e. two swaps of a lane-index bit with a register-index bit, and a swap costs ONE
+// instruction per register: v_cndmask_b32 with a DPP quad_perm on its first source ("my own value, or my neighbour's other
+// register").  64 VALU instructions per transform instead of 16 ds_write_b64 + 16 ds_read_b64 and a round trip through the
+// LDS queue: the stage kernel ran its VALU 49 % of the time with the LDS store path (ds_write_b64: ~85 B/clk per CU) as
+// the second limit, so the transform trades a resource it is short of twice for one it has to spare between the waits.
+// D = VCC ? src1 : dpp(src0).  Inline asm: the masks go through VCC (the DPP encoding has no SGPR-pair operand), and a DPP
+// source must not have been written by the two instructions before it (the assembler adds no wait states inside asm): the
+// order below keeps three instructions between any write and its DPP read, s_nop covers the code in front.
+__device__ __forceinline__ void fft_quad_transpose2(float &a0, float &a1, float &a2, float &a3, float &b0, float &b1, float &b2,
+                                                    float &b3) {
+  float s0, s1, s2, s3, t0, t1, t2, t3;
+  const uint64_t me = 0x5555555555555555ull, mo = 0xaaaaaaaaaaaaaaaaull, ml = 0x3333333333333333ull, mh = 0xccccccccccccccccull;
+  asm volatile(
+      "s_nop 1\n\t"
+      "s_mov_b64 vcc, %[me]\n\t"
+      "v_cndmask_b32_dpp %[s0], %[a1], %[a0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[s2], %[a3], %[a2], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[t0], %[b1], %[b0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[t2], %[b3], %[b2], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b64 vcc, %[mo]\n\t"
+      "v_cndmask_b32_dpp %[s1], %[a0], %[a1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[s3], %[a2], %[a3], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[t1], %[b0], %[b1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[t3], %[b2], %[b3], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b64 vcc, %[ml]\n\t"
+      "v_cndmask_b32_dpp %[a0], %[s2], %[s0], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[b0], %[t2], %[t0], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[a1], %[s3], %[s1], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[b1], %[t3], %[t1], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b64 vcc, %[mh]\n\t"
+      "v_cndmask_b32_dpp %[a2], %[s0], %[s2], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[b2], %[t0], %[t2], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[a3], %[s1], %[s3], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %[b3], %[t1], %[t3], vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [b0] "+v"(b0), [b1] "+v"(b1), [b2] "+v"(b2), [b3] "+v"(b3),
+        [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2), [s3] "=&v"(s3), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+      : [me] "s"(me), [mo] "s"(mo), [ml] "s"(ml), [mh] "s"(mh)
+      : "vcc");
+}
+__device__ __forceinline__ void fft_x2_quads(fft_c32 (&z)[16]) {   // both directions: the transpose is its own inverse
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float a0 = z[4 * g].x, a1 = z[4 * g + 1].x, a2 = z[4 * g + 2].x, a3 = z[4 * g + 3].x;
+    float b0 = z[4 * g].y, b1 = z[4 * g + 1].y, b2 = z[4 * g + 2].y, b3 = z[4 * g + 3].y;
+    fft_quad_transpose2(a0, a1, a2, a3, b0, b1, b2, b3);
+    z[4 * g] = fft_mk(a0, b0);
+    z[4 * g + 1] = fft_mk(a1, b1);
+    z[4 * g + 2] = fft_mk(a2, b2);
+    z[4 * g + 3] = fft_mk(a3, b3);
+  }
+}
+#elif defined(__HIPCC__)
+__device__ void fft_x2_quads(fft_c32 (&z)[16]);   // (the host pass of a .hip file only parses the device functions that call it)
+#endif
 FFT_HD void fft_fwd_c(fft_c32 (&z)[16]) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) fft_dft4<false>(z[4 * g], z[4 * g + 1], z[4 * g + 2], z[4 * g + 3]);
@@ -423,12 +490,12 @@ __device__ __forceinline__ void fft_wave_sync() {   // LDS accesses of one wave 
 // ra_hi) holds run n1's address for channel 0 (fir_stage_fft); v_readlane brings it to scalar registers where it is used,
 // so every load is (scalar base) + 4 lane and the 16 runs cost two vector registers instead of 32 scalar ones; which runs
 // are history / zeros is one bit each of two scalar masks.
-template <int M>
+template <int M, int N1A = 0, int N1B = 16>
 __device__ __forceinline__ void fft_fetch(int pr, fft_c32 (&z)[16], unsigned ra_lo, unsigned ra_hi, unsigned zmask,
                                           unsigned hmask, unsigned cs_in, uint64_t a_zero, unsigned lo) {
   const int a = 2 * pr, b = 2 * pr + 1;
 #pragma unroll
-  for (int n1 = 0; n1 < 16; ++n1) {
+  for (int n1 = N1A; n1 < N1B; ++n1) {
     const uint64_t r0 = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)ra_hi, n1) << 32) |
                         (unsigned)__builtin_amdgcn_readlane((int)ra_lo, n1);
     // channel stride of the run in bytes: the frame size in the call's input, 256 samples in the history, 0 in the zeros
@@ -464,9 +531,41 @@ __device__ __forceinline__ const float *fft_y_ptr(const float *scratch_all, int 
 // y[e][c0 .. c0 + 3072) of both ears -> the waves' scratch areas (fft_y_ptr).
 // Wave w takes hop w = samples [c0 + 768 w, + 768).  All 256 threads call it; the caller synchronises afterwards.
 // gy != nullptr: the outputs go to global memory instead, planar [2 ears][p.total] for this stream (fir_fft_kernel).
-template <int M>
+// The same fetch where the 1024-sample window of a hop consists of at most TWO stretches that are contiguous per channel
+// and share one channel stride (frame size a multiple of 256 and >= 1024: the window crosses at most one frame boundary,
+// and "before the call" / "past its end" begin at one; the history is kept at the input's stride for this, RenderParams::
+// fir_pre; the zeros too).  Run n1 of channel c is then  base + 256 n1 + c * stride  with base one of two wave-uniform
+// addresses: a scalar compare + select per run, the run's 256 n1 in the instruction's offset field and the channel in the
+// lane's offset register (two additions per pair).  The general form above spends per LOAD two v_readlane, the wait states
+// between a VALU-written SGPR and its use as an address, and a 64-bit scalar multiply-add — 240 of the ~660 instruction
+// slots of a pair step; without its sample fetch the stage kernel took 1.06 instead of 1.51 ms (tools/fft_exp.sh).
+template <int M, int N1A, int N1B>
+__device__ __forceinline__ void fft_fetch2(int pr, fft_c32 (&z)[16], uint64_t base1, uint64_t base2p, int kseg, unsigned cs4,
+                                           unsigned lo4) {
+  typedef const char __attribute__((address_space(1))) *gbptr;
+  typedef const float __attribute__((address_space(1))) *gptr;
+  int k = kseg;
+  asm volatile("" : "+s"(k));   // per step: sixteen selected bases hoisted out of the pair loop would not fit the scalar registers
+  const unsigned oa = lo4 + (unsigned)(2 * pr) * cs4, ob = oa + cs4;
+#pragma unroll
+  for (int n1 = N1A; n1 < N1B; ++n1) {
+    const gbptr base = (gbptr)(n1 < k ? base1 : base2p);
+    const gptr sa = (gptr)(base + 256 * n1 + oa), sb = (gptr)(base + 256 * n1 + ob);
+    float va, vb;
+    if (n1 >= 4 && n1 < 12) {   // read by this wave alone: streamed past the caches
+      va = __builtin_nontemporal_load(sa);
+      vb = __builtin_nontemporal_load(sb);
+    } else {                    // the hop's first and last 256 samples are also the neighbouring hops' overlap
+      va = *sa;
+      vb = *sb;
+    }
+    z[n1] = fft_mk(va, vb);
+  }
+}
+template <int M, bool FAST2 = false>
 __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float *in_s, const float *hist, int c0,
-                                              fft_c32 *scratch_all, const FftTwiddles &tw, float *gy = nullptr) {
+                                              fft_c32 *scratch_all, const FftTwiddles &tw, float *gy = nullptr,
+                                              const float *pre = nullptr) {
   const int t = threadIdx.x, lane = t & 63, lane_ = lane;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform, and known to be: what follows stays in scalar registers
   const int b0 = c0 + kFftHop * w;   // the hop's first new sample, relative to the call
@@ -507,7 +606,38 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
   }
   const unsigned cs_in = 4u * (unsigned)p.frame_size;
   const unsigned lo = (unsigned)lane;
-#define FFT_FETCH(pr, z) fft_fetch<M>(pr, z, ra_lo, ra_hi, zmask, hmask, cs_in, a_zero, lo)
+  // FAST2: the two stretches of the window (wave-uniform; see fft_fetch2)
+  uint64_t base1 = 0, base2p = 0;
+  int kseg = 16;
+  if constexpr (FAST2) {
+    const int fs = p.frame_size;
+    const int n0 = b0 - (kFftN - kFftHop);   // the window's first sample: -256 in a call's first hop, else >= 0
+    int64_t nb = 0;                          // first sample of the second stretch
+    if (n0 < 0) {
+      base1 = reinterpret_cast<uint64_t>(pre);   // `pre` = the stream's sample -256 of channel 0
+    } else {
+      const int f0 = n0 / fs, i0 = n0 - f0 * fs;
+      base1 = reinterpret_cast<uint64_t>(in_s + (int64_t)f0 * p.in_frame_stride + i0);
+      nb = (int64_t)(f0 + 1) * fs;
+    }
+    kseg = (int)((nb - n0) >> 6);            // runs of the first stretch (>= 16: the window lies inside one frame)
+    const uint64_t b2 = nb >= p.total ? a_zero : reinterpret_cast<uint64_t>(in_s + (nb / fs) * p.in_frame_stride);
+    base2p = b2 - 256ull * (uint64_t)kseg;   // run n1 >= kseg: base2p + 256 n1
+    base1 = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(base1 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base1);
+    base2p = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(base2p >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base2p);
+    kseg = __builtin_amdgcn_readfirstlane(kseg);
+  }
+  const unsigned lo4 = 4u * lo;
+#define FFT_FETCH(pr, z)                                                          \
+  do {                                                                            \
+    if constexpr (FAST2) fft_fetch2<M, 0, 16>(pr, z, base1, base2p, kseg, cs_in, lo4); \
+    else fft_fetch<M>(pr, z, ra_lo, ra_hi, zmask, hmask, cs_in, a_zero, lo);      \
+  } while (0)
+#define FFT_FETCH_HALF(pr, z, A, B)                                               \
+  do {                                                                            \
+    if constexpr (FAST2) fft_fetch2<M, A, B>(pr, z, base1, base2p, kseg, cs_in, lo4); \
+    else fft_fetch<M, A, B>(pr, z, ra_lo, ra_hi, zmask, hmask, cs_in, a_zero, lo); \
+  } while (0)
   fft_c32 u[16], v[16], z[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) u[r] = v[r] = fft_mk(0.f, 0.f);
@@ -539,11 +669,16 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
     }
     fft_fwd_b_tab(za, tw2);
     if (IAMF_FFT_EXP != 3) {
+#if IAMF_FFT_X2_LDS
       fft_wave_sync();
       fft_x2_write(za, lane, S);
       fft_wave_sync();
       fft_x2_read(za, lane, S);
       fft_wave_sync();
+#else
+      fft_wave_sync();   // exchange 1 has been read back: its LDS rows may be overwritten by the next pair
+      fft_x2_quads(za);
+#endif
     }
     fft_fwd_c(za);
 #pragma unroll
@@ -552,14 +687,20 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
       v[r] = fft_cmac(v[r], za[r], fft_mk(c[r].z, c[r].w));
       c[r] = IAMF_FFT_EXP == 1 ? make_float4(0.5f, 0.25f, 0.125f, 0.0625f) : (tq + (8 + r) * 64)[lo];
     }
+    fft_pin();
+    // za[0 .. 7] are free: the first half of the samples of the pair after next (past the last pair: the last one again,
+    // dropped; no branch) — issued HERE, between the two halves of the accumulation: the second half of the table was
+    // requested a few instructions ago and the L2 round trip it needs is what issuing these sixteen loads takes
+    const int prn = pr + 2 < kPairs ? pr + 2 : kPairs - 1;
+    if (IAMF_FFT_EXP != 2) FFT_FETCH_HALF(prn, za, 0, 8);
+    fft_pin();
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       u[8 + r] = fft_cmac(u[8 + r], za[8 + r], fft_mk(c[r].x, c[r].y));
       v[8 + r] = fft_cmac(v[8 + r], za[8 + r], fft_mk(c[r].z, c[r].w));
     }
     fft_pin();
-    // za is free: the samples of the pair after next (past the last pair: the last one again, dropped; no branch)
-    if (IAMF_FFT_EXP != 2) FFT_FETCH(pr + 2 < kPairs ? pr + 2 : kPairs - 1, za);
+    if (IAMF_FFT_EXP != 2) FFT_FETCH_HALF(prn, za, 8, 16);
     fft_pin();
   };
   FFT_FETCH(0, z);
@@ -582,9 +723,13 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
   fft_mirror_read_add(u, lane, S);
   fft_wave_sync();
   fft_inv_c(u);
+#if IAMF_FFT_X2_LDS
   fft_x2_write_back(u, lane, S);
   fft_wave_sync();
   fft_x2_read_back(u, lane, S);
+#else
+  fft_x2_quads(u);
+#endif
   fft_inv_b_tab(u, tw.tw2);
   fft_wave_sync();
   fft_x1_write_back(u, lane, S);
@@ -612,6 +757,7 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
     }
   }
 #undef FFT_FETCH
+#undef FFT_FETCH_HALF
 }
 
 // The stage as a kernel of its own (round 3, what the batch launches for kind FIR): overlap-save blocks are independent —
@@ -624,7 +770,7 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
 #ifndef IAMF_FFT_OCC
 #define IAMF_FFT_OCC 2   // workgroups per CU the stage kernel is compiled for (tools/fft_exp.sh: 3 = 168 registers)
 #endif
-template <int M>
+template <int M, bool FAST2 = false>
 __global__ __launch_bounds__(256, IAMF_FFT_OCC) void fir_fft_kernel(const RenderParams p, float *gy, int64_t gy_stream_stride) {
   extern __shared__ float fft_lds[];
   const int s = blockIdx.y + p.stream0, t = threadIdx.x;
@@ -633,10 +779,18 @@ __global__ __launch_bounds__(256, IAMF_FFT_OCC) void fir_fft_kernel(const Render
   __syncthreads();
   const float *in_s = p.in + (int64_t)s * p.in_stream_stride;
   const float *hist = p.fir_hist + (int64_t)s * M * kFirHist;
-  fir_stage_fft<M>(p, in_s, hist, kFftSpan * (int)blockIdx.x, reinterpret_cast<fft_c32 *>(fft_lds), tw, gy + (int64_t)s * gy_stream_stride);
+  // (FAST2) the stream's rows of the history kept at the input's channel stride: G = frame size / 256 streams per slab
+  const int g256 = p.frame_size >> 8;
+  const int64_t pre_off = FAST2 ? ((int64_t)(s / g256) * M) * p.frame_size + (int64_t)(s % g256) * kFirHist : 0;
+  fir_stage_fft<M, FAST2>(p, in_s, hist, kFftSpan * (int)blockIdx.x, reinterpret_cast<fft_c32 *>(fft_lds), tw,
+                          gy + (int64_t)s * gy_stream_stride, FAST2 ? p.fir_pre + pre_off : nullptr);
   if (blockIdx.x == 0) {   // input history for the next call: the last 256 samples of [old history | this call's input]
     float *hn = p.fir_hist_next + (int64_t)s * M * kFirHist;
-    for (int ch = 0; ch < M; ++ch) hn[ch * kFirHist + t] = fir_input(p, in_s, hist, ch, p.total - kFirHist + t);
+    for (int ch = 0; ch < M; ++ch) {
+      const float x = fir_input(p, in_s, hist, ch, p.total - kFirHist + t);
+      hn[ch * kFirHist + t] = x;
+      if (FAST2) p.fir_pre_next[pre_off + (int64_t)ch * p.frame_size + t] = x;
+    }
   }
 }
 #endif  // __HIPCC__

@@ -14,7 +14,7 @@ out=gpurun_out/fft_exp.txt
 : > $out
 for n in 0 ${EXPS:-1 2 3 4 5}; do
   if [ $n = 0 ]; then unset IAMF_HIP_LIB; else export IAMF_HIP_LIB=$PWD/iac_amd/lib/fftexp$n/libiamf_hip.so; fi
-  line=$(timeout -k 10 200 python bench.py --no-cpu-baseline --no-verify --repeats 1 --placement-tries 1 --streams 1024 --workload toa_hrtf256_limiter_s16 2>/dev/null | tail -1)
+  line=$(timeout -k 10 200 python bench.py --no-cpu-baseline --no-verify --repeats 1 --placement-tries 1 --streams 1024 --workload toa_hrtf256_limiter_s16 --no-facade --hrir-scale 0.0481 2>/dev/null | tail -1)
   echo "hrtf256 exp$n $(echo "$line" | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["roofline"]["kernel_ms"])')" >> $out
 done
 cat $out
