@@ -164,6 +164,13 @@ def test_fft_stage_against_the_two_mfma_stages(hip, monkeypatch):
     monkeypatch.delenv("IAMF_HIP_FIR_FUSED")
     for s in range(2):
         assert np.array_equal(yf[s], yfused[s]), s
+    # the stage kernel's two-base sample fetch (frame sizes that are multiples of 256 from 1024 on, an even channel count;
+    # the history kept at the input's channel stride) against its general per-run fetch: the same floats
+    monkeypatch.setenv("IAMF_HIP_FIR_GENERAL_FETCH", "1")
+    ygen = _fir_stage_output(A, G, h, x, fs, [3, 4], taps)
+    monkeypatch.delenv("IAMF_HIP_FIR_GENERAL_FETCH")
+    for s in range(2):
+        assert np.array_equal(yf[s], ygen[s]), s
     monkeypatch.setenv("IAMF_HIP_FIR_F16", "1")
     y16 = _fir_stage_output(A, G, h, x, fs, [3, 4], taps)
     monkeypatch.delenv("IAMF_HIP_FIR_F16")
@@ -177,6 +184,25 @@ def test_fft_stage_against_the_two_mfma_stages(hip, monkeypatch):
               % (s, ef, e16, e32, float(np.abs(yf[s] - y32[s]).max())))
         assert ef <= 2.0 ** -19 and e16 <= 2.0 ** -19 and e32 <= 2.0 ** -19
         assert not np.array_equal(yf[s], y16[s])   # it really is another stage that ran
+
+
+@pytest.mark.parametrize("fs,m,S", [(2048, 12, 11), (1024, 2, 9), (1280, 4, 7), (1024, 16, 5)])
+def test_two_base_fetch_slabs_and_frame_sizes(hip, monkeypatch, fs, m, S):
+    """the history of G = frame size / 256 streams shares a slab (stream counts that are not multiples of G; G = 8, 4, 5),
+    calls of one, two and five frames so that windows lie inside a frame, cross a frame boundary, start before the call and
+    end past it: the two-base fetch must give the floats of the general fetch, and both the float64 convolution"""
+    A, G = hip
+    taps, calls = 256, [1, 2, 5, 1]
+    F = sum(calls)
+    x = np.stack([synth.gaussian(990 + s, m, F * fs, 0.1) for s in range(S)])
+    h = hrir_set(13, m, taps)
+    y2 = _fir_stage_output(A, G, h, x, fs, calls, taps)
+    monkeypatch.setenv("IAMF_HIP_FIR_GENERAL_FETCH", "1")
+    yg = _fir_stage_output(A, G, h, x, fs, calls, taps)
+    monkeypatch.delenv("IAMF_HIP_FIR_GENERAL_FETCH")
+    for s in range(S):
+        assert np.array_equal(y2[s], yg[s]), s
+        assert np.abs(y2[s].T - fir64(h, x[s])).max() <= 2.0 ** -19, s
 
 
 @pytest.mark.parametrize("calls", [[24, 3, 37], [10, 10]])
