@@ -376,7 +376,7 @@ def kernel_tag(kind, in_ch, out_ch):
         for env, st in (("IAMF_HIP_FIR_F32", 1), ("IAMF_HIP_FIR_F16", 2), ("IAMF_HIP_FIR_FUSED", 3)):
             if os.environ.get(env):
                 return "render_fast_kernel<%d, 2, %d" % (in_ch, st)
-        return ("fir_fft_kernel<%d>" % in_ch, "render_fast_kernel<2, 2, 0, false, false")
+        return ("fir_fft_kernel<%d" % in_ch, "render_fast_kernel<2, 2, 0, false, false")
     if kind == "h2m_lfe":   # render_wide4_kernel<.., LFE>, behind the generator's two kernels (render_lfe.hpp)
         return "render_wide4_kernel<%d, %d, true, false, false, false, true" % (in_ch, out_ch)
     if out_ch <= 2:
