@@ -224,6 +224,11 @@ struct IAMF_Decoder {
   uint8_t *pkt[2][MAX_SUBSTREAMS];
   uint32_t pkt_len[2][MAX_SUBSTREAMS];
   uint32_t pkt_cap[2][MAX_SUBSTREAMS]; /* bytes allocated: a packet buffer only ever grows (no allocator call per frame) */
+  /* while the handle is in a group: where sub-stream s's packet goes instead (its slot in the group's pinned upload row),
+   * the slot's size, and whether the current packet is there (iamf_decoder_group.inc) */
+  uint8_t *pkt_ext[2][MAX_SUBSTREAMS];
+  uint32_t pkt_ext_cap[2][MAX_SUBSTREAMS];
+  uint8_t pkt_in_ext[2][MAX_SUBSTREAMS];
   int pkt_have[2][MAX_SUBSTREAMS];
   uint64_t tu_trim_start, tu_trim_end;
   uint64_t timestamp; /* stream time of the next frame, samples */
@@ -1482,11 +1487,17 @@ static int decode_parse(struct IAMF_Decoder *d, const uint8_t *data, int32_t siz
           if (d->sel_el[e]->sub_ids[s] == sid) {
             uint32_t len = o.payload_size - r.pos;
             uint8_t *b = d->pkt[e][s];
-            if (!b || len > d->pkt_cap[e][s]) {
-              b = (uint8_t *)realloc(b, len ? len : 1);
-              if (!b) return IAMF_ERR_ALLOC_FAIL;
-              d->pkt[e][s] = b;
-              d->pkt_cap[e][s] = len ? len : 1;
+            if (d->pkt_ext[e][s] && len <= d->pkt_ext_cap[e][s]) { /* grouped: straight into the upload row */
+              b = d->pkt_ext[e][s];
+              d->pkt_in_ext[e][s] = 1;
+            } else {
+              d->pkt_in_ext[e][s] = 0;
+              if (!b || len > d->pkt_cap[e][s]) {
+                b = (uint8_t *)realloc(b, len ? len : 1);
+                if (!b) return IAMF_ERR_ALLOC_FAIL;
+                d->pkt[e][s] = b;
+                d->pkt_cap[e][s] = len ? len : 1;
+              }
             }
             memcpy(b, o.payload + r.pos, len);
             d->pkt_len[e][s] = len;
