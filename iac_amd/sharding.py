@@ -23,11 +23,12 @@ class GatherPipeline:
     returns whatever it likes.  step() waits only for the gather that last read that buffer.
     """
 
-    def __init__(self, buffers, world, rank, enabled=True, make_recv=None):
+    def __init__(self, buffers, world, rank, enabled=True, make_recv=None, single_rank_too=False):
         assert len(buffers) == 2
         self.buffers = buffers
         self.world, self.rank = world, rank
-        self.enabled = enabled and world > 1
+        # (single_rank_too: a one-rank job has nothing to gather; tests/nccl_one_rank.py runs the collective anyway)
+        self.enabled = enabled and (world > 1 or single_rank_too)
         self.pending = [None, None]
         self.recv = None
         if self.enabled and rank == 0:
