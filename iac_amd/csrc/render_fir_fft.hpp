@@ -40,6 +40,9 @@
 #define FFT_HD __host__ __device__ __forceinline__
 #endif
 
+#ifndef IAMF_FFT_NT
+#define IAMF_FFT_NT 1                // 0: the sample fetch with the default cache policy throughout (A/B builds)
+#endif
 #ifndef IAMF_FFT_X2_LDS
 #define IAMF_FFT_X2_LDS 0            // 1: exchange 2 through LDS (the first form; kept for A/B builds, tools/fft_exp.sh)
 #endif
@@ -505,7 +508,7 @@ __device__ __forceinline__ void fft_fetch(int pr, fft_c32 (&z)[16], unsigned ra_
     const gptr sa = (gptr)(r0 + (uint64_t)a * cs);
     const gptr sb = (gptr)(b < M ? r0 + (uint64_t)b * cs : a_zero);
     float va, vb;
-    if (n1 >= 4 && n1 < 12) {   // read by this wave alone: streamed past the caches
+    if (IAMF_FFT_NT && n1 >= 4 && n1 < 12) {   // read by this wave alone: streamed past the caches
       va = __builtin_nontemporal_load(sa + lo);
       vb = __builtin_nontemporal_load(sb + lo);
     } else {                    // the hop's first and last 256 samples are also the neighbouring hops' overlap
@@ -552,7 +555,7 @@ __device__ __forceinline__ void fft_fetch2(int pr, fft_c32 (&z)[16], uint64_t ba
     const gbptr base = (gbptr)(n1 < k ? base1 : base2p);
     const gptr sa = (gptr)(base + 256 * n1 + oa), sb = (gptr)(base + 256 * n1 + ob);
     float va, vb;
-    if (n1 >= 4 && n1 < 12) {   // read by this wave alone: streamed past the caches
+    if (IAMF_FFT_NT && n1 >= 4 && n1 < 12) {   // read by this wave alone: streamed past the caches
       va = __builtin_nontemporal_load(sa);
       vb = __builtin_nontemporal_load(sb);
     } else {                    // the hop's first and last 256 samples are also the neighbouring hops' overlap
