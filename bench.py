@@ -341,7 +341,7 @@ def facade_rates(fs, n_group=64, frames=96):
             "group_handles": n_group, "group_msamples_s": round(g64, 2), "group_ms_per_round": round(ms64, 3),
             "group%d_msamples_s" % (4 * n_group): round(g256, 2), "group%d_ms_per_round" % (4 * n_group): round(ms256, 3),
             "group_phases_per_round": {str(k): v for k, v in phases.items()},
-            "note": "host OBU parsing + H2D of the LPCM packets + device unpack + render + D2H per call: PCIe-inclusive, never `value`"}
+            "note": "host OBU parsing + the LPCM packets over PCIe + device unpack + render + PCM back over PCIe, per call: never `value`"}
 
 
 SIGNALS = {"hot": "hot (sigma 0.25 + 1.5 bursts)", "quiet": "quiet (sigma 0.05)",
