@@ -184,7 +184,9 @@ def run_group(gdriver, tmp_path, stream, n, threads, layout="0", bits=16):
     return r.stdout.strip().splitlines()
 
 
-@pytest.mark.parametrize("n,threads", [(1, 1), (5, 3), (13, 0)])
+# (8 / 9 / 17 / 70 handles: whole upload chunks, a chunk of one handle, chunks of nine — iamf_decoder_group.inc cuts a round
+#  into at most eight chunks of at least eight handles; 1 thread = no pool, the calling thread parses and uploads)
+@pytest.mark.parametrize("n,threads", [(1, 1), (5, 3), (13, 0), (8, 2), (9, 1), (17, 5), (70, 4)])
 def test_group_of_handles_out_of_step_matches_the_single_handle_totals(driver, group_driver, tmp_path, n, threads):
     """N handles on one stream, starved in different rounds and finishing at different times: every handle must emit
     what a handle alone emits (here: the sample count; the PCM itself is checked on the GPU, tests/test_gpu_group.py)"""
