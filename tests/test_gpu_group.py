@@ -167,6 +167,21 @@ def test_group_of_64_in_step(lib, golden):
         assert rets == want_rets and np.array_equal(pcm, want), i
 
 
+@pytest.mark.parametrize("name,n,threads", [("toa_binaural_s16", 70, 5), ("stereo_A_s16", 9, 1)])
+def test_group_sizes_around_the_upload_chunks(lib, golden, name, n, threads):
+    """70 handles = eight upload chunks of nine, the last one short; 9 handles without a pool (one thread: the calling
+    thread parses, then uploads chunk by chunk): out of step, every handle still gets the reference's PCM"""
+    if name not in e2e_cases.CASES:
+        name = sorted(e2e_cases.CASES)[0]
+    case = e2e_cases.CASES[name]
+    stream, _ = e2e_cases.build(name)
+    want, want_rets = golden.npz("e2e")[name], list(golden.npz("e2e")[name + "_rets"])
+    rc, outs = group_decode_all(lib, case, stream, n, threads, starve=lambda r, i: (r + i) % 7 == 3)
+    assert rc == 0
+    for i, (pcm, rets) in enumerate(outs):
+        assert rets == want_rets and np.array_equal(pcm, want), i
+
+
 def test_group_refuses_mixed_topologies(lib):
     names = sorted(e2e_cases.CASES)
     a, b = "stereo_A_s16", next(nm for nm in names if "toa" in nm)
