@@ -50,7 +50,9 @@ void launch_fir_m(const RenderParams &p, hipStream_t st) {
 template <int M>
 void launch_fft_m(const RenderParams &p, hipStream_t st) {   // as in iamf_render.hip
   const dim3 g((unsigned)((p.total + kFftSpan - 1) / kFftSpan), (unsigned)p.n_launch);
-  if ((M & 1) == 0 && p.fir_pre && p.fir_pre_next && !getenv("IAMF_HIP_FIR_GENERAL_FETCH"))
+  // (whole frames only: past a call that ends inside a frame the two-base fetch would read what the caller left in the rest
+  //  of the frame — harmless to the samples that are kept unless it is a NaN, which a transform spreads over its block)
+  if ((M & 1) == 0 && p.fir_pre && p.fir_pre_next && p.total % p.frame_size == 0 && !getenv("IAMF_HIP_FIR_GENERAL_FETCH"))
     hipLaunchKernelGGL((fir_fft_kernel<M, (M & 1) == 0>), g, dim3(256), sizeof(float) * (size_t)kFftLdsFloats, st, p, p.fir_y, 2 * (int64_t)p.total);
   else
     hipLaunchKernelGGL((fir_fft_kernel<M, false>), g, dim3(256), sizeof(float) * (size_t)kFftLdsFloats, st, p, p.fir_y, 2 * (int64_t)p.total);

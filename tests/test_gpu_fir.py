@@ -223,3 +223,42 @@ def test_many_streams_long_calls_hot_programme(hip, calls):
         z, _ = O.limiter_run(np.ascontiguousarray(y_dev[s].T), [fs] * F)
         assert np.array_equal(got[s], O.pack(z, 16)), s
         assert np.abs(y_dev[s]).max() > 1.0
+
+
+def test_a_call_that_ends_inside_a_frame_with_nans_behind_it(hip):
+    """a trimmed last frame (n_samples = 512 of 1024): what the caller left in the rest of the frame buffer — here NaN — must
+    not reach the output.  A transform spreads one NaN over its whole block, so the stage has to take zeros past the end
+    of the call (its general fetch does; the two-base fetch is for whole frames only and must not be chosen here)."""
+    import torch
+    A, G = hip
+    fs, m, taps, S = 1024, 4, 256, 3
+    x = np.stack([synth.gaussian(1700 + s, m, 3 * fs, 0.1) for s in range(S)])
+    h = hrir_set(17, m, taps)
+    keep = 2 * fs + 512
+    xin = G.to_frames(x, fs).copy()                       # [S][3][m][fs]
+    xin.reshape(S, 3, m, fs)[:, 2, :, 512:] = np.nan
+    d_in = torch.from_numpy(xin).cuda()
+    b = A.Batch(S, A.fir_matrix(h), 2, frame_size=fs, out_format=A.FMT_F32, limiter=True, threshold_db=60.0, fir_taps=taps)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = [[] for _ in range(S)]
+    cap = 2 * fs * 2 * 4
+    for f0, nf, ns in ((0, 2, 0), (2, 1, 512)):
+        pcm = torch.zeros((S, cap), dtype=torch.uint8, device="cuda")
+        a = A.RenderArgs()
+        a.d_in, a.in_stream_stride, a.in_frame_stride = d_in.data_ptr() + 4 * f0 * m * fs, 3 * m * fs, m * fs
+        a.n_frames, a.n_samples, a.d_pcm, a.pcm_stream_stride_bytes, a.stream = nf, ns, pcm.data_ptr(), cap, st
+        n = b.render_ex(a)
+        torch.cuda.synchronize()
+        hp = pcm.cpu().numpy()
+        for s in range(S):
+            outs[s].append(hp[s][:n * 2 * 4].view(np.float32).reshape(n, 2).copy())
+    pcm = torch.zeros((S, 240 * 2 * 4), dtype=torch.uint8, device="cuda")
+    n = b.flush(pcm.data_ptr(), 240 * 2 * 4, st)
+    torch.cuda.synchronize()
+    hp = pcm.cpu().numpy()
+    b.close()
+    for s in range(S):
+        y = np.concatenate(outs[s] + [hp[s][:n * 2 * 4].view(np.float32).reshape(n, 2)], axis=0)
+        assert y.shape == (keep, 2)
+        assert np.isfinite(y).all(), s
+        assert np.abs(y.T - fir64(h, x[s][:, :keep])).max() <= 2.0 ** -19, s
