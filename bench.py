@@ -95,7 +95,8 @@ def measured_traffic(kernel_tag, sf_per_step, workload=None):
     import glob
     best = None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    own = [f for f in files if workload and os.path.basename(f).endswith("_%s_pmc.json" % workload)]
+    import re
+    own = [f for f in files if workload and re.fullmatch(r"r\d+_%s_pmc\.json" % re.escape(workload), os.path.basename(f))]
     for f in own or files:   # this workload's own summary if there is one
         try:
             d = json.load(open(f))
@@ -378,7 +379,8 @@ def kernel_tag(kind, in_ch, out_ch):
                 return "render_fast_kernel<%d, 2, %d" % (in_ch, st)
         return ("fir_fft_kernel<%d" % in_ch, "render_fast_kernel<2, 2, 0, false, false")
     if kind == "h2m_lfe":   # render_wide4_kernel<.., LFE>, behind the generator's two kernels (render_lfe.hpp)
-        return "render_wide4_kernel<%d, %d, true, false, false, false, true" % (in_ch, out_ch)
+        # (the dominant kernel first; the summaries keep 80 characters of a name)
+        return ("render_wide4_kernel<%d, %d, true, false, false, false" % (in_ch, out_ch), "lfe_chain_kernel", "lfe_ff_kernel")
     if out_ch <= 2:
         return "render_fast_kernel<%d, %d, 0, false, false" % (in_ch, out_ch)
     # whole 1024-sample chunks of s16: the 4-samples-per-lane kernel (else render_wide_kernel)

@@ -250,7 +250,16 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
   uint4 *stage = reinterpret_cast<uint4 *>(arr_p);  // [4 waves][LR][S] packed PCM, over arr_p (see wide4_stage_lanes)
   static_assert(wide4_lds_floats(C, M, kExtra) <= wide4_budget_floats(C, kExtra), "LDS per workgroup");
 
-  const int s = blockIdx.x + p.stream0;   // a launch covers streams [stream0, stream0 + n_launch) of the batch
+  // a launch covers streams [stream0, stream0 + n_launch) of the batch.  LFE: the generator's output lies transposed by
+  // blocks of 64 streams (one 16-byte piece per stream and quad, render_lfe.hpp), so the 64 workgroups of a block read
+  // the same 64-byte sectors — and workgroups go to the eight XCDs in turn, each with an L2 of its own: every XCD
+  // fetched every sector (PMC: 108.9 B per sample-frame where 80 are needed).  Workgroup b therefore takes stream
+  // (b mod 8) * n / 8 + b / 8: the workgroups of one XCD = a contiguous eighth of the streams = whole blocks.
+  int wg = blockIdx.x;
+  if constexpr (LFE) {
+    if ((p.n_launch & 511) == 0) wg = (wg & 7) * (p.n_launch >> 3) + (wg >> 3);
+  }
+  const int s = wg + p.stream0;
   const int t = threadIdx.x;
   const int wave = t >> 6;
   const int lane = t & 63;
@@ -453,7 +462,9 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
     if constexpr (LFE) {  // transposed by blocks of 64 streams (lfe_index, render_lfe.hpp); unconditional like the rest
       const int k0 = cbase + 4 * tt;
       const int k = k0 < p.total ? k0 : p.total - 4;   // past the end: the call's last quad (total >= 256, a multiple of 64)
-      lq = ld_stream4(p.lfe + (((((int64_t)(s >> 6) * p.lfe_t4 + (k >> 2)) * 64 + (s & 63)) << 2)));
+      // (default cache policy, not the streaming one of the element PCM: the 64-byte sector this piece lies in is read by
+      //  three neighbouring streams' workgroups too)
+      lq = *reinterpret_cast<const float4 *>(p.lfe + (((((int64_t)(s >> 6) * p.lfe_t4 + (k >> 2)) * 64 + (s & 63)) << 2)));
     }
     if constexpr (MIX) {
       // the lane's own 4 samples (lanes past the end of a short last chunk re-read the call's last quad)

@@ -18,8 +18,8 @@ import sys
 
 
 def ours(name):
-    """the kernels of the hot path (render_*_kernel, and the HRTF stage's fir_fft_kernel)"""
-    return "render" in name or "fir_fft" in name
+    """the kernels of the hot path (render_*_kernel, the HRTF stage's fir_fft_kernel, the LFE generator's lfe_*_kernel)"""
+    return "render" in name or "fir_fft" in name or "lfe_" in name
 
 
 def main():
