@@ -59,12 +59,32 @@ __global__ __launch_bounds__(256) void lfe_ff_kernel(const LfeParams p) {
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
     if (s < p.n_streams && k0 < p.total) {
       const float h1 = p.state[4 * s + 0], h2 = p.state[4 * s + 1];
-      float wm1 = k0 >= 1 ? lfe_w_at(p, s, k0 - 1) : h1;
-      float wm2 = k0 >= 2 ? lfe_w_at(p, s, k0 - 2) : (k0 == 1 ? h1 : h2);
-      float w[4], uu[4];
+      float wm1, wm2, w[4], uu[4];
+      const bool quick = !p.pre_matrix && ((p.frame_size | p.in_stream_stride | p.in_frame_stride) & 3) == 0 &&
+                         (reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && k0 + 4 <= p.total;
+      if (quick) {   // the usual case: one division per quad instead of six (the quad lies inside one frame)
+        const int f = k0 / p.frame_size, i0 = k0 - f * p.frame_size;
+        const float *src = p.in + (int64_t)s * p.in_stream_stride + (int64_t)f * p.in_frame_stride + i0;
+        const float4 q = *reinterpret_cast<const float4 *>(src);
+        w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
+        if (i0 >= 4) {
+          wm1 = src[-1];
+          wm2 = src[-2];
+        } else if (k0 == 0) {
+          wm1 = h1;
+          wm2 = h2;
+        } else {     // the frame before: its last two samples
+          const float *prv = p.in + (int64_t)s * p.in_stream_stride + (int64_t)(f - 1) * p.in_frame_stride + p.frame_size;
+          wm1 = prv[-1];
+          wm2 = prv[-2];
+        }
+      } else {
+        wm1 = k0 >= 1 ? lfe_w_at(p, s, k0 - 1) : h1;
+        wm2 = k0 >= 2 ? lfe_w_at(p, s, k0 - 2) : (k0 == 1 ? h1 : h2);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        w[i] = k0 + i < p.total ? lfe_w_at(p, s, k0 + i) : 0.f;
+        if (!quick) w[i] = k0 + i < p.total ? lfe_w_at(p, s, k0 + i) : 0.f;
         const float a = i >= 1 ? w[i - 1] : wm1, b = i >= 2 ? w[i - 2] : (i == 1 ? wm1 : wm2);
         uu[i] = (p.a1 * w[i] + p.a2 * a) + p.a3 * b;
       }
