@@ -41,6 +41,13 @@ CASES = {
     # BASELINE configs[0]: stereo element -> Sound System A, 16 bit (the reference's own
     # CPU-runnable case, iamfplayer -o2 -s0)
     "stereo_A_s16": dict(layout=_ss_layout("A"), bit_depth=16, frames=20, fs=1024, seed=7),
+    # frame sizes away from 1024 (the codec configuration's num_samples_per_frame is free): shorter than the limiter's
+    # 240-sample delay (the first calls emit nothing or less than a frame), and longer than 1024 (max_frame_size = 6 frames,
+    # IAMF_decoder.c:1628-1630)
+    "stereo_fs128": dict(layout=_ss_layout("A"), bit_depth=16, frames=48, fs=128, seed=71),
+    "stereo_fs2048": dict(layout=_ss_layout("A"), bit_depth=16, frames=4, fs=2048, seed=72),
+    "toa_binaural_fs256": dict(layout=("binaural",), bit_depth=16, frames=24, fs=256, seed=1073),
+    "toa_H_fs2048": dict(layout=_ss_layout("H"), bit_depth=16, frames=3, fs=2048, seed=74),
     "toa_binaural_s16": dict(layout=("binaural",), bit_depth=16, frames=12, fs=1024, seed=1000),
     "toa_H_s16": dict(layout=_ss_layout("H"), bit_depth=16, frames=5, fs=1024, seed=13),
     "l714_J_s24_gain": dict(layout=_ss_layout("J"), bit_depth=24, frames=6, fs=960, seed=11,
@@ -141,7 +148,7 @@ def build(name):
     def frames_of(subs_fn):
         return subs_fn
 
-    if name in ("stereo_A_s16", "stereo_441_to_48k", "stereo_trim"):
+    if name in ("stereo_A_s16", "stereo_441_to_48k", "stereo_trim", "stereo_fs128", "stereo_fs2048"):
         x = synth.uniform(c["seed"], 2, n, 0.9)
         desc, x_al, xq = _channel_element(1, 1, x, 0, ss)
         stream += desc
@@ -194,8 +201,8 @@ def build(name):
             stream += W.temporal_delimiter()
             stream += W.demixing_block(200, c["dmx_modes"][f])
             stream += W.audio_frames(W.channel_element_substreams(7, x_al[:, f * fs:(f + 1) * fs], 0, ss))
-    elif name in ("toa_binaural_s16", "toa_H_s16", "toa_binaural_loudness"):
-        if name == "toa_H_s16":
+    elif name in ("toa_binaural_s16", "toa_H_s16", "toa_binaural_loudness", "toa_binaural_fs256", "toa_H_fs2048"):
+        if name in ("toa_H_s16", "toa_H_fs2048"):
             x = synth.gaussian(c["seed"], 16, n, 0.15)
         else:
             x = np.clip(synth.hot(c["seed"], 16, n, sigma=0.2, burst_amp=0.7, burst_phase=900, burst_period=5000),
