@@ -48,6 +48,11 @@ CASES = {
     "stereo_fs2048": dict(layout=_ss_layout("A"), bit_depth=16, frames=4, fs=2048, seed=72),
     "toa_binaural_fs256": dict(layout=("binaural",), bit_depth=16, frames=24, fs=256, seed=1073),
     "toa_H_fs2048": dict(layout=_ss_layout("H"), bit_depth=16, frames=3, fs=2048, seed=74),
+    # first- and second-order ambisonics (the order follows from the channel count, IAMF_decoder.c:2403-2413), and a limiter
+    # threshold other than the default -1 dBFS
+    "foa_binaural_s16": dict(layout=("binaural",), bit_depth=16, frames=6, fs=1024, seed=75, amb_ch=4),
+    "soa_B_s24": dict(layout=_ss_layout("B"), bit_depth=24, frames=5, fs=1024, seed=76, amb_ch=9),
+    "toa_binaural_thr6": dict(layout=("binaural",), bit_depth=16, frames=6, fs=1024, seed=77, threshold=-6.0),
     "toa_binaural_s16": dict(layout=("binaural",), bit_depth=16, frames=12, fs=1024, seed=1000),
     "toa_H_s16": dict(layout=_ss_layout("H"), bit_depth=16, frames=5, fs=1024, seed=13),
     "l714_J_s24_gain": dict(layout=_ss_layout("J"), bit_depth=24, frames=6, fs=960, seed=11,
@@ -201,21 +206,23 @@ def build(name):
             stream += W.temporal_delimiter()
             stream += W.demixing_block(200, c["dmx_modes"][f])
             stream += W.audio_frames(W.channel_element_substreams(7, x_al[:, f * fs:(f + 1) * fs], 0, ss))
-    elif name in ("toa_binaural_s16", "toa_H_s16", "toa_binaural_loudness", "toa_binaural_fs256", "toa_H_fs2048"):
+    elif name in ("toa_binaural_s16", "toa_H_s16", "toa_binaural_loudness", "toa_binaural_fs256", "toa_H_fs2048",
+                  "foa_binaural_s16", "soa_B_s24", "toa_binaural_thr6"):
+        ach = c.get("amb_ch", 16)
         if name in ("toa_H_s16", "toa_H_fs2048"):
-            x = synth.gaussian(c["seed"], 16, n, 0.15)
+            x = synth.gaussian(c["seed"], ach, n, 0.15)
         else:
-            x = np.clip(synth.hot(c["seed"], 16, n, sigma=0.2, burst_amp=0.7, burst_phase=900, burst_period=5000),
+            x = np.clip(synth.hot(c["seed"], ach, n, sigma=0.2, burst_amp=0.7, burst_phase=900, burst_period=5000),
                         -1, 1 - 2 ** -15).astype(np.float32)
         desc, xq = _toa_element(1, x, 0, ss)
         stream += desc
         stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100), default_q78=eg)],
                                      dict(pdef=_pdef_static(101), default_q78=og), layouts_field,
                                      loudness_q78=c.get("mix_loudness_q78", 0))
-        info["elements"].append(dict(kind="scene", order=3, x=xq))
+        info["elements"].append(dict(kind="scene", order={4: 1, 9: 2, 16: 3}[ach], x=xq))
         for f in range(F):
             stream += W.temporal_delimiter()
-            subs = [(i, W.lpcm_bytes(xq[i:i + 1, f * fs:(f + 1) * fs], ss)) for i in range(16)]
+            subs = [(i, W.lpcm_bytes(xq[i:i + 1, f * fs:(f + 1) * fs], ss)) for i in range(ach)]
             stream += W.audio_frames(subs)
     elif c.get("lpcm"):
         x = synth.uniform(c["seed"], 2, n, 0.6)
