@@ -53,6 +53,16 @@ CASES = {
     "foa_binaural_s16": dict(layout=("binaural",), bit_depth=16, frames=6, fs=1024, seed=75, amb_ch=4),
     "soa_B_s24": dict(layout=_ss_layout("B"), bit_depth=24, frames=5, fs=1024, seed=76, amb_ch=9),
     "toa_binaural_thr6": dict(layout=("binaural",), bit_depth=16, frames=6, fs=1024, seed=77, threshold=-6.0),
+    # the loudspeaker layouts the other cases do not touch: the permutation from audio-layer to playback order
+    # (IAMF_utils.c:117-133 vs :181-196) and the layout -> layout matrix of each, end to end
+    "mono_A_s16": dict(layout=_ss_layout("A"), bit_depth=16, frames=4, fs=1024, seed=81, ch_layout=0),
+    "l51_A_s16": dict(layout=_ss_layout("A"), bit_depth=16, frames=4, fs=1024, seed=82, ch_layout=2),
+    "l512_J_s16": dict(layout=_ss_layout("J"), bit_depth=16, frames=4, fs=1024, seed=83, ch_layout=3),
+    "l514_B_s24": dict(layout=_ss_layout("B"), bit_depth=24, frames=4, fs=1024, seed=84, ch_layout=4),
+    "l71_D_s16": dict(layout=_ss_layout("D"), bit_depth=16, frames=4, fs=1024, seed=85, ch_layout=5),
+    "l712_binaural_s16": dict(layout=("binaural",), bit_depth=16, frames=4, fs=1024, seed=86, ch_layout=6),
+    "l312_I_s16": dict(layout=_ss_layout("I"), bit_depth=16, frames=4, fs=1024, seed=87, ch_layout=8),
+    "l514_312_s16": dict(layout=("ss", 11), bit_depth=16, frames=4, fs=1024, seed=88, ch_layout=4),
     "toa_binaural_s16": dict(layout=("binaural",), bit_depth=16, frames=12, fs=1024, seed=1000),
     "toa_H_s16": dict(layout=_ss_layout("H"), bit_depth=16, frames=5, fs=1024, seed=13),
     "l714_J_s24_gain": dict(layout=_ss_layout("J"), bit_depth=24, frames=6, fs=960, seed=11,
@@ -296,6 +306,19 @@ def build(name):
                 subs.append((i, W.lpcm_bytes(xd[ch:ch + w, f * fs:(f + 1) * fs], ss)))
                 ch += w
             stream += W.audio_frames(subs)
+    elif c.get("ch_layout") is not None:
+        lay_id = c["ch_layout"]
+        nch = W.LAYOUT_CHANNELS[lay_id]
+        x = np.clip(synth.hot(c["seed"], nch, n, sigma=0.2, burst_amp=0.6, burst_phase=400, burst_period=2900),
+                    -1, 1 - 2 ** -15).astype(np.float32)
+        desc, x_al, xq = _channel_element(1, lay_id, x, 0, ss)
+        stream += desc
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100), default_q78=eg)],
+                                     dict(pdef=_pdef_static(101), default_q78=og), layouts_field)
+        info["elements"].append(dict(kind="channel", layout=lay_id, x=xq))
+        for f in range(F):
+            stream += W.temporal_delimiter()
+            stream += W.audio_frames(W.channel_element_substreams(lay_id, x_al[:, f * fs:(f + 1) * fs], 0, ss))
     elif name in ("l714_J_s24_gain", "l714_A_s16"):
         x = np.clip(synth.hot(c["seed"], 12, n, sigma=0.2, burst_amp=0.6, burst_phase=500, burst_period=3000),
                     -1, 1 - 2 ** -15).astype(np.float32)
