@@ -63,6 +63,14 @@ CASES = {
     "l712_binaural_s16": dict(layout=("binaural",), bit_depth=16, frames=4, fs=1024, seed=86, ch_layout=6),
     "l312_I_s16": dict(layout=_ss_layout("I"), bit_depth=16, frames=4, fs=1024, seed=87, ch_layout=8),
     "l514_312_s16": dict(layout=("ss", 11), bit_depth=16, frames=4, fs=1024, seed=88, ch_layout=4),
+    # output sound systems the other cases do not reach (E, F, G, the 7.1.2 and mono extensions)
+    "toa_G_s32": dict(layout=_ss_layout("G"), bit_depth=32, frames=4, fs=1024, seed=91),
+    "toa_E_s16": dict(layout=_ss_layout("E"), bit_depth=16, frames=4, fs=1024, seed=92),
+    "soa_F_s16": dict(layout=_ss_layout("F"), bit_depth=16, frames=4, fs=1024, seed=93, amb_ch=9),
+    "foa_D_s16": dict(layout=_ss_layout("D"), bit_depth=16, frames=4, fs=1024, seed=94, amb_ch=4),
+    "l714_ext712_s16": dict(layout=("ss", 10), bit_depth=16, frames=4, fs=1024, seed=95, ch_layout=7),
+    "l714_mono_s16": dict(layout=("ss", 12), bit_depth=16, frames=4, fs=1024, seed=96, ch_layout=7),
+    "toa_mono_s16": dict(layout=("ss", 12), bit_depth=16, frames=4, fs=1024, seed=97),
     "toa_binaural_s16": dict(layout=("binaural",), bit_depth=16, frames=12, fs=1024, seed=1000),
     "toa_H_s16": dict(layout=_ss_layout("H"), bit_depth=16, frames=5, fs=1024, seed=13),
     "l714_J_s24_gain": dict(layout=_ss_layout("J"), bit_depth=24, frames=6, fs=960, seed=11,
@@ -217,7 +225,8 @@ def build(name):
             stream += W.demixing_block(200, c["dmx_modes"][f])
             stream += W.audio_frames(W.channel_element_substreams(7, x_al[:, f * fs:(f + 1) * fs], 0, ss))
     elif name in ("toa_binaural_s16", "toa_H_s16", "toa_binaural_loudness", "toa_binaural_fs256", "toa_H_fs2048",
-                  "foa_binaural_s16", "soa_B_s24", "toa_binaural_thr6"):
+                  "foa_binaural_s16", "soa_B_s24", "toa_binaural_thr6", "toa_G_s32", "toa_E_s16", "soa_F_s16", "foa_D_s16",
+                  "toa_mono_s16"):
         ach = c.get("amb_ch", 16)
         if name in ("toa_H_s16", "toa_H_fs2048"):
             x = synth.gaussian(c["seed"], ach, n, 0.15)
