@@ -71,6 +71,15 @@ CASES = {
     "l714_ext712_s16": dict(layout=("ss", 10), bit_depth=16, frames=4, fs=1024, seed=95, ch_layout=7),
     "l714_mono_s16": dict(layout=("ss", 12), bit_depth=16, frames=4, fs=1024, seed=96, ch_layout=7),
     "toa_mono_s16": dict(layout=("ss", 12), bit_depth=16, frames=4, fs=1024, seed=97),
+    # other stacks of scalable layers (demixer paths S1to2 / S2to3 / S3to5 / S5to7 / TF2toT2 / T2toT4 end to end), into an
+    # output that takes the top layer and into one that selects a lower layer or the down-mixer
+    "scalable_0125_I": dict(layout=_ss_layout("I"), bit_depth=16, frames=8, fs=1024, seed=101, scalable=True, layers=[0, 1, 2, 5]),
+    "scalable_0125_A": dict(layout=_ss_layout("A"), bit_depth=16, frames=8, fs=1024, seed=101, scalable=True, layers=[0, 1, 2, 5]),
+    "scalable_18_312": dict(layout=("ss", 11), bit_depth=16, frames=8, fs=1024, seed=102, scalable=True, layers=[1, 8]),
+    "scalable_24_D": dict(layout=_ss_layout("D"), bit_depth=16, frames=8, fs=1024, seed=103, scalable=True, layers=[2, 4]),
+    "scalable_34_binaural": dict(layout=("binaural",), bit_depth=16, frames=8, fs=1024, seed=104, scalable=True, layers=[3, 4]),
+    "scalable_836_ext712": dict(layout=("ss", 10), bit_depth=16, frames=8, fs=1024, seed=105, scalable=True, layers=[8, 3, 6]),
+    "scalable_836_C": dict(layout=_ss_layout("C"), bit_depth=16, frames=8, fs=1024, seed=105, scalable=True, layers=[8, 3, 6]),
     "toa_binaural_s16": dict(layout=("binaural",), bit_depth=16, frames=12, fs=1024, seed=1000),
     "toa_H_s16": dict(layout=_ss_layout("H"), bit_depth=16, frames=5, fs=1024, seed=13),
     "l714_J_s24_gain": dict(layout=_ss_layout("J"), bit_depth=24, frames=6, fs=960, seed=11,
@@ -261,7 +270,8 @@ def build(name):
             stream += W.audio_frames([(0, W.lpcm_bytes(x[:, f * fs:(f + 1) * fs], ss, le))])
     elif c.get("scalable"):
         import demix_cases as D
-        layers = SCALABLE_LAYERS
+        layers = c.get("layers", SCALABLE_LAYERS)
+        lgains = SCALABLE_GAINS if layers == SCALABLE_LAYERS else {}
         order, per_layer = D.channels_order(layers)
         xd = W.quantize(synth.hot(c["seed"], len(order), n, sigma=0.15, burst_amp=0.45, burst_phase=600,
                                   burst_period=2700).clip(-1, 1 - 2 ** -15).astype(np.float32), ss)
@@ -270,14 +280,14 @@ def build(name):
             # recon gains ride on the layers above the first: flags = what that layer needs rebuilt
             rf = D.recon_flags(layers[0], lay) if li else 0
             wl.append(dict(layout=lay, nsub=pl["substreams"], ncoupled=pl["coupled"],
-                           out_gain=SCALABLE_GAINS.get(li), recon=bool(rf), recon_flags=rf))
+                           out_gain=lgains.get(li), recon=bool(rf), recon_flags=rf))
         nsub = sum(l["nsub"] for l in wl)
         stream += W.audio_element_scalable(1, 0, wl, list(range(nsub)),
                                            demixing=dict(pid=200, rate=rate, frame=fs, mode=1, w=3),
                                            recon=dict(pid=201, rate=rate, frame=fs))
         stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100), default_q78=eg)],
                                      dict(pdef=_pdef_static(101), default_q78=og), layouts_field)
-        info["elements"].append(dict(kind="scalable", layers=layers, order=order, x=xd, wl=wl))
+        info["elements"].append(dict(kind="scalable", layers=layers, order=order, x=xd, wl=wl, gains=lgains))
         for f in range(F):
             stream += W.temporal_delimiter()
             stream += W.demixing_block(200, SCALABLE_MODES[f])

@@ -58,7 +58,7 @@ def demix_scalable(el, c):
     layers = el["layers"][:li + 1]
     order, _ = D.channels_order(layers)
     layout = layers[-1]
-    gains = D.output_gain_list(layers, {k: (f, q78_to_lin(q)) for k, (f, q) in e2e_cases.SCALABLE_GAINS.items() if k <= li})
+    gains = D.output_gain_list(layers, {k: (f, q78_to_lin(q)) for k, (f, q) in el.get("gains", e2e_cases.SCALABLE_GAINS).items() if k <= li})
     flags = D.recon_flags(layers[0], layout) if li else 0
     rec = D.recon_order(layout, flags)
     sched = []
