@@ -98,6 +98,11 @@ CASES = {
     # 44.1 kHz stream, 48 kHz output: speex-derived resampler in the path
     "stereo_441_to_48k": dict(layout=_ss_layout("A"), bit_depth=16, frames=6, fs=1024, seed=53, rate=44100,
                               out_rate=48000),
+    # the other stream rates IAMF allows, to 48 kHz and (48 kHz stream) down to 44.1 kHz
+    "stereo_96k_to_48k": dict(layout=_ss_layout("A"), bit_depth=16, frames=6, fs=1024, seed=58, rate=96000, out_rate=48000),
+    "stereo_32k_to_48k": dict(layout=_ss_layout("A"), bit_depth=24, frames=6, fs=1024, seed=59, rate=32000, out_rate=48000),
+    "stereo_16k_to_48k": dict(layout=_ss_layout("A"), bit_depth=16, frames=6, fs=1024, seed=60, rate=16000, out_rate=48000),
+    "stereo_48k_to_441": dict(layout=_ss_layout("A"), bit_depth=16, frames=6, fs=1024, seed=66, rate=48000, out_rate=44100),
     # frame trimming: 100 samples off the first frame, 300 off the last
     "stereo_trim": dict(layout=_ss_layout("A"), bit_depth=16, frames=5, fs=1024, seed=54, trims={0: (100, 0), 4: (0, 300)}),
     # projection-mode ambisonics: 10 sub-streams (6 coupled) -> 16 decoded channels -> Q15 de-mapping
@@ -180,7 +185,8 @@ def build(name):
     def frames_of(subs_fn):
         return subs_fn
 
-    if name in ("stereo_A_s16", "stereo_441_to_48k", "stereo_trim", "stereo_fs128", "stereo_fs2048"):
+    if name in ("stereo_A_s16", "stereo_441_to_48k", "stereo_trim", "stereo_fs128", "stereo_fs2048", "stereo_96k_to_48k",
+                "stereo_32k_to_48k", "stereo_16k_to_48k", "stereo_48k_to_441"):
         x = synth.uniform(c["seed"], 2, n, 0.9)
         desc, x_al, xq = _channel_element(1, 1, x, 0, ss)
         stream += desc
