@@ -23,6 +23,19 @@ CASES = {
     "l51_G_s16": dict(layout=("ss", 6), bit_depth=16, frames=4, fs=1024, seed=301, in_layout=2),   # 5.1 -> 14 ch (TV table differs)
     "l512_F_s16": dict(layout=("ss", 5), bit_depth=16, frames=4, fs=1024, seed=302, in_layout=3),  # 5.1.2 -> F
     "l312_J_s24": dict(layout=("ss", 9), bit_depth=24, frames=3, fs=960, seed=303, in_layout=8),   # 3.1.2 -> J
+    # round 3: the e2e cases added for the default build, on the TV build's tables and stride
+    "l51_A_s16": dict(e2e="l51_A_s16"),
+    "l514_B_s24": dict(e2e="l514_B_s24"),
+    "l71_D_s16": dict(e2e="l71_D_s16"),
+    "l712_binaural_s16": dict(e2e="l712_binaural_s16"),
+    "mono_A_s16": dict(e2e="mono_A_s16"),
+    "l714_ext712_s16": dict(e2e="l714_ext712_s16"),
+    "toa_G_s32": dict(e2e="toa_G_s32"),                       # 14 channels > 12
+    "foa_binaural_s16": dict(e2e="foa_binaural_s16"),
+    "stereo_fs128": dict(e2e="stereo_fs128"),
+    "toa_H_fs2048": dict(e2e="toa_H_fs2048"),
+    "scalable_0125_A": dict(e2e="scalable_0125_A"),           # TV: always the top layer (7.1), then 7.1 -> stereo
+    "scalable_836_C": dict(e2e="scalable_836_C"),
 }
 
 
