@@ -45,7 +45,7 @@ def test_hip_matches_reference_decoder_pcm(hip, golden, name):
         gains["loudness"] = [O.lib().orc_db2lin(float(np.float32(c["loudness"]) - mix_l))]
     got = G.hip_render(mx, ch, el["x"][None], frame_size=c["fs"], fmt=fmt, limiter=c.get("limiter", True),
                        flush=True, frames_per_call=[1] * c["frames"], gains=gains, loudness=loud,
-                       projection=A.PROJ_EXACT)[0]
+                       threshold_db=c.get("threshold", -1.0), projection=A.PROJ_EXACT)[0]
     want = golden.npz("e2e")[name]
     assert got.shape == want.shape
     assert np.array_equal(got, want), name
