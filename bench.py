@@ -542,11 +542,11 @@ class Workload:
         """Setup, untimed: the same search for the two PCM output buffers.  What is slow is a PAIR: an input region and an
         output region of the same kind (tools/placement_va_probe.hip `out`: every input buffer is slow with one group of
         output buffers and fast with the other, or fast with both — DESIGN.md 3), and the timed region alternates
-        between two PCM buffers, so both have to suit the chosen input.  `tries` candidates (the two already allocated
-        among them), the chosen input, silence; the best two stay."""
-        cands = list(self.pcm) + [torch.zeros((self.S, self.stride_bytes), dtype=torch.uint8, device=dev) for _ in range(tries - 2)]
-        rates = []
-        for buf in cands:
+        between two PCM buffers, so BOTH have to suit the chosen input.  Candidates are therefore pairs: the two buffers
+        already allocated, and `tries` - 1 more, each pair ONE allocation cut in two (neighbours share their kind of region;
+        with single buffers as candidates a run found one fast buffer among six and timed every other step on a slow one).
+        The chosen input, silence; the pair whose slower half is fastest stays."""
+        def rate(buf):
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
             for a, b in ev:
                 a.record()
@@ -556,13 +556,19 @@ class Workload:
             torch.cuda.synchronize()
             self.batch.reset()
             ms = float(np.median([a.elapsed_time(b) for a, b in ev[1:]]))
-            rates.append(round(self.sf_per_step / (ms * 1e-3) / 1e6, 1))
-        order = [int(i) for i in np.argsort(rates)[::-1]]
-        if sorted(order[:2]) != [0, 1]:
-            self.pcm_first = [cands[0], cands[1]]
-        self.pcm = [cands[order[0]], cands[order[1]]]
-        self.pcm_placement = {"candidates_msamples_s": rates, "picked": order[:2]}
-        del cands
+            return round(self.sf_per_step / (ms * 1e-3) / 1e6, 1)
+
+        pairs = [list(self.pcm)]
+        for _ in range(max(0, tries - 1)):
+            both = torch.zeros((2, self.S, self.stride_bytes), dtype=torch.uint8, device=dev)
+            pairs.append([both[0], both[1]])
+        rates = [[rate(b) for b in pr] for pr in pairs]
+        best = int(np.argmax([min(r) for r in rates]))
+        if best != 0:
+            self.pcm_first = list(pairs[0])
+        self.pcm = list(pairs[best])
+        self.pcm_placement = {"candidate_pairs_msamples_s": rates, "picked": best}
+        del pairs
         torch.cuda.empty_cache()
 
     def render_into(self, buf, ev_pair=None):
