@@ -59,6 +59,12 @@ E2E = {
     "toa_A_s16": dict(order=3, ss="A", bit_depth=16, frames=3, fs=1024, seed=207),   # no LFE slot: unchanged path
     # projection-mode ambisonics: W is channel 0 AFTER the de-mapping (IAMF_core_decoder.c:116-130)
     "toa_projection_D_s16": dict(order=3, ss="D", bit_depth=16, frames=4, fs=1024, seed=208, projection=True),
+    # round 3: frames shorter than the limiter's delay and longer than 1024, the 14-channel system, the LFE pair of E
+    "toa_B_fs256": dict(order=3, ss="B", bit_depth=16, frames=20, fs=256, seed=209),
+    "soa_J_fs2048": dict(order=2, ss="J", bit_depth=16, frames=3, fs=2048, seed=210),
+    "toa_G_s16": dict(order=3, ss="G", bit_depth=16, frames=4, fs=1024, seed=211),
+    "foa_E_s24": dict(order=1, ss="E", bit_depth=24, frames=4, fs=1024, seed=212),
+    "toa_D_s16": dict(order=3, ss="D", bit_depth=16, frames=5, fs=1024, seed=213),
 }
 
 
