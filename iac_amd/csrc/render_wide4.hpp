@@ -125,10 +125,11 @@ __device__ __forceinline__ void w4_demix(const RenderParams &p, float4 (&x)[M],
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      if ((p.demix_gmask >> m) & 1) {  // dmx_gainup (:426-435)
-        const float g = gin[m];
-        x[m].x = x[m].x * g; x[m].y = x[m].y * g; x[m].z = x[m].z * g; x[m].w = x[m].w * g;
-      }
+      // dmx_gainup (:426-435).  Unconditional: a channel without an output gain has g = 1.0f in the table
+      // (iamf_hip_batch_set_demixer) and x * 1.0f is x, bit for bit — the test of the per-batch mask had been compiled
+      // into a multiply AND four selects per channel (48 v_cndmask per lane and chunk).
+      const float g = gin[m];
+      x[m].x = x[m].x * g; x[m].y = x[m].y * g; x[m].z = x[m].z * g; x[m].w = x[m].w * g;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
