@@ -278,10 +278,11 @@ int iamf_hip_shard_render(iamf_hip_shard *s, const float *const *d_in, int64_t i
 int iamf_hip_shard_flush(iamf_hip_shard *s, void *const *d_pcm, int64_t pcm_stream_stride_bytes) {
   if (!s || !d_pcm) return IAMF_HIP_ERR_BAD_ARG;
   const int n = (int)s->devs.size();
+  for (int i = 0; i < n; ++i)   // checked before anything is submitted: no device is left flushed while another is not
+    if (!d_pcm[i]) return IAMF_HIP_ERR_BAD_ARG;
   for (int i = 0; i < n; ++i) {
     Dev *d = s->devs[i];
     void *pcm = d_pcm[i];
-    if (!pcm) return IAMF_HIP_ERR_BAD_ARG;
     d->w.submit([=] {
       (void)hipStreamWaitEvent(d->render, d->gathered, 0);
       d->result = iamf_hip_batch_flush(d->batch, pcm, pcm_stream_stride_bytes, d->render);
@@ -329,7 +330,13 @@ int iamf_hip_shard_gather(iamf_hip_shard *s, int root_index, void *d_dst, int64_
     if (hipSetDevice(d->device) != hipSuccess || hipStreamWaitEvent(d->gather, d->rendered, 0) != hipSuccess) err = 1;
   }
   Dev *root = s->devs[root_index];
-  if (!err && R.GroupStart() != ncclSuccess) err = 1;
+  for (int i = 0; i < n; ++i)
+    if (!d_pcm[i]) err = 1;
+  bool group = false;
+  if (!err) {
+    group = R.GroupStart() == ncclSuccess;
+    if (!group) err = 1;
+  }
   for (int i = 0; i < n && !err; ++i) {
     Dev *d = s->devs[i];
     const size_t bytes = (size_t)d->count * (size_t)pcm_stream_stride_bytes;
@@ -338,7 +345,7 @@ int iamf_hip_shard_gather(iamf_hip_shard *s, int root_index, void *d_dst, int64_
                root->gather) != ncclSuccess)
       err = 1;
   }
-  if (R.GroupEnd() != ncclSuccess) err = 1;
+  if (group && R.GroupEnd() != ncclSuccess) err = 1;   // a started group is always ended
   for (int i = 0; i < n; ++i) {
     Dev *d = s->devs[i];
     if (hipSetDevice(d->device) != hipSuccess || hipEventRecord(d->gathered, d->gather) != hipSuccess) err = 1;

@@ -44,7 +44,11 @@ template <int BYTES>
 __global__ __launch_bounds__(64) void lpcm_unpack_kernel(const UnpackParams p) {
   const int s = blockIdx.z, c = blockIdx.y;
   const int i0 = 4 * (blockIdx.x * 64 + threadIdx.x);
-  const int first = p.first_count[s * p.fc_stride], count = p.first_count[s * p.fc_stride + 1];
+  // {first, count} come from the host per call; whatever they hold, no thread reads outside the frame's packet
+  // (the bytes of samples [0, frame_size) are what iamf_hip_lpcm_unpack checked against the raw stride)
+  int first = p.first_count[s * p.fc_stride], count = p.first_count[s * p.fc_stride + 1];
+  first = first < 0 ? 0 : (first > p.lay.frame_size ? p.lay.frame_size : first);
+  count = count < p.lay.frame_size - first ? count : p.lay.frame_size - first;
   if (i0 >= count) return;
   const int off = p.lay.src_offset[c], step = p.lay.src_step[c];
   float *dst = p.out + (int64_t)s * p.out_stride + (int64_t)c * p.lay.frame_size + i0;
