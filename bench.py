@@ -346,7 +346,8 @@ def facade_rates(fs, n_group=64, frames=96):
 
 
 SIGNALS = {"hot": "hot (sigma 0.25 + 1.5 bursts)", "quiet": "quiet (sigma 0.05)",
-           "sparse": "sparse (sigma 0.05 + an 8-sample 1.5 peak every 1531 samples)"}
+           "sparse": "sparse (sigma 0.05 + an 8-sample 1.5 peak every 1531 samples)",
+           "zero": "digital silence (diagnostic: the same instruction stream without data-dependent switching)"}
 # BASELINE.json configs that fit one GPU besides the headline (configs[3] matrix form): measured in
 # the same process and reported under "configs" of the one JSON line (N=1 only)
 # (workload, streams per GPU, placement tries).  BASELINE fixes 512 streams per GPU only for the headline (config 5:
@@ -437,6 +438,8 @@ class Workload:
         x = synth_hot_device(S, in_ch, F, fs, 1000 + rank, dev)
         if args.signal == "quiet":
             x = (torch.randn_like(x) * 0.05).contiguous()
+        if args.signal == "zero":
+            x = torch.zeros_like(x)
         if args.signal == "sparse":
             x = torch.randn_like(x) * 0.05
             tt = torch.arange(F * fs, device=dev).view(1, F, 1, fs)

@@ -92,10 +92,10 @@ __device__ __forceinline__ void w4_transpose_rows(float &r0, float &r1, float &r
 
 // Demixer of scalable channel audio (reference demixer.c:636-664) on a lane's 4 consecutive samples:
 // x[] arrives as the M decoded channels (bitstream order) and leaves as the target layout's channels
-// in playback order.  The channel file, indexed by IAChannel, is a register array; scr = 64 * M floats
+// in playback order.  The channel file, indexed by IAChannel, is a register array; scr = 64 * M (PAIR: 128 * M) floats
 // of LDS private to the wave.
 // Same operations in the same order as the generic kernel's demixer (render_generic.hpp).
-template <int M>
+template <int M, bool PAIR>
 __device__ __forceinline__ void w4_demix(const RenderParams &p, float4 (&x)[M], 
                                          const float (&gin)[M], const int (&row)[kChCount], const float *dmx_rec,
                                          const float *dmx_ws,
@@ -131,12 +131,34 @@ __device__ __forceinline__ void w4_demix(const RenderParams &p, float4 (&x)[M],
       const float g = gin[m];
       x[m].x = x[m].x * g; x[m].y = x[m].y * g; x[m].z = x[m].z * g; x[m].w = x[m].w * g;
     }
+    if constexpr (PAIR) {
+      // two sample positions per pass (8-byte LDS operations, rows of 64 lanes x float2: row[c] = 128 * tab + 2 * lane):
+      // 2 x (M + 23) LDS instructions per lane and chunk instead of 4 x (M + 23), where the wave's area holds 128 * M floats
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+      for (int h = 0; h < 2; ++h) {
 #pragma unroll
-      for (int m = 0; m < M; ++m) scr[64 * m + lane] = w4_comp(x[m], i);
+        for (int m = 0; m < M; ++m)
+          *reinterpret_cast<float2 *>(&scr[128 * m + 2 * lane]) = h == 0 ? make_float2(x[m].x, x[m].y) : make_float2(x[m].z, x[m].w);
 #pragma unroll
-      for (int c = 1; c < kChCount; ++c) w4_set(ch[c], i, scr[row[c]]);
+        for (int c = 1; c < kChCount; ++c) {
+          const float2 v = *reinterpret_cast<const float2 *>(&scr[row[c]]);
+          if (h == 0) {
+            ch[c].x = v.x;
+            ch[c].y = v.y;
+          } else {
+            ch[c].z = v.x;
+            ch[c].w = v.y;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) scr[64 * m + lane] = w4_comp(x[m], i);
+#pragma unroll
+        for (int c = 1; c < kChCount; ++c) w4_set(ch[c], i, scr[row[c]]);
+      }
     }
   }
   const int steps = p.demix_steps;
@@ -373,11 +395,13 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
       }
     }
   };
+  // the demixer's scatter rows lie in the wave's PCM staging area: two sample positions per pass where 128 * M floats fit
+  constexpr bool kDmxPair = DMX && wide4_stage_lanes(C, M, kW4DmxFloats) * wide4_stage_stride(C) * 4 >= 128 * M;
   float dmx_gin[DMX ? M : 1];  // output gain of every decoded channel (wave-uniform)
   int dmx_row[DMX ? kChCount : 1];  // where the lane finds IAChannel c in the wave's scatter rows (w4_demix)
   if constexpr (DMX) {
 #pragma unroll
-    for (int c = 1; c < kChCount; ++c) dmx_row[c] = 64 * p.demix_tab[40 + c] + lane;
+    for (int c = 1; c < kChCount; ++c) dmx_row[c] = kDmxPair ? 128 * p.demix_tab[40 + c] + 2 * lane : 64 * p.demix_tab[40 + c] + lane;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       dmx_gin[m] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__float_as_int(p.demix_ftab[12 + 2 * fs + m])));
@@ -580,7 +604,7 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
       for (int j = 0; j < kW4DmxRecs; ++j) any_mask |= __float_as_int(recs[kW4DmxRec * j + 10]);
       static_assert(wide4_stage_lanes(C, M, kW4DmxFloats) * wide4_stage_stride(C) * 4 >= 64 * M, "scatter rows fit the wave's staging area");
       float *scr = reinterpret_cast<float *>(stage + (tv >> 6) * (wide4_stage_lanes(C, M, kW4DmxFloats) * wide4_stage_stride(C)));
-      w4_demix<M>(p, xw, dmx_gin, dmx_row, recs, dmx_ws, scr, c0, 4 * tv, fs, __builtin_amdgcn_readfirstlane(any_mask));
+      w4_demix<M, kDmxPair>(p, xw, dmx_gin, dmx_row, recs, dmx_ws, scr, c0, 4 * tv, fs, __builtin_amdgcn_readfirstlane(any_mask));
     }
 
     // ---- element renderer + gains (reference operation order), 4 slots x 4 samples at a time ----
