@@ -19,8 +19,9 @@
 // State per stream between calls: w[-1], w[-2], y[-1], y[-2] (lfe_filter_t's two histories).
 #pragma once
 
+#include "lfe_chain_asm.inc"
+
 constexpr int kLfeTileQ = 16;   // quads (of 4 samples) per ff tile
-constexpr int kLfeBlk = 32;     // quads per prefetch block of the chain kernel
 
 struct LfeParams {
   const float *in;            // element PCM (planar per frame, as RenderParams::in)
@@ -114,9 +115,7 @@ __global__ __launch_bounds__(64) void lfe_chain_kernel(const LfeParams p) {
   const float b1 = p.b1, b2 = p.b2;
   float4 *row = p.u_t + (int64_t)sb * p.t4 * 64 + lane;   // this lane's quad q sits at row[64 q]
   const int nfull = p.total >> 2;                          // quads whose four samples all belong to the call
-  // One step: y = (u - b1*y1) - b2*y2, three dependent f32 operations.  The hot loop has nothing else in it:
-  // whole blocks of kLfeBlk quads, no per-quad conditions (the first version carried the short-last-quad
-  // selects and a bounds branch per quad: 35 instructions per quad, 53 cycles per step).
+  // One step: y = (u - b1*y1) - b2*y2, three dependent f32 operations (used for what the main loop leaves).
   auto step4 = [&](const float4 u) {
     float4 o;
     o.x = (u.x - b1 * y1) - b2 * y2;
@@ -127,29 +126,35 @@ __global__ __launch_bounds__(64) void lfe_chain_kernel(const LfeParams p) {
     y1 = o.w;
     return o;
   };
-  float4 bufa[kLfeBlk], bufb[kLfeBlk];
-  const int nblk = nfull / kLfeBlk;  // whole blocks
-  auto load = [&](float4(&buf)[kLfeBlk], int blk) {  // blk < nblk, or a clamped re-read whose values are not used
-    const float4 *src = row + (int64_t)(blk < nblk ? blk : (nblk > 0 ? nblk - 1 : 0)) * kLfeBlk * 64;
-#pragma unroll
-    for (int i = 0; i < kLfeBlk; ++i) buf[i] = src[i * 64];
-  };
-  auto run = [&](const float4(&buf)[kLfeBlk], int blk) {
-    float4 *dst = row + (int64_t)blk * kLfeBlk * 64;
-#pragma unroll
-    for (int i = 0; i < kLfeBlk; ++i) dst[i * 64] = step4(buf[i]);  // in place: the wave writes one contiguous 1 KiB row
-  };
-  if (nblk > 0) load(bufa, 0);
-  int blk = 0;
-  for (; blk + 1 < nblk; blk += 2) {
-    load(bufb, blk + 1);
-    run(bufa, blk);
-    load(bufa, blk + 2);
-    run(bufb, blk + 1);
+  // Main loop: whole rotations of IAMF_LFE_RING quads as one asm statement (lfe_chain_asm.inc, written by
+  // tools/gen_lfe_chain_asm.py): per step v_sub, v_sub and ONE v_pk_mul_f32 that makes b1*y and b2*y from y where it
+  // lies in the output quad; registers by hand, loads a rotation ahead, stores in place.  (As C++ the same loop is
+  // 4.65 instruction slots per step: the compiler pairs the two products too and pays with copies into aligned pairs
+  // and into the store's quad)
+  int q_done = 0;
+  {
+    const int nrot = nfull / IAMF_LFE_RING;
+    if (nrot > 0) {
+      const float4 *base = p.u_t + (int64_t)sb * p.t4 * 64;   // wave-uniform: the block's first row
+      const unsigned voff = (unsigned)lane * 16u;
+      asm volatile(IAMF_LFE_ASM_BODY
+                   : [y1] "+v"(y1), [y2] "+v"(y2)
+                   : [base] "s"(base), [nrot] "s"(nrot), [voff] "v"(voff), [b1] "v"(b1), [b2] "v"(b2)
+                   : IAMF_LFE_ASM_CLOBBERS);
+      q_done = nrot * IAMF_LFE_RING;
+    }
   }
-  if (blk < nblk) run(bufa, blk);
-  // what is left: fewer than kLfeBlk whole quads, then at most one quad that the call ends inside
-  for (int q = nblk * kLfeBlk; q < nfull; ++q) row[(int64_t)q * 64] = step4(row[(int64_t)q * 64]);
+  // what is left: fewer than a rotation of whole quads — all their loads first, then the steps (wave-uniform guards)
+  {
+    const int nrem = nfull - q_done;
+    float4 rem[IAMF_LFE_RING];
+#pragma unroll
+    for (int i = 0; i < IAMF_LFE_RING; ++i)
+      if (i < nrem) rem[i] = row[(int64_t)(q_done + i) * 64];
+#pragma unroll
+    for (int i = 0; i < IAMF_LFE_RING; ++i)
+      if (i < nrem) row[(int64_t)(q_done + i) * 64] = step4(rem[i]);
+  }
   const int left = p.total - 4 * nfull;  // 0..3 samples in the last quad
   if (left > 0) {
     const float4 u = row[(int64_t)nfull * 64];
