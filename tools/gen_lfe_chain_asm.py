@@ -22,6 +22,7 @@ operations retire in order, one s_waitcnt vmcnt(2R - 8) per four quads).  The la
 """
 import os
 
+FMA = os.environ.get("LFE_ASM_FMA", "0") == "1"   # experiment: products as v_pk_fma_f32 with a (-0, -0) addend
 R = 32            # quads per rotation (vmcnt is a 6-bit counter: 2 (R - 1) <= 63)
 RING0 = 16
 K = [(4, 5), (6, 7), (8, 9), (10, 11)]
@@ -43,8 +44,12 @@ def quad(slot, off, wait):
     for i, (p, q, pair, half, dst) in enumerate(steps):
         lines.append("v_sub_f32 v%d, v%d, v%d" % (a + i, a + i, p))
         lines.append("v_sub_f32 v%d, v%d, v%d" % (a + i, a + i, q))
-        lines.append("v_pk_mul_f32 v[%d:%d], v[%d:%d], v[2:3] op_sel:[%d,0] op_sel_hi:[%d,1]"
-                     % (dst[0], dst[1], pair[0], pair[1], half, half))
+        if FMA:   # y * b + (-0) is y * b bit for bit (a -0 product stays -0); v_pk_fma_f32 issues faster than v_pk_mul_f32
+            lines.append("v_pk_fma_f32 v[%d:%d], v[%d:%d], v[2:3], v[12:13] op_sel:[%d,0,0] op_sel_hi:[%d,1,1]"
+                         % (dst[0], dst[1], pair[0], pair[1], half, half))
+        else:
+            lines.append("v_pk_mul_f32 v[%d:%d], v[%d:%d], v[2:3] op_sel:[%d,0] op_sel_hi:[%d,1]"
+                         % (dst[0], dst[1], pair[0], pair[1], half, half))
     lines.append("global_store_dwordx4 v0, v[%d:%d], s[42:43] offset:%d" % (a, a + 3, off))
     lines.append("global_load_dwordx4 v[%d:%d], v0, s[46:47] offset:%d" % (a, a + 3, off))
     return lines
@@ -53,7 +58,7 @@ def quad(slot, off, wait):
 def body():
     L = []
     L += ["s_mov_b64 s[40:41], %[base]", "s_mov_b32 s44, %[nrot]", "v_mov_b32 v0, %[voff]", "v_mov_b32 v2, %[b1]",
-          "v_mov_b32 v3, %[b2]",
+          "v_mov_b32 v3, %[b2]", "v_mov_b32 v12, 0x80000000", "v_mov_b32 v13, 0x80000000",
           "v_mul_f32 v10, v2, %[y1]", "v_mul_f32 v11, v3, %[y1]", "v_mul_f32 v9, v3, %[y2]",
           "s_add_u32 s46, s40, 4096", "s_addc_u32 s47, s41, 0"]
     for g in range(R // 8):      # the first rotation's rows
