@@ -31,6 +31,7 @@ from .hipabi import (  # noqa: F401
     fir_matrix,
     IamfHipError,
     LpcmLayout,
+    LpcmInput,
     Matrix,
     build,
     get_h2m_matrix,

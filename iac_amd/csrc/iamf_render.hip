@@ -47,6 +47,8 @@
 extern "C" int iamf_hip_fir_m2b_has(int m);                                           // iamf_render_fir_m2b.hip
 extern "C" int iamf_hip_fir_m2b_launch(const void *params, int m, hipStream_t st);    // iamf_render_fir_m2b.hip
 extern "C" int iamf_hip_fir_m2b_launch_fft(const void *params, int m, hipStream_t st);  // iamf_render_fir_m2b.hip
+extern "C" int iamf_hip_fast_lpcm_has(int m, int oc);                                   // iamf_render_lpcm.hip
+extern "C" int iamf_hip_fast_lpcm_launch(const void *params, int m, hipStream_t st);   // iamf_render_lpcm.hip
 extern "C" int iamf_hip_wide4_has_mix(int m, int c);                                  // iamf_render_wide4_mix.hip
 extern "C" int iamf_hip_wide4_mix_launch(const void *params, int m, hipStream_t st);  // iamf_render_wide4_mix.hip
 extern "C" int iamf_hip_wide4_has_lfe(int m, int c);                                  // iamf_render_wide4_lfe.hip
@@ -221,6 +223,11 @@ struct iamf_hip_batch {
   size_t fir_pre_bytes = 0;
   float *d_fir_y = nullptr;                         // [n_streams][2][total] f32: its output when it runs as its own kernel
   size_t fir_y_floats = 0;
+  // iamf_hip_batch_render_lpcm, calls the fused kernel does not take: the unpacked element and the unpacker's {first, count}
+  float *d_lp_in = nullptr;
+  size_t lp_in_floats = 0;
+  int32_t *d_lp_fc = nullptr;
+  int32_t lp_fc[2] = {-1, -1};
   float *d_fir_id = nullptr;                        // 2 x 2 identity + slot map for the limiter / pack kernel behind it
   int32_t *d_fir_id_feed = nullptr;
   float fir_inv_scale = 1.f;
@@ -450,6 +457,11 @@ bool wide4_path_ok(const RenderParams &p, int m) {
 
 int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
   dim3 grid((unsigned)p.n_launch);
+  if (p.lpcm) {  // element 0 as LPCM packets: render_call has checked that this is a call of the fast kernel
+    if (!iamf_hip_fast_lpcm_launch(&p, m, st)) return IAMF_HIP_ERR_INVALID_STATE;
+    HIPCHK(hipGetLastError());
+    return IAMF_HIP_OK;
+  }
   if (p.fir_taps > 0 && p.in) {  // HRTF renderer: aligned calls only (the flush goes to the generic kernel)
     if (!fast_path_ok(p)) return IAMF_HIP_ERR_UNIMPLEMENTED;
     // the FIR stage keeps input offsets of one stream as 32-bit integers
@@ -550,8 +562,21 @@ const int kLayoutSurround[9] = {1, 2, 5, 5, 5, 7, 7, 7, 3};
 const int kLayoutTop[9] = {0, 0, 0, 2, 4, 0, 2, 4, 2};
 
 // streams [s0, s0 + cnt) of the batch; they must stand at the same position (samples consumed so far)
-int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int s0, int cnt) {
+// Element 0 as LPCM packets for the fused kernel (render_fast_kernel<.., LP>, iamf_render_lpcm.hip).  render_call
+// returns kNotFused — before it has changed or launched anything — when the call is not one that kernel takes; the caller
+// (iamf_hip_batch_render_lpcm) then unpacks to f32 and renders as usual.
+struct LpcmIn {
+  const uint8_t *raw;
+  int64_t stream_stride, frame_stride;
+  int32_t off[16];
+};
+constexpr int kNotFused = INT32_MIN;
+
+int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int s0, int cnt, const LpcmIn *lp = nullptr) {
   if (!on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
+  if (lp && (b->fir || b->lfe || b->d_pre || b->demix || b->dmx || b->has2 || a.d_element_ramp || a.d_element2_ramp ||
+             a.d_output_ramp || getenv("IAMF_HIP_LPCM_UNFUSED")))
+    return kNotFused;
   if (s0 < 0 || cnt <= 0 || s0 + cnt > b->cfg.n_streams) return IAMF_HIP_ERR_BAD_ARG;
   const int64_t pos = b->spos[(size_t)s0];
   for (int i = s0; i < s0 + cnt; ++i)
@@ -648,6 +673,13 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int
     p.demix_layout = b->demix_layout;
     p.demix_gmask = b->demix_gmask;
     p.demix_w4 = b->demix_w4;
+  }
+  if (lp) {
+    p.lpcm = lp->raw;
+    p.lpcm_stream_stride = lp->stream_stride;
+    p.lpcm_frame_stride = lp->frame_stride;
+    for (int m = 0; m < 16; ++m) p.lpcm_off[m] = lp->off[m];
+    if (!fast_path_ok(p) || !iamf_hip_fast_lpcm_has(m_eff, p.out_ch)) return kNotFused;
   }
   if (b->fir) {
     p.fir_taps = b->fir_taps;
@@ -1061,6 +1093,8 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_fir_pre[0]);
   (void)hipFree(b->d_fir_pre[1]);
   (void)hipFree(b->d_fir_y);
+  (void)hipFree(b->d_lp_in);
+  (void)hipFree(b->d_lp_fc);
   (void)hipFree(b->d_fir_id);
   (void)hipFree(b->d_fir_id_feed);
   (void)hipFree(b->d_lfe_state);
@@ -1089,7 +1123,7 @@ int iamf_hip_batch_set_gains(iamf_hip_batch *b, const float *eg, const float *og
   return IAMF_HIP_OK;
 }
 
-int iamf_hip_batch_render_range(iamf_hip_batch *b, const iamf_hip_render_args *a, int32_t stream0, int32_t n_streams) {
+static int render_range_impl(iamf_hip_batch *b, const iamf_hip_render_args *a, int32_t stream0, int32_t n_streams, const LpcmIn *lp) {
   if (!b || !a || !a->d_in || !a->d_pcm || a->n_frames < 0) return IAMF_HIP_ERR_BAD_ARG;
   if (stream0 < 0 || n_streams <= 0 || stream0 + n_streams > b->cfg.n_streams) return IAMF_HIP_ERR_BAD_ARG;
   if (a->n_frames == 0) return 0;
@@ -1111,7 +1145,83 @@ int iamf_hip_batch_render_range(iamf_hip_batch *b, const iamf_hip_render_args *a
   const int64_t need = (total * sc + (b->cfg.out_channels > sc ? b->cfg.out_channels - sc : 0)) *
                        iamf_hip_format_bytes(b->cfg.out_format);
   if (b->cfg.n_streams > 1 && a->pcm_stream_stride_bytes < need) return IAMF_HIP_ERR_BUFFER_TOO_SMALL;
-  return render_call(b, *a, (int)total, stream0, n_streams);
+  return render_call(b, *a, (int)total, stream0, n_streams, lp);
+}
+
+int iamf_hip_batch_render_range(iamf_hip_batch *b, const iamf_hip_render_args *a, int32_t stream0, int32_t n_streams) {
+  return render_range_impl(b, a, stream0, n_streams, nullptr);
+}
+
+// Element 0 as LPCM packets.  Fused (render_fast_kernel<.., LP>: the packets' 16-bit samples are converted where the
+// render kernel loads them) when the call is one of the headline kernel's and every channel is a contiguous run of
+// little-endian 16-bit samples; in every other case exactly what the caller would do itself: iamf_hip_lpcm_unpack into a
+// buffer of the batch, then the f32 path.  Both give the same PCM bit for bit.
+int iamf_hip_batch_render_lpcm(iamf_hip_batch *b, const iamf_hip_lpcm_input *in, const iamf_hip_render_args *args) {
+  if (!b || !in || !args || !in->d_raw || args->d_in || !args->d_pcm || args->n_frames < 0) return IAMF_HIP_ERR_BAD_ARG;
+  if (!on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
+  if (args->n_frames == 0) return 0;
+  const iamf_hip_lpcm_layout &L = in->layout;
+  const int fs = b->cfg.frame_size, ch = b->d_pre ? b->pre_l : b->m, ns = b->cfg.n_streams, nf = args->n_frames;
+  if (L.sample_bytes < 2 || L.sample_bytes > 4 || L.channels != ch || ch > IAMF_HIP_LPCM_MAX_CHANNELS || L.frame_size != fs ||
+      (fs & 3) || in->raw_frame_stride <= 0 || in->raw_stream_stride < (int64_t)nf * in->raw_frame_stride)
+    return IAMF_HIP_ERR_BAD_ARG;
+  const int first = in->first_sample, count = args->n_samples > 0 ? args->n_samples : fs;
+  if (first < 0 || (first > 0 && (nf != 1 || args->n_samples <= 0)) || first + count > fs) return IAMF_HIP_ERR_BAD_ARG;
+  bool fusable = L.sample_bytes == 2 && L.little_endian && ch <= 16 && (in->raw_frame_stride & 7) == 0 &&
+                 (in->raw_stream_stride & 7) == 0 && (reinterpret_cast<uintptr_t>(in->d_raw) & 15) == 0;
+  for (int c = 0; c < ch; ++c) {   // every byte a kernel may read lies inside the frame's packet row (as iamf_hip_lpcm_unpack)
+    if (L.src_offset[c] < 0) {
+      fusable = false;
+      continue;
+    }
+    if (L.src_step[c] < L.sample_bytes ||
+        (int64_t)L.src_offset[c] + (int64_t)(fs - 1) * L.src_step[c] + L.sample_bytes > in->raw_frame_stride)
+      return IAMF_HIP_ERR_BAD_ARG;
+    if (L.src_step[c] != 2 || ((L.src_offset[c] + 2 * first) & 7)) fusable = false;
+  }
+  iamf_hip_render_args a = *args;
+  if (fusable) {
+    LpcmIn lp;
+    memset(&lp, 0, sizeof(lp));
+    lp.raw = static_cast<const uint8_t *>(in->d_raw);
+    lp.stream_stride = in->raw_stream_stride;
+    lp.frame_stride = in->raw_frame_stride;
+    for (int c = 0; c < ch; ++c) lp.off[c] = L.src_offset[c] + 2 * first;
+    a.d_in = reinterpret_cast<const float *>(in->d_raw);   // not read by the fused kernel; non-null = "not a flush"
+    a.in_stream_stride = a.in_frame_stride = 0;
+    const int r = render_range_impl(b, &a, 0, ns, &lp);
+    if (r != kNotFused) return r;
+  }
+  hipStream_t st = static_cast<hipStream_t>(args->stream);
+  const size_t need = (size_t)ns * nf * ch * fs;
+  if (need > b->lp_in_floats) {   // grows with the largest call seen
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(b->d_lp_in);
+    b->d_lp_in = nullptr;
+    b->lp_in_floats = 0;
+    HIPCHK(hipMalloc(&b->d_lp_in, sizeof(float) * need));
+    // rows of channels no sub-stream carries (src_offset < 0) are never written by the unpacker: keep them defined
+    HIPCHK(hipMemset(b->d_lp_in, 0, sizeof(float) * need));
+    b->lp_in_floats = need;
+  }
+  if (!b->d_lp_fc) HIPCHK(hipMalloc(&b->d_lp_fc, sizeof(int32_t) * 2));
+  if (b->lp_fc[0] != first || b->lp_fc[1] != count) {
+    const int q = quiesce(b);   // an unpacker queued earlier may still be reading the pair
+    if (q != IAMF_HIP_OK) return q;
+    b->lp_fc[0] = first;
+    b->lp_fc[1] = count;
+    HIPCHK(hipMemcpy(b->d_lp_fc, b->lp_fc, sizeof(b->lp_fc), hipMemcpyHostToDevice));
+  }
+  for (int f = 0; f < nf; ++f) {   // one {first, count} pair for all streams: stride 0
+    const int r = iamf_hip_lpcm_unpack(&L, static_cast<const uint8_t *>(in->d_raw) + (int64_t)f * in->raw_frame_stride,
+                                       in->raw_stream_stride, b->d_lp_fc, 0, b->d_lp_in + (size_t)f * ch * fs,
+                                       (int64_t)nf * ch * fs, ns, st);
+    if (r != IAMF_HIP_OK) return r;
+  }
+  a.d_in = b->d_lp_in;
+  a.in_stream_stride = (int64_t)nf * ch * fs;
+  a.in_frame_stride = (int64_t)ch * fs;
+  return render_range_impl(b, &a, 0, ns, nullptr);
 }
 
 int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *a) {

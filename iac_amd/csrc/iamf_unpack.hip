@@ -85,7 +85,7 @@ extern "C" int iamf_hip_upload_by_kernel(const void *h_pinned, void *d_dst, size
 extern "C" int iamf_hip_lpcm_unpack(const iamf_hip_lpcm_layout *lay, const void *d_raw, int64_t raw_stream_stride,
                                     const int32_t *d_first_count, int64_t first_count_stride, float *d_out,
                                     int64_t out_stream_stride, int32_t n_streams, void *stream) {
-  if (!lay || !d_raw || !d_first_count || first_count_stride < 2 || !d_out || n_streams <= 0) return IAMF_HIP_ERR_BAD_ARG;
+  if (!lay || !d_raw || !d_first_count || (first_count_stride < 2 && first_count_stride != 0) || !d_out || n_streams <= 0) return IAMF_HIP_ERR_BAD_ARG;
   if (lay->sample_bytes < 2 || lay->sample_bytes > 4 || lay->channels <= 0 || lay->channels > IAMF_HIP_LPCM_MAX_CHANNELS ||
       lay->frame_size <= 0 || (lay->frame_size & 3) || raw_stream_stride <= 0 || out_stream_stride < (int64_t)lay->channels * lay->frame_size)
     return IAMF_HIP_ERR_BAD_ARG;

@@ -136,6 +136,13 @@ struct RenderParams {
   float *fir_y;             // device scratch [n_streams][2][total]: the FFT stage's output when it runs as a kernel of its own
   const float *fir_id_matrix;   // device: the 2 x 2 identity (feed-major) and its slot map, for the limiter / pack kernel behind it
   const int32_t *fir_id_feed;
+  // ---- element 0 handed over as LPCM packets (render_fast_kernel<.., LP>, iamf_hip_batch_render_lpcm): 16-bit
+  //      little-endian samples, one contiguous run per channel and frame.  Sample i of channel m, frame f, stream s:
+  //      lpcm + s * lpcm_stream_stride + f * lpcm_frame_stride + lpcm_off[m] + 2 * i (bytes; every term a multiple of 8
+  //      for i a multiple of 4).  `in` is not read then ----
+  const uint8_t *lpcm;
+  int64_t lpcm_stream_stride, lpcm_frame_stride;
+  int32_t lpcm_off[16];
 };
 
 // IAChannel ids (reference IAMF_types.h:61-90; L5/R5 alias L7/R7)

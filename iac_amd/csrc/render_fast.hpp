@@ -203,9 +203,13 @@ constexpr int kFIn2 = 4;
 // FIR:  0 = gain matrix; 1 = HRTF stage on the f32 MFMA (render_fir.hpp); 2 = HRTF stage on the f16
 //       MFMA with split operands (render_fir16.hpp); 3 = HRTF stage by overlap-save FFT on the VALU
 //       (render_fir_fft.hpp: one pass per THREE chunks, a wave per 768-sample hop)
-template <int M, int OC, int FIR = 0, bool DOWN = false, bool IN2 = false>
+// LP:   element 0 arrives as 16-bit little-endian LPCM packets (RenderParams::lpcm) instead of planar f32: the
+//       reference's LPCM "decoder" (pcm/IAMF_pcm_decoder.c:64-83: sample / 32768.f) runs where the samples are loaded,
+//       8 bytes per lane and channel instead of 16, and the f32 copy of the element never exists in HBM.
+template <int M, int OC, int FIR = 0, bool DOWN = false, bool IN2 = false, bool LP = false>
 __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <= 16 && !IN2)) ? 4 : 2)) void render_fast_kernel(const RenderParams p) {
   static_assert(!(FIR && DOWN), "one renderer");
+  static_assert(!(LP && (FIR || DOWN || IN2)) && (!LP || M <= 16), "the LPCM input feeds the plain matrix variant");
   static_assert(!(IN2 && (FIR || DOWN)), "the second element joins a matrix-rendered first one");
   extern __shared__ float lds[];
   constexpr int R = kFRing;
@@ -321,6 +325,28 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
 
   // input of the first chunk
   float4 x[FIR ? 1 : M];
+  // LP: the prefetched packets' samples as they lie in memory (four 16-bit samples per channel), converted at the top of
+  // the chunk that uses them: (float)sample * (1 / 32768), the expression of iamf_hip_lpcm_unpack and of the reference
+  using lp_u2 = __attribute__((ext_vector_type(2))) unsigned;
+  lp_u2 xr[LP ? M : 1];
+  const uint8_t *lp_s = LP ? p.lpcm + (int64_t)s * p.lpcm_stream_stride : nullptr;
+  auto load_lp = [&](int f, int i) {
+    if constexpr (LP) {
+      const uint8_t *src = lp_s + (int64_t)f * p.lpcm_frame_stride + 2 * i;
+#pragma unroll
+      for (int m = 0; m < M; ++m) xr[m] = __builtin_nontemporal_load(reinterpret_cast<const lp_u2 *>(src + p.lpcm_off[m]));
+    }
+  };
+  auto convert_lp = [&]() {
+    if constexpr (LP) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const unsigned a = xr[m].x, b = xr[m].y;
+        x[m] = make_float4((float)(int)(short)(a & 0xffffu) * (1.0f / 32768.0f), (float)((int)a >> 16) * (1.0f / 32768.0f),
+                           (float)(int)(short)(b & 0xffffu) * (1.0f / 32768.0f), (float)((int)b >> 16) * (1.0f / 32768.0f));
+      }
+    }
+  };
   float drec[DOWN ? 11 : 1];  // DOWN: the frame record of the lane's samples, fetched with them
   const int dmx_nfr = DOWN ? (p.total + fs - 1) / fs : 0;
   auto load_drec = [&](int f) {
@@ -335,11 +361,17 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
     if (k < p.total) {
       const int f = k / fs;
       const int i = k - f * fs;
-      const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
+      if constexpr (LP) {
+        load_lp(f, i);
+      } else {
+        const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
 #pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
+        for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
+      }
       load_x2(f, i);
     } else {
+#pragma unroll
+      for (int m = 0; m < (LP ? M : 0); ++m) xr[m] = lp_u2{0u, 0u};
 #pragma unroll
       for (int m = 0; m < M; ++m) x[m] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -377,6 +409,7 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
     // ---- element renderer + gains (reference operation order) ----
     float4 y[OC];
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
+    convert_lp();   // LP: the chunk's packets -> f32 (lanes past the end of the call keep what they hold: never used)
     if constexpr (FIR == 2) {  // both ears of this chunk AND the next three -> LDS (one pass per four chunks)
       if (((c0 >> 10) & 3) == 0) fir_stage16<M>(p, in_s, fir_hist, c0, fir, fir);
     }
@@ -488,9 +521,13 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
       if (kn < p.total) {
         const int f = kn / fs;
         const int i = kn - f * fs;
-        const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
+        if constexpr (LP) {
+          load_lp(f, i);
+        } else {
+          const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
 #pragma unroll
-        for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
+          for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
+        }
         load_drec(f);
         load_x2(f, i);
       }

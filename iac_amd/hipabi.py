@@ -64,6 +64,11 @@ class LpcmLayout(C.Structure):   # iamf_hip_lpcm_layout
                 ("src_offset", C.c_int32 * 32), ("src_step", C.c_int32 * 32)]
 
 
+class LpcmInput(C.Structure):   # iamf_hip_lpcm_input
+    _fields_ = [("d_raw", C.c_void_p), ("raw_stream_stride", C.c_int64), ("raw_frame_stride", C.c_int64),
+                ("first_sample", C.c_int32), ("layout", LpcmLayout)]
+
+
 class DemixConfig(C.Structure):
     _fields_ = [("layout", C.c_int32), ("n_in", C.c_int32), ("chs_in", C.c_int32 * 12), ("n_gain", C.c_int32),
                 ("gain_ch", C.c_int32 * 12), ("gain", C.c_float * 12), ("frame_offset", C.c_uint32)]
@@ -127,6 +132,7 @@ def lib():
         L.iamf_hip_format_bytes.argtypes = [C.c_int]
         L.iamf_hip_version.restype = C.c_char_p
         L.iamf_hip_batch_render_ex.argtypes = [C.c_void_p, C.POINTER(RenderArgs)]
+        L.iamf_hip_batch_render_lpcm.argtypes = [C.c_void_p, C.POINTER(LpcmInput), C.POINTER(RenderArgs)]
         L.iamf_hip_batch_set_second_element.argtypes = [C.c_void_p, C.POINTER(Matrix), FP]
         L.iamf_hip_resampler_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.iamf_hip_resampler_destroy.argtypes = [C.c_void_p]
@@ -276,6 +282,13 @@ class Batch:
         r = lib().iamf_hip_batch_render_ex(self.h, C.byref(args))
         if r < 0:
             raise IamfHipError(r, "iamf_hip_batch_render_ex")
+        return r
+
+    def render_lpcm(self, lpcm_input, args):
+        """iamf_hip_batch_render_lpcm: element 0 as LPCM packets (LpcmInput), `args` a RenderArgs with d_in = None"""
+        r = lib().iamf_hip_batch_render_lpcm(self.h, C.byref(lpcm_input), C.byref(args))
+        if r < 0:
+            raise IamfHipError(r, "iamf_hip_batch_render_lpcm")
         return r
 
     def render_range(self, args, stream0, n_streams):

@@ -426,7 +426,7 @@ const char *iamf_hip_shard_rccl_version(void);
  * from one sample of the channel to the next: sample_bytes for a mono sub-stream, twice that for a coupled one);
  * src_offset[c] < 0 = a channel no sub-stream carries: silence.  d_first_count: on the device, per stream two int32,
  * `first_count_stride` int32 from one stream's pair to the next (2 for a packed array; raw_stream_stride / 4 for pairs
- * kept at the head of each stream's raw region, so that one upload carries both): the first sample to take (a trimmed
+ * kept at the head of each stream's raw region, so that one upload carries both; 0: one pair for all streams): the first sample to take (a trimmed
  * start, iamf_frame_trim IAMF_decoder.c:1361-1381) and the number of samples to write (0: the stream is left alone);
  * first + count <= frame_size is the caller's to guarantee.  Output:
  * d_out[stream * out_stream_stride + c * frame_size + i], i < count.  Asynchronous on `stream`.
@@ -445,6 +445,30 @@ typedef struct iamf_hip_lpcm_layout {
 int iamf_hip_lpcm_unpack(const iamf_hip_lpcm_layout *layout, const void *d_raw, int64_t raw_stream_stride,
                          const int32_t *d_first_count, int64_t first_count_stride, float *d_out, int64_t out_stream_stride,
                          int32_t n_streams, void *stream);
+
+/* Render with element 0 handed over as LPCM packets instead of planar f32: iamf_hip_lpcm_unpack and iamf_hip_batch_render_ex
+ * in one call, and for the calls of the headline kernel in one KERNEL — the reference decodes a packet into its f32 decoder
+ * buffer (pcm/IAMF_pcm_decoder.c:64-83) and renders from there (IAMF_decoder.c:2550-2640); on the device that f32 copy is
+ * 64 of the path's 68 bytes per sample-frame, so the render kernel reads the packets' 16-bit samples itself (32 + 4 bytes)
+ * and converts them where it loads them.  d_raw: [n_streams][n_frames] packet rows, frame f of stream s at
+ * d_raw + s * raw_stream_stride + f * raw_frame_stride (bytes), described by `layout` exactly as for iamf_hip_lpcm_unpack
+ * (offsets relative to the frame's row; layout.channels = the element's channels, layout.frame_size = the batch's).
+ * first_sample: with args->n_frames == 1 and args->n_samples > 0, the frame position of the first sample to render (a
+ * trimmed start); else 0.  `args` as for iamf_hip_batch_render_ex with d_in == NULL (the in_* strides are not used).
+ * Fused when: 16-bit little-endian, every channel a contiguous run (src_step == 2) at an offset that is a multiple of 8
+ * bytes (with first_sample), strides multiples of 8, d_raw 16-byte aligned, and the batch is a plain matrix render of a
+ * 1 / 4 / 9 / 16-channel element into one or two channels with the limiter on (no second element, ramps, demixer, down-mixer,
+ * de-mapping, FIR or LFE generator).  Every other input — 24 / 32 bit, big-endian, coupled sub-streams, wide layouts —
+ * takes iamf_hip_lpcm_unpack into a buffer of the batch and then the f32 kernels.  The PCM is the same bit for bit either
+ * way (tests/test_gpu_lpcm.py); IAMF_HIP_LPCM_UNFUSED=1 in the environment forces the second way.
+ * Returns what iamf_hip_batch_render_ex returns. */
+typedef struct iamf_hip_lpcm_input {
+  const void *d_raw;
+  int64_t raw_stream_stride, raw_frame_stride;   /* bytes */
+  int32_t first_sample;
+  iamf_hip_lpcm_layout layout;
+} iamf_hip_lpcm_input;
+int iamf_hip_batch_render_lpcm(iamf_hip_batch *b, const iamf_hip_lpcm_input *in, const iamf_hip_render_args *args);
 
 /* Host -> device by a kernel that reads pinned host memory (hipHostMalloc) over PCIe, 16 bytes per lane: the bytes of a
  * hipMemcpyAsync without leaving the compute queue, for callers that put a small upload between kernels (a pinned
