@@ -38,6 +38,10 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 WORKLOADS = {
     # name: (kind, in_id, out_id, in_ch, algorithmic bytes per sample-frame)
     "toa_binaural_limiter_s16": ("h2m", 3, 0x1020, 16, 16 * 4 + 2 * 2),
+    # SURVEY §8 N1 on the device: the headline with element 0 handed over as the stream's own 16-bit LPCM packets
+    # (iamf_hip_batch_render_lpcm: the reference's pcm decoder, IAMF_pcm_decoder.c:64-83, fused into the render kernel's
+    # loads) instead of the f32 decoder buffer: 16 x 2 B read + 2 x 2 B written per sample-frame
+    "toa_binaural_limiter_s16_lpcm16": ("h2m_lpcm", 3, 0x1020, 16, 16 * 2 + 2 * 2),
     "toa_ssH_limiter_s16": ("h2m", 3, 0x9A3, 16, 16 * 4 + 24 * 2),
     "toa_ssB_limiter_s16": ("h2m", 3, 0x050, 16, 16 * 4 + 6 * 2),
     # the same with the HOA LFE generator on (h2m_rdr.c:1151-1239, the reference built
@@ -357,6 +361,8 @@ SIGNALS = {"hot": "hot (sigma 0.25 + 1.5 bursts)", "quiet": "quiet (sigma 0.05)"
 # streams per GPU = a whole number of rounds of the workgroups a CU holds (256 CUs x 3 for the 12-channel kernel,
 # x 2 for the 24-channel and HRTF kernels)
 EXTRA_CONFIGS = [("714_ssJ_limiter_s16", 3072, 4), ("toa_ssH_limiter_s16", 2048, 4), ("toa_hrtf256_limiter_s16", 1024, 1),
+                 # the headline fed with the stream's own 16-bit LPCM packets (SURVEY 8 N1 on the device; 36 B per sample-frame)
+                 ("toa_binaural_limiter_s16_lpcm16", 2048, 1),
                  # secondary kernels of SURVEY 8 rows N2 / N4 / A5: in the driver's line so that it times them
                  ("scalable_714_ssJ_limiter_s16", 2048, 1), ("toa_ssB_lfe_limiter_s16", 1024, 1),
                  ("710_downmix_stereo_limiter_s16", 1024, 1)]
@@ -372,6 +378,8 @@ def kernel_tag(kind, in_ch, out_ch):
                 "render_wide4_kernel<%d, %d, false, false, true") % (in_ch, out_ch)
     if kind == "demix":
         return "render_wide4_kernel<%d, %d, false, true" % (in_ch, out_ch)
+    if kind == "h2m_lpcm":
+        return "render_fast_kernel<%d, %d, 0, false, false, true" % (in_ch, out_ch)
     if kind == "fir":
         # default: the overlap-save FFT stage as a kernel of its own (the dominant one) + the two-channel matrix kernel over
         # its output; IAMF_HIP_FIR_FUSED: the same stage inside the limiter kernel (3); _F16 / _F32: the MFMA stages (2 / 1)
@@ -405,7 +413,7 @@ class Workload:
         elif kind == "dmx":
             mx = A.dmx_matrix(in_id, out_id)
         else:
-            mx = A.get_h2m_matrix(in_id, out_id) if kind in ("h2m", "h2m_proj", "h2m_in2", "h2m_lfe") else A.get_m2m_matrix(in_id, out_id)
+            mx = A.get_h2m_matrix(in_id, out_id) if kind in ("h2m", "h2m_proj", "h2m_in2", "h2m_lfe", "h2m_lpcm") else A.get_m2m_matrix(in_id, out_id)
         out_ch = self.out_ch = mx.channels if kind == "dmx" else A.layout_channels(out_id)
         self.mx = mx
         S, F, fs = args.streams, args.frames, args.frame_size
@@ -498,6 +506,22 @@ class Workload:
                              SL7, SR7, HFL, HFR], dim=2).contiguous()
             del L7, R7, Cc, LFE, SL7, SR7, BL7, BR7, HFL, HFR, HBL, HBR, SL5, SR5, L2, R2, HL, HR
         n = F * in_ch * fs
+        self.raw = None
+        if kind == "h2m_lpcm":
+            # the programme as a 16-bit LPCM stream carries it: one mono sub-stream packet per ambisonics channel and frame
+            # (fs x 2 bytes), the packets of a frame one after the other, frames back to back, streams 4 KiB apart like the
+            # f32 buffer's.  What the oracle is given (self.x) is the reference's decode of those packets: sample / 32768.
+            q = torch.clamp(torch.round(x * 32768.0), -32768, 32767).to(torch.int16)
+            self.raw_frame, self.raw_stride = in_ch * fs * 2, F * in_ch * fs * 2 + args.pad_kb * 1024
+            self.raw = torch.zeros((S, self.raw_stride), dtype=torch.uint8, device=dev)
+            self.raw[:, :F * self.raw_frame] = q.reshape(S, -1).view(torch.uint8)
+            x = q.to(torch.float32) * (1.0 / 32768.0)
+            L = A.LpcmLayout()
+            L.sample_bytes, L.little_endian, L.channels, L.frame_size = 2, 1, in_ch, fs
+            for c_ in range(in_ch):
+                L.src_offset[c_], L.src_step[c_] = c_ * fs * 2, 2
+            self.lpcm_layout = L
+            del q
         if self.x is None:
             self.x = torch.zeros((S, self.stream_stride), dtype=torch.float32, device=dev)
         self.x[:, :n] = x.reshape(S, -1)   # into the chosen buffer
@@ -580,7 +604,13 @@ class Workload:
         A, kind = self.A, self.kind
         if ev_pair:
             ev_pair[0].record()
-        if self.extra is not None:
+        if kind == "h2m_lpcm":
+            inp, a = A.LpcmInput(), A.RenderArgs()
+            inp.d_raw, inp.raw_stream_stride, inp.raw_frame_stride = self.raw.data_ptr(), self.raw_stride, self.raw_frame
+            inp.layout = self.lpcm_layout
+            a.n_frames, a.d_pcm, a.pcm_stream_stride_bytes, a.stream = self.F, buf.data_ptr(), self.stride_bytes, self.stream
+            n = self.batch.render_lpcm(inp, a)
+        elif self.extra is not None:
             a = A.RenderArgs()
             a.d_in, a.in_stream_stride, a.in_frame_stride = self.x.data_ptr(), self.stream_stride, self.frame_stride
             a.n_frames, a.d_pcm, a.pcm_stream_stride_bytes, a.stream = self.F, buf.data_ptr(), self.stride_bytes, self.stream
@@ -664,7 +694,7 @@ class Workload:
         out_ch / 2 x 16 B written per lane and chunk), timed like the render kernel.  Runs after the timed
         regions (it overwrites the PCM buffer).  None where the shape has no probe (odd channel counts)."""
         A = self.A
-        if self.fs != 1024 or self.out_ch % 2 and self.out_ch != 1:
+        if self.fs != 1024 or self.out_ch % 2 and self.out_ch != 1 or self.kind == "h2m_lpcm":   # (the probe reads 16-byte pieces)
             return None
         rows, pieces = self.in_ch, max(1, self.out_ch // 2)
         in_stride_b = self.stream_stride * 4

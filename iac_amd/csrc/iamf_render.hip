@@ -47,6 +47,10 @@
 extern "C" int iamf_hip_fir_m2b_has(int m);                                           // iamf_render_fir_m2b.hip
 extern "C" int iamf_hip_fir_m2b_launch(const void *params, int m, hipStream_t st);    // iamf_render_fir_m2b.hip
 extern "C" int iamf_hip_fir_m2b_launch_fft(const void *params, int m, hipStream_t st);  // iamf_render_fir_m2b.hip
+extern "C" int iamf_hip_lpcm_unpack_frames(const iamf_hip_lpcm_layout *lay, const void *d_raw, int64_t raw_stream_stride,   // iamf_unpack.hip
+                                           int64_t raw_frame_stride, int32_t n_frames, const int32_t *d_first_count,
+                                           int64_t first_count_stride, float *d_out, int64_t out_stream_stride,
+                                           int64_t out_frame_stride, int32_t n_streams, void *stream);
 extern "C" int iamf_hip_fast_lpcm_has(int m, int oc);                                   // iamf_render_lpcm.hip
 extern "C" int iamf_hip_fast_lpcm_launch(const void *params, int m, hipStream_t st);   // iamf_render_lpcm.hip
 extern "C" int iamf_hip_wide4_has_mix(int m, int c);                                  // iamf_render_wide4_mix.hip
@@ -1212,10 +1216,13 @@ int iamf_hip_batch_render_lpcm(iamf_hip_batch *b, const iamf_hip_lpcm_input *in,
     b->lp_fc[1] = count;
     HIPCHK(hipMemcpy(b->d_lp_fc, b->lp_fc, sizeof(b->lp_fc), hipMemcpyHostToDevice));
   }
-  for (int f = 0; f < nf; ++f) {   // one {first, count} pair for all streams: stride 0
-    const int r = iamf_hip_lpcm_unpack(&L, static_cast<const uint8_t *>(in->d_raw) + (int64_t)f * in->raw_frame_stride,
-                                       in->raw_stream_stride, b->d_lp_fc, 0, b->d_lp_in + (size_t)f * ch * fs,
-                                       (int64_t)nf * ch * fs, ns, st);
+  // one {first, count} pair for all streams (stride 0); as many frames per launch as the grid's third dimension takes
+  const int fmax = 65535 / ns > 0 ? 65535 / ns : 0;
+  if (fmax == 0) return IAMF_HIP_ERR_UNIMPLEMENTED;
+  for (int f = 0; f < nf; f += fmax) {
+    const int r = iamf_hip_lpcm_unpack_frames(&L, static_cast<const uint8_t *>(in->d_raw) + (int64_t)f * in->raw_frame_stride,
+                                              in->raw_stream_stride, in->raw_frame_stride, nf - f < fmax ? nf - f : fmax, b->d_lp_fc, 0,
+                                              b->d_lp_in + (size_t)f * ch * fs, (int64_t)nf * ch * fs, (int64_t)ch * fs, ns, st);
     if (r != IAMF_HIP_OK) return r;
   }
   a.d_in = b->d_lp_in;

@@ -21,6 +21,9 @@ struct UnpackParams {
   float *out;
   int64_t out_stride;
   int32_t n_streams;
+  int32_t n_frames;             // frames per stream in one launch (iamf_hip_batch_render_lpcm); the public entry: 1
+  int64_t raw_frame_stride;     // bytes from one frame's packet row to the next
+  int64_t out_frame_stride;     // floats
 };
 
 template <int BYTES>
@@ -42,7 +45,7 @@ __device__ __forceinline__ float lpcm_value(const uint8_t *p, bool le) {
 // grid (quads of samples / 64, channels, streams); a thread = four consecutive samples of one channel
 template <int BYTES>
 __global__ __launch_bounds__(64) void lpcm_unpack_kernel(const UnpackParams p) {
-  const int s = blockIdx.z, c = blockIdx.y;
+  const int s = blockIdx.z / p.n_frames, fr = blockIdx.z - s * p.n_frames, c = blockIdx.y;
   const int i0 = 4 * (blockIdx.x * 64 + threadIdx.x);
   // {first, count} come from the host per call; whatever they hold, no thread reads outside the frame's packet
   // (the bytes of samples [0, frame_size) are what iamf_hip_lpcm_unpack checked against the raw stride)
@@ -51,8 +54,8 @@ __global__ __launch_bounds__(64) void lpcm_unpack_kernel(const UnpackParams p) {
   count = count < p.lay.frame_size - first ? count : p.lay.frame_size - first;
   if (i0 >= count) return;
   const int off = p.lay.src_offset[c], step = p.lay.src_step[c];
-  float *dst = p.out + (int64_t)s * p.out_stride + (int64_t)c * p.lay.frame_size + i0;
-  const uint8_t *src = p.raw + (int64_t)s * p.raw_stride + off + (int64_t)(first + i0) * step;
+  float *dst = p.out + (int64_t)s * p.out_stride + (int64_t)fr * p.out_frame_stride + (int64_t)c * p.lay.frame_size + i0;
+  const uint8_t *src = p.raw + (int64_t)s * p.raw_stride + (int64_t)fr * p.raw_frame_stride + off + (int64_t)(first + i0) * step;
   const bool le = p.lay.little_endian != 0;
   float v[4];
 #pragma unroll
@@ -82,18 +85,25 @@ extern "C" int iamf_hip_upload_by_kernel(const void *h_pinned, void *d_dst, size
   return hipGetLastError() == hipSuccess ? IAMF_HIP_OK : IAMF_HIP_ERR_DEVICE;
 }
 
-extern "C" int iamf_hip_lpcm_unpack(const iamf_hip_lpcm_layout *lay, const void *d_raw, int64_t raw_stream_stride,
-                                    const int32_t *d_first_count, int64_t first_count_stride, float *d_out,
-                                    int64_t out_stream_stride, int32_t n_streams, void *stream) {
-  if (!lay || !d_raw || !d_first_count || (first_count_stride < 2 && first_count_stride != 0) || !d_out || n_streams <= 0) return IAMF_HIP_ERR_BAD_ARG;
+// n_frames frames per stream in one launch: frame f of stream s reads its packet row at d_raw + s * raw_stream_stride +
+// f * raw_frame_stride and writes d_out + s * out_stream_stride + f * out_frame_stride (iamf_hip_batch_render_lpcm's
+// general form; one {first, count} pair serves all frames of a stream).  The public entry below is n_frames = 1.
+extern "C" __attribute__((visibility("hidden"))) int iamf_hip_lpcm_unpack_frames(
+    const iamf_hip_lpcm_layout *lay, const void *d_raw, int64_t raw_stream_stride, int64_t raw_frame_stride, int32_t n_frames,
+    const int32_t *d_first_count, int64_t first_count_stride, float *d_out, int64_t out_stream_stride, int64_t out_frame_stride,
+    int32_t n_streams, void *stream) {
+  if (!lay || !d_raw || !d_first_count || (first_count_stride < 2 && first_count_stride != 0) || !d_out || n_streams <= 0 ||
+      n_frames <= 0 || (int64_t)n_streams * n_frames > 65535)
+    return IAMF_HIP_ERR_BAD_ARG;
   if (lay->sample_bytes < 2 || lay->sample_bytes > 4 || lay->channels <= 0 || lay->channels > IAMF_HIP_LPCM_MAX_CHANNELS ||
-      lay->frame_size <= 0 || (lay->frame_size & 3) || raw_stream_stride <= 0 || out_stream_stride < (int64_t)lay->channels * lay->frame_size)
+      lay->frame_size <= 0 || (lay->frame_size & 3) || raw_frame_stride <= 0 || raw_stream_stride < (int64_t)n_frames * raw_frame_stride ||
+      out_frame_stride < (int64_t)lay->channels * lay->frame_size || out_stream_stride < (int64_t)n_frames * out_frame_stride)
     return IAMF_HIP_ERR_BAD_ARG;
   for (int c = 0; c < lay->channels; ++c) {
-    // every byte a thread may read lies inside the stream's raw region (first + count <= frame_size is the caller's)
+    // every byte a thread may read lies inside the frame's packet row (first + count <= frame_size: clamped by the kernel)
     if (lay->src_offset[c] < 0) continue;
     if (lay->src_step[c] < lay->sample_bytes ||
-        (int64_t)lay->src_offset[c] + (int64_t)(lay->frame_size - 1) * lay->src_step[c] + lay->sample_bytes > raw_stream_stride)
+        (int64_t)lay->src_offset[c] + (int64_t)(lay->frame_size - 1) * lay->src_step[c] + lay->sample_bytes > raw_frame_stride)
       return IAMF_HIP_ERR_BAD_ARG;
   }
   UnpackParams p;
@@ -105,7 +115,10 @@ extern "C" int iamf_hip_lpcm_unpack(const iamf_hip_lpcm_layout *lay, const void 
   p.out = d_out;
   p.out_stride = out_stream_stride;
   p.n_streams = n_streams;
-  const dim3 grid((unsigned)((lay->frame_size / 4 + 63) / 64), (unsigned)lay->channels, (unsigned)n_streams);
+  p.n_frames = n_frames;
+  p.raw_frame_stride = raw_frame_stride;
+  p.out_frame_stride = out_frame_stride;
+  const dim3 grid((unsigned)((lay->frame_size / 4 + 63) / 64), (unsigned)lay->channels, (unsigned)(n_streams * n_frames));
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (lay->sample_bytes) {
     case 2: hipLaunchKernelGGL(lpcm_unpack_kernel<2>, grid, dim3(64), 0, st, p); break;
@@ -113,4 +126,12 @@ extern "C" int iamf_hip_lpcm_unpack(const iamf_hip_lpcm_layout *lay, const void 
     default: hipLaunchKernelGGL(lpcm_unpack_kernel<4>, grid, dim3(64), 0, st, p); break;
   }
   return hipGetLastError() == hipSuccess ? IAMF_HIP_OK : IAMF_HIP_ERR_DEVICE;
+}
+
+extern "C" int iamf_hip_lpcm_unpack(const iamf_hip_lpcm_layout *lay, const void *d_raw, int64_t raw_stream_stride,
+                                    const int32_t *d_first_count, int64_t first_count_stride, float *d_out,
+                                    int64_t out_stream_stride, int32_t n_streams, void *stream) {
+  // one frame per stream: the stream's raw region is the frame's packet row
+  return iamf_hip_lpcm_unpack_frames(lay, d_raw, raw_stream_stride, raw_stream_stride, 1, d_first_count, first_count_stride, d_out,
+                                     out_stream_stride, out_stream_stride, n_streams, stream);
 }

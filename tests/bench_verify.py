@@ -43,7 +43,7 @@ def oracle_pcm(kind, in_id, out_id, out_ch, x, fs, s=0, proj=None):
     """x: [F][in_ch][fs] float32 — the element PCM of stream `s` exactly as the kernel read it.
     Returns int16 [F*fs - 240][out_ch]."""
     F = x.shape[0]
-    if kind in ("h2m", "h2m_lfe", "h2m_proj", "m2m"):
+    if kind in ("h2m", "h2m_lfe", "h2m_proj", "m2m", "h2m_lpcm"):   # h2m_lpcm: x is the decoded packets, sample / 32768
         mx = O.get_m2m(in_id, out_id) if kind == "m2m" else O.get_h2m(in_id, out_id)
         xp = planar(x)
         if kind == "h2m_proj":   # iamf_core_decoder_convert_projection (IAMF_core_decoder.c:116-130): f32, ascending l
