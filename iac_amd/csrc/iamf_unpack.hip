@@ -42,11 +42,13 @@ __device__ __forceinline__ float lpcm_value(const uint8_t *p, bool le) {
   }
 }
 
-// grid (quads of samples / 64, channels, streams); a thread = four consecutive samples of one channel
+// grid (quads of samples / 256, channels, streams x frames); a thread = four consecutive samples of one channel
+// (256 threads: a 1024-sample frame is one workgroup per channel — with 64 the launch was bound by the rate at which
+//  workgroups are dispatched: 4 M workgroups for 1024 streams x 64 frames x 16 channels)
 template <int BYTES>
-__global__ __launch_bounds__(64) void lpcm_unpack_kernel(const UnpackParams p) {
+__global__ __launch_bounds__(256) void lpcm_unpack_kernel(const UnpackParams p) {
   const int s = blockIdx.z / p.n_frames, fr = blockIdx.z - s * p.n_frames, c = blockIdx.y;
-  const int i0 = 4 * (blockIdx.x * 64 + threadIdx.x);
+  const int i0 = 4 * (blockIdx.x * 256 + threadIdx.x);
   // {first, count} come from the host per call; whatever they hold, no thread reads outside the frame's packet
   // (the bytes of samples [0, frame_size) are what iamf_hip_lpcm_unpack checked against the raw stride)
   int first = p.first_count[s * p.fc_stride], count = p.first_count[s * p.fc_stride + 1];
@@ -118,12 +120,12 @@ extern "C" __attribute__((visibility("hidden"))) int iamf_hip_lpcm_unpack_frames
   p.n_frames = n_frames;
   p.raw_frame_stride = raw_frame_stride;
   p.out_frame_stride = out_frame_stride;
-  const dim3 grid((unsigned)((lay->frame_size / 4 + 63) / 64), (unsigned)lay->channels, (unsigned)(n_streams * n_frames));
+  const dim3 grid((unsigned)((lay->frame_size / 4 + 255) / 256), (unsigned)lay->channels, (unsigned)(n_streams * n_frames));
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (lay->sample_bytes) {
-    case 2: hipLaunchKernelGGL(lpcm_unpack_kernel<2>, grid, dim3(64), 0, st, p); break;
-    case 3: hipLaunchKernelGGL(lpcm_unpack_kernel<3>, grid, dim3(64), 0, st, p); break;
-    default: hipLaunchKernelGGL(lpcm_unpack_kernel<4>, grid, dim3(64), 0, st, p); break;
+    case 2: hipLaunchKernelGGL(lpcm_unpack_kernel<2>, grid, dim3(256), 0, st, p); break;
+    case 3: hipLaunchKernelGGL(lpcm_unpack_kernel<3>, grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL(lpcm_unpack_kernel<4>, grid, dim3(256), 0, st, p); break;
   }
   return hipGetLastError() == hipSuccess ? IAMF_HIP_OK : IAMF_HIP_ERR_DEVICE;
 }
