@@ -172,3 +172,17 @@ def test_gather_pipeline_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_generated_lfe_chain_loop_is_what_the_generator_writes(tmp_path):
+    # iac_amd/csrc/lfe_chain_asm.inc (the hand-assigned-register main loop of lfe_chain_kernel) is generated code kept in
+    # the tree: the committed file must be the generator's output, instruction for instruction
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "lfe_chain_asm.inc"
+    env = dict(os.environ)
+    env.pop("LFE_ASM_FMA", None)
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_lfe_chain_asm.py"), str(out)], env=env,
+                          stdout=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(root, "iac_amd", "csrc", "lfe_chain_asm.inc")).read()

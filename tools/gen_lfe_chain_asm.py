@@ -80,8 +80,8 @@ def body():
     return L
 
 
-def main():
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "iac_amd", "csrc", "lfe_chain_asm.inc")
+def main(out=None):
+    out = out or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "iac_amd", "csrc", "lfe_chain_asm.inc")
     lines = body()
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_lfe_chain_asm.py - do not edit.  The main loop of lfe_chain_kernel (render_lfe.hpp)\n")
@@ -98,4 +98,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+    main(sys.argv[1] if len(sys.argv) > 1 else None)
