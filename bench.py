@@ -365,7 +365,7 @@ EXTRA_CONFIGS = [("714_ssJ_limiter_s16", 3072, 4), ("toa_ssH_limiter_s16", 2048,
                  ("toa_binaural_limiter_s16_lpcm16", 2048, 1),
                  # secondary kernels of SURVEY 8 rows N2 / N4 / A5: in the driver's line so that it times them
                  ("scalable_714_ssJ_limiter_s16", 2048, 1), ("toa_ssB_lfe_limiter_s16", 1024, 1),
-                 ("710_downmix_stereo_limiter_s16", 1024, 1)]
+                 ("710_downmix_stereo_limiter_s16", 2048, 1)]   # (2048: 108 Gsamples/s; 1024: 102, 4096: 110)
 
 
 def kernel_tag(kind, in_ch, out_ch):
