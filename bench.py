@@ -364,7 +364,10 @@ EXTRA_CONFIGS = [("714_ssJ_limiter_s16", 3072, 4), ("toa_ssH_limiter_s16", 2048,
                  # the headline fed with the stream's own 16-bit LPCM packets (SURVEY 8 N1 on the device; 36 B per sample-frame)
                  ("toa_binaural_limiter_s16_lpcm16", 2048, 1),
                  # secondary kernels of SURVEY 8 rows N2 / N4 / A5: in the driver's line so that it times them
-                 ("scalable_714_ssJ_limiter_s16", 2048, 1), ("toa_ssB_lfe_limiter_s16", 1024, 1),
+                 ("scalable_714_ssJ_limiter_s16", 2048, 1),
+                 # the LFE generator's serial recurrence takes 0.61 ms per call WHATEVER the stream count (one lane per stream,
+                 # 65 536 dependent steps): the shard is sized to amortise it (1024: 37.6, 2048: 46.5, 4096: 51.9 Gsamples/s)
+                 ("toa_ssB_lfe_limiter_s16", 4096, 1),
                  ("710_downmix_stereo_limiter_s16", 2048, 1)]   # (2048: 108 Gsamples/s; 1024: 102, 4096: 110)
 
 
