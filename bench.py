@@ -362,7 +362,7 @@ SIGNALS = {"hot": "hot (sigma 0.25 + 1.5 bursts)", "quiet": "quiet (sigma 0.05)"
 # x 2 for the 24-channel and HRTF kernels)
 EXTRA_CONFIGS = [("714_ssJ_limiter_s16", 3072, 4), ("toa_ssH_limiter_s16", 2048, 4), ("toa_hrtf256_limiter_s16", 1024, 1),
                  # the headline fed with the stream's own 16-bit LPCM packets (SURVEY 8 N1 on the device; 36 B per sample-frame)
-                 ("toa_binaural_limiter_s16_lpcm16", 2048, 1),
+                 ("toa_binaural_limiter_s16_lpcm16", 4096, 1),   # not HBM-bound: 512: 85, 1024: 116, 2048: 120-125, 4096: 132 Gsamples/s
                  # secondary kernels of SURVEY 8 rows N2 / N4 / A5: in the driver's line so that it times them
                  ("scalable_714_ssJ_limiter_s16", 2048, 1),
                  # the LFE generator's serial recurrence takes 0.61 ms per call WHATEVER the stream count (one lane per stream,

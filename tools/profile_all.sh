@@ -13,7 +13,7 @@ OUT=$R/gpurun_out/profiles
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # workload:streams per GPU, as bench.py's default line (EXTRA_CONFIGS) runs them
-for WS in ${WORKLOADS:-toa_binaural_limiter_s16:512 714_ssJ_limiter_s16:3072 toa_ssH_limiter_s16:2048 toa_hrtf256_limiter_s16:1024 toa_binaural_limiter_s16_lpcm16:2048 scalable_714_ssJ_limiter_s16:2048 toa_ssB_lfe_limiter_s16:4096 710_downmix_stereo_limiter_s16:2048}; do
+for WS in ${WORKLOADS:-toa_binaural_limiter_s16:512 714_ssJ_limiter_s16:3072 toa_ssH_limiter_s16:2048 toa_hrtf256_limiter_s16:1024 toa_binaural_limiter_s16_lpcm16:4096 scalable_714_ssJ_limiter_s16:2048 toa_ssB_lfe_limiter_s16:4096 710_downmix_stereo_limiter_s16:2048}; do
   W=${WS%%:*}; S=${WS##*:}
   P=$R/gpurun_out/prof_$W
   rm -rf "$P"
