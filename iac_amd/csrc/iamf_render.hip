@@ -1161,7 +1161,16 @@ int iamf_hip_batch_render_range(iamf_hip_batch *b, const iamf_hip_render_args *a
 // little-endian 16-bit samples; in every other case exactly what the caller would do itself: iamf_hip_lpcm_unpack into a
 // buffer of the batch, then the f32 path.  Both give the same PCM bit for bit.
 int iamf_hip_batch_render_lpcm(iamf_hip_batch *b, const iamf_hip_lpcm_input *in, const iamf_hip_render_args *args) {
+  if (!b) return IAMF_HIP_ERR_BAD_ARG;
+  return iamf_hip_batch_render_lpcm_range(b, in, args, 0, b->cfg.n_streams);
+}
+
+// the same for the streams [stream0, stream0 + n_streams) only (as iamf_hip_batch_render_range: buffers and strides are
+// still indexed by the stream's number in the batch)
+int iamf_hip_batch_render_lpcm_range(iamf_hip_batch *b, const iamf_hip_lpcm_input *in, const iamf_hip_render_args *args,
+                                     int32_t stream0, int32_t n_streams) {
   if (!b || !in || !args || !in->d_raw || args->d_in || !args->d_pcm || args->n_frames < 0) return IAMF_HIP_ERR_BAD_ARG;
+  if (stream0 < 0 || n_streams <= 0 || stream0 + n_streams > b->cfg.n_streams) return IAMF_HIP_ERR_BAD_ARG;
   if (!on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
   if (args->n_frames == 0) return 0;
   const iamf_hip_lpcm_layout &L = in->layout;
@@ -1193,7 +1202,7 @@ int iamf_hip_batch_render_lpcm(iamf_hip_batch *b, const iamf_hip_lpcm_input *in,
     for (int c = 0; c < ch; ++c) lp.off[c] = L.src_offset[c] + 2 * first;
     a.d_in = reinterpret_cast<const float *>(in->d_raw);   // not read by the fused kernel; non-null = "not a flush"
     a.in_stream_stride = a.in_frame_stride = 0;
-    const int r = render_range_impl(b, &a, 0, ns, &lp);
+    const int r = render_range_impl(b, &a, stream0, n_streams, &lp);
     if (r != kNotFused) return r;
   }
   hipStream_t st = static_cast<hipStream_t>(args->stream);
@@ -1228,7 +1237,7 @@ int iamf_hip_batch_render_lpcm(iamf_hip_batch *b, const iamf_hip_lpcm_input *in,
   a.d_in = b->d_lp_in;
   a.in_stream_stride = (int64_t)nf * ch * fs;
   a.in_frame_stride = (int64_t)ch * fs;
-  return render_range_impl(b, &a, 0, ns, nullptr);
+  return render_range_impl(b, &a, stream0, n_streams, nullptr);   // (every stream was unpacked; the range is rendered)
 }
 
 int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *a) {

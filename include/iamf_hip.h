@@ -469,6 +469,9 @@ typedef struct iamf_hip_lpcm_input {
   iamf_hip_lpcm_layout layout;
 } iamf_hip_lpcm_input;
 int iamf_hip_batch_render_lpcm(iamf_hip_batch *b, const iamf_hip_lpcm_input *in, const iamf_hip_render_args *args);
+/* ... for the streams [stream0, stream0 + n_streams) of the batch only, as iamf_hip_batch_render_range */
+int iamf_hip_batch_render_lpcm_range(iamf_hip_batch *b, const iamf_hip_lpcm_input *in, const iamf_hip_render_args *args,
+                                     int32_t stream0, int32_t n_streams);
 
 /* Host -> device by a kernel that reads pinned host memory (hipHostMalloc) over PCIe, 16 bytes per lane: the bytes of a
  * hipMemcpyAsync without leaving the compute queue, for callers that put a small upload between kernels (a pinned

@@ -161,6 +161,28 @@ int iamf_hip_lpcm_unpack(const iamf_hip_lpcm_layout *lay, const void *d_raw, int
       }
   return IAMF_HIP_OK;
 }
+/* the fused LPCM entry: touches, byte for byte, the samples the render kernel would read from the packet rows */
+int iamf_hip_batch_render_lpcm_range(iamf_hip_batch *b, const iamf_hip_lpcm_input *in, const iamf_hip_render_args *a, int32_t s0,
+                                     int32_t cnt) {
+  int n = a->n_samples ? a->n_samples : a->n_frames * b->cfg.frame_size, r = 0;
+  if (!in || !in->d_raw || a->d_in || s0 < 0 || cnt <= 0 || s0 + cnt > b->cfg.n_streams || in->first_sample < 0 ||
+      (in->first_sample > 0 && a->n_frames != 1) || in->first_sample + (a->n_samples ? a->n_samples : b->cfg.frame_size) > b->cfg.frame_size)
+    return IAMF_HIP_ERR_BAD_ARG;
+  for (int s = s0; s < s0 + cnt; ++s) {
+    int acc = 0;
+    for (int f = 0; f < a->n_frames; ++f)
+      for (int c = 0; c < in->layout.channels; ++c)
+        for (int i = 0; i < (a->n_samples ? a->n_samples : b->cfg.frame_size) && in->layout.src_offset[c] >= 0; ++i) {
+          const volatile uint8_t *p = (const volatile uint8_t *)in->d_raw + (int64_t)s * in->raw_stream_stride + (int64_t)f * in->raw_frame_stride +
+                                      in->layout.src_offset[c] + (int64_t)(in->first_sample + i) * in->layout.src_step[c];
+          for (int k = 0; k < in->layout.sample_bytes; ++k) acc += p[k];
+        }
+    (void)acc;
+    r = emit(b, s, a->d_pcm, a->pcm_stream_stride_bytes, n);
+    if (r < 0) return r;
+  }
+  return r;
+}
 int iamf_hip_resampler_create(int ns, int ch, int in, int out, iamf_hip_resampler **r) {
   (void)ns;
   *r = (iamf_hip_resampler *)calloc(1, sizeof(**r));

@@ -155,8 +155,14 @@ def test_group_of_handles_matches_reference_decoder(lib, golden, name):
         assert pcm.shape == want.shape and np.array_equal(pcm, want), (name, i)
 
 
-def test_group_of_64_in_step(lib, golden):
-    """BASELINE config 4's stream kind (TOA -> binaural) over 64 handles that advance together: one launch per round"""
+@pytest.mark.parametrize("unpack_first", [False, True])
+def test_group_of_64_in_step(lib, golden, unpack_first, monkeypatch):
+    """BASELINE config 4's stream kind (TOA -> binaural) over 64 handles that advance together: one launch per round.
+    For this kind of stream (one mono-coded ambisonics element, 16-bit, into two channels) the group hands the packets
+    straight to the render kernel (iamf_hip_batch_render_lpcm_range: the fused LPCM form of the headline kernel);
+    IAMF_HIP_GROUP_UNPACK=1 makes it unpack first as for every other kind.  Both against the reference's own PCM."""
+    if unpack_first:
+        monkeypatch.setenv("IAMF_HIP_GROUP_UNPACK", "1")
     name = "toa_binaural_s16" if "toa_binaural_s16" in e2e_cases.CASES else sorted(e2e_cases.CASES)[0]
     case = e2e_cases.CASES[name]
     stream, _ = e2e_cases.build(name)
