@@ -285,11 +285,17 @@ def facade_rates(fs, n_group=64, frames=96):
     d, used = handle()
     pcm = C.create_string_buffer(2 * 6144 * 2)
     rs = C.c_uint32(0)
-    total, t0 = 0, time.perf_counter()
+    # steady state: the first 8 calls are not timed (the first launch of a kernel loads its code object and opts into its
+    # LDS size once per process: ~1 ms, which a 96-frame stream would otherwise carry as 10 us per call)
+    total, calls, t0 = 0, 0, time.perf_counter()
     while used < len(stream):
         n = L.IAMF_decoder_decode(d, base + used, len(stream) - used, C.byref(rs), pcm)
         assert n >= 0
-        total += n
+        calls += 1
+        if calls == 8:
+            total, t0 = 0, time.perf_counter()
+        elif calls > 8:
+            total += n
         used += rs.value
         if not rs.value:
             break
@@ -342,7 +348,8 @@ def facade_rates(fs, n_group=64, frames=96):
     g256, ms256 = group_rate(4 * n_group)
     return {"workload": "TOA -> binaural, 16-bit LPCM .iamf, %d frames of %d samples per handle, through the reference's API"
                         % (frames, fs),
-            "single_handle_msamples_s": round(single, 2), "single_handle_us_per_call": round(t_single / (frames + 1) * 1e6, 1),
+            "single_handle_msamples_s": round(single, 2), "single_handle_us_per_call": round(t_single / (frames + 1 - 8) * 1e6, 1),
+            "single_handle_note": "steady state: the first 8 of the %d calls are not timed" % (frames + 1),
             "group_handles": n_group, "group_msamples_s": round(g64, 2), "group_ms_per_round": round(ms64, 3),
             "group%d_msamples_s" % (4 * n_group): round(g256, 2), "group%d_ms_per_round" % (4 * n_group): round(ms256, 3),
             "group_phases_per_round": {str(k): v for k, v in phases.items()},

@@ -236,6 +236,11 @@ struct IAMF_Decoder {
   /* pinned host memory that the kernels read and write directly (a frame is 64 KB in, 4 KB out: over PCIe inside the
    * one render launch, instead of three copies around it — each ~9 us of call and ~12 us of engine hand-over) */
   float *h_in[2], *h_ramp[3], *d_mid, *d_res;
+  /* element 0's packets as they are, pinned, for the fused LPCM form of the render kernel (iamf_hip_batch_render_lpcm):
+   * one mono-coded ambisonics element in 16-bit little-endian LPCM into one or two channels with the limiter on */
+  uint8_t *h_raw;
+  int lp_ok;
+  iamf_hip_lpcm_layout lp_layout;
   float gain_set[2]; /* element / output constant gains the batch holds (iamf_hip_batch_set_gains synchronises: only on change) */
   float *tmp; /* [MAX_SUBSTREAMS * 2][frame_size] unpack scratch */
   iamf_hip_dmx_frame *h_dmx; /* pinned */
@@ -825,6 +830,9 @@ static void free_runtime(struct IAMF_Decoder *d) {
   if (d->rs) iamf_hip_resampler_destroy(d->rs);
   d->batch = d->batch3 = 0;
   d->rs = 0;
+  if (d->h_raw) (void)hipHostFree(d->h_raw);
+  d->h_raw = 0;
+  d->lp_ok = 0;
   for (int e = 0; e < 2; ++e) {
     if (d->h_in[e]) (void)hipHostFree(d->h_in[e]);
     d->h_in[e] = 0;
@@ -1130,6 +1138,28 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   }
   for (int i = 0; i < 3; ++i)
     if (hipHostMalloc((void **)&d->h_ramp[i], sizeof(float) * d->frame_size, 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+  {
+    /* the headline's kind of stream: its packets go to the render kernel as they are (the reference's LPCM decode,
+     * pcm/IAMF_pcm_decoder.c:64-83, happens where the kernel loads them).  The library decides per call whether the
+     * fused kernel takes it and unpacks on the device otherwise; here: whether asking is worth it */
+    const Element *e0 = d->sel_el[0];
+    iamf_hip_lpcm_layout *L = &d->lp_layout;
+    d->lp_ok = p->nel == 1 && e0->type == AUDIO_ELEMENT_SCENE_BASED && !e0->amb_projection && !d->use_dmx && !d->use_demix &&
+               !resample && d->sample_size == 16 && d->little_endian && d->limiter_on && d->out_channels <= 2 &&
+               d->pcm_stride == d->out_channels && (d->frame_size & 63) == 0 && e0->nsub > 0 && e0->nsub <= MAX_SUBSTREAMS &&
+               (e0->channels == 1 || e0->channels == 4 || e0->channels == 9 || e0->channels == 16) && !getenv("IAMF_HIP_FACADE_UNPACK");
+    memset(L, 0, sizeof(*L));
+    L->sample_bytes = 2;
+    L->little_endian = 1;
+    L->channels = e0->channels;
+    L->frame_size = (int32_t)d->frame_size;
+    for (int c = 0; c < e0->channels && d->lp_ok; ++c) {
+      if (e0->amb_map[c] >= e0->nsub) d->lp_ok = 0; /* a channel no sub-stream carries: the f32 form zeroes it */
+      L->src_offset[c] = (int32_t)(e0->amb_map[c] * d->frame_size * 2);
+      L->src_step[c] = 2;
+    }
+    if (d->lp_ok && hipHostMalloc((void **)&d->h_raw, (size_t)e0->nsub * d->frame_size * 2 + 256, 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+  }
   if (hipHostMalloc((void **)&d->h_dmx, sizeof(iamf_hip_dmx_frame), 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
   d->pcm_cap = (size_t)4 * ((size_t)d->info.max_frame_size * d->pcm_stride + d->pcm_extra);
   if (hipHostMalloc(&d->h_pcm, d->pcm_cap, 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
@@ -1308,6 +1338,21 @@ static int unpack_element(struct IAMF_Decoder *d, int ei) {
   return ns;
 }
 
+/* element 0's packets as they are -> the pinned raw row (sub-stream s at s * frame_size * 2); unpack_element's checks;
+ * returns samples per channel */
+static int stage_lpcm_row(struct IAMF_Decoder *d) {
+  const Element *e = d->sel_el[0];
+  const int fs = (int)d->frame_size;
+  int ns = -1;
+  for (int s = 0; s < e->nsub; ++s) {
+    const int n = (int)(d->pkt_len[0][s] / 2u);
+    if (ns < 0) ns = n;
+    if (n != ns || n > fs) return IAMF_ERR_INVALID_PACKET;
+    memcpy(d->h_raw + (size_t)s * fs * 2, d->pkt[0][s], (size_t)n * 2);
+  }
+  return ns < 0 ? IAMF_ERR_INVALID_PACKET : ns;
+}
+
 static int tu_complete(const struct IAMF_Decoder *d) { /* IAMF_decoder.c:2854-2869 */
   for (int e = 0; e < d->sel->nel; ++e)
     for (int s = 0; s < d->sel_el[e]->nsub; ++s)
@@ -1321,11 +1366,18 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
   int ns = 0, n, keep, s0;
   float cgain[3];
   int ramp[3] = {0, 0, 0};
+  int lp = d->lp_ok && !d->group; /* the packets go to the render kernel as they are (decided per frame below) */
   memset(&a, 0, sizeof(a));
-  for (int e = 0; e < d->sel->nel; ++e) {
-    int r = unpack_element(d, e);
+  if (lp) {
+    int r = stage_lpcm_row(d);
     if (r < 0) return r;
     ns = r;
+  } else {
+    for (int e = 0; e < d->sel->nel; ++e) {
+      int r = unpack_element(d, e);
+      if (r < 0) return r;
+      ns = r;
+    }
   }
   /* iamf_frame_trim (IAMF_decoder.c:1361-1381): rendering is memoryless, so trimming the
    * element PCM before the renderer equals trimming the rendered frame */
@@ -1345,11 +1397,6 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     d->timestamp += fs;
     return 0;
   }
-  for (int e = 0; e < d->sel->nel; ++e) {
-    const int ch = element_in_channels(d->sel_el[e]);
-    if (s0)
-      for (int c = 0; c < ch; ++c) memmove(d->h_in[e] + (size_t)c * fs, d->h_in[e] + (size_t)c * fs + s0, sizeof(float) * keep);
-  }
   /* mix gains of this frame */
   {
     const uint64_t pt = d->timestamp + (uint64_t)s0;
@@ -1368,7 +1415,18 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
         for (int k = 0; k < keep; ++k) d->h_ramp[i][k] = cgain[i];
     }
   }
-  a.d_in = d->h_in[0];
+  if (lp && ((s0 & 3) || (keep & 63) || ramp[0] || ramp[2])) { /* not a call of the fused kernel: the f32 form after all */
+    int r = unpack_element(d, 0);
+    if (r < 0) return r;
+    lp = 0;
+  }
+  if (!lp)
+    for (int e = 0; e < d->sel->nel; ++e) {
+      const int ch = element_in_channels(d->sel_el[e]);
+      if (s0)
+        for (int c = 0; c < ch; ++c) memmove(d->h_in[e] + (size_t)c * fs, d->h_in[e] + (size_t)c * fs + s0, sizeof(float) * keep);
+    }
+  a.d_in = lp ? 0 : d->h_in[0];
   a.in_stream_stride = a.in_frame_stride = (int64_t)element_in_channels(d->sel_el[0]) * fs;
   if (d->sel->nel > 1) {
     a.d_in2 = d->h_in[1];
@@ -1414,7 +1472,17 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
   a.n_frames = 1;
   a.n_samples = keep < fs ? keep : 0;
   a.stream = d->stream;
-  if (!d->rs) {
+  if (lp) {
+    iamf_hip_lpcm_input in;
+    memset(&in, 0, sizeof(in));
+    in.d_raw = d->h_raw;
+    in.raw_stream_stride = in.raw_frame_stride = (int64_t)d->sel_el[0]->nsub * fs * 2;
+    in.first_sample = s0;
+    in.layout = d->lp_layout;
+    a.d_pcm = d->h_pcm;
+    a.pcm_stream_stride_bytes = (int64_t)d->pcm_cap;
+    n = iamf_hip_batch_render_lpcm(d->batch, &in, &a);
+  } else if (!d->rs) {
     a.d_pcm = d->h_pcm;
     a.pcm_stream_stride_bytes = (int64_t)d->pcm_cap;
     n = iamf_hip_batch_render_ex(d->batch, &a);

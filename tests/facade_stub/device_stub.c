@@ -183,6 +183,9 @@ int iamf_hip_batch_render_lpcm_range(iamf_hip_batch *b, const iamf_hip_lpcm_inpu
   }
   return r;
 }
+int iamf_hip_batch_render_lpcm(iamf_hip_batch *b, const iamf_hip_lpcm_input *in, const iamf_hip_render_args *a) {
+  return iamf_hip_batch_render_lpcm_range(b, in, a, 0, b->cfg.n_streams);
+}
 int iamf_hip_resampler_create(int ns, int ch, int in, int out, iamf_hip_resampler **r) {
   (void)ns;
   *r = (iamf_hip_resampler *)calloc(1, sizeof(**r));

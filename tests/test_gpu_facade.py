@@ -33,6 +33,22 @@ def test_facade_matches_reference_decoder(lib, golden, name):
     assert np.array_equal(pcm, want), name
 
 
+@pytest.mark.parametrize("name", [n for n in sorted(e2e_cases.CASES) if "binaural" in n or n.startswith(("foa", "soa", "toa"))])
+def test_facade_host_unpack_form_of_the_fused_streams(lib, golden, name, monkeypatch):
+    """Streams of one mono-coded ambisonics element (16-bit, <= 2 output channels) hand their packets straight to the render
+    kernel (iamf_hip_batch_render_lpcm, the fused LPCM form: what test_facade_matches_reference_decoder runs for them);
+    IAMF_HIP_FACADE_UNPACK=1 keeps the host unpacker + f32 kernels for them as for every other stream.  Same goldens."""
+    monkeypatch.setenv("IAMF_HIP_FACADE_UNPACK", "1")
+    case = e2e_cases.CASES[name]
+    stream, _ = e2e_cases.build(name)
+    pcm, rets = decode_stream(lib, stream, case["layout"], bit_depth=case.get("bit_depth", 16),
+                              out_rate=case.get("out_rate", 0), loudness=case.get("loudness", 0.0),
+                              limiter=case.get("limiter", True), threshold=case.get("threshold", -1.0))
+    want = golden.npz("e2e")[name]
+    assert list(rets) == list(golden.npz("e2e")[name + "_rets"]), name
+    assert pcm.shape == want.shape and np.array_equal(pcm, want), name
+
+
 def test_facade_api_surface(lib):
     lib.IAMF_decoder_open.restype = C.c_void_p
     lib.IAMF_decoder_close.argtypes = [C.c_void_p]
