@@ -50,7 +50,8 @@ extern "C" int iamf_hip_fir_m2b_launch_fft(const void *params, int m, hipStream_
 extern "C" int iamf_hip_lpcm_unpack_frames(const iamf_hip_lpcm_layout *lay, const void *d_raw, int64_t raw_stream_stride,   // iamf_unpack.hip
                                            int64_t raw_frame_stride, int32_t n_frames, const int32_t *d_first_count,
                                            int64_t first_count_stride, float *d_out, int64_t out_stream_stride,
-                                           int64_t out_frame_stride, int32_t n_streams, void *stream);
+                                           int64_t out_frame_stride, int32_t n_streams, void *stream, int32_t uniform_first,
+                                           int32_t uniform_count);
 extern "C" int iamf_hip_fast_lpcm_has(int m, int oc);                                   // iamf_render_lpcm.hip
 extern "C" int iamf_hip_fast_lpcm_launch(const void *params, int m, hipStream_t st);   // iamf_render_lpcm.hip
 extern "C" int iamf_hip_wide4_has_mix(int m, int c);                                  // iamf_render_wide4_mix.hip
@@ -230,8 +231,6 @@ struct iamf_hip_batch {
   // iamf_hip_batch_render_lpcm, calls the fused kernel does not take: the unpacked element and the unpacker's {first, count}
   float *d_lp_in = nullptr;
   size_t lp_in_floats = 0;
-  int32_t *d_lp_fc = nullptr;
-  int32_t lp_fc[2] = {-1, -1};
   float *d_fir_id = nullptr;                        // 2 x 2 identity + slot map for the limiter / pack kernel behind it
   int32_t *d_fir_id_feed = nullptr;
   float fir_inv_scale = 1.f;
@@ -1098,7 +1097,6 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_fir_pre[1]);
   (void)hipFree(b->d_fir_y);
   (void)hipFree(b->d_lp_in);
-  (void)hipFree(b->d_lp_fc);
   (void)hipFree(b->d_fir_id);
   (void)hipFree(b->d_fir_id_feed);
   (void)hipFree(b->d_lfe_state);
@@ -1127,10 +1125,12 @@ int iamf_hip_batch_set_gains(iamf_hip_batch *b, const float *eg, const float *og
   return IAMF_HIP_OK;
 }
 
-static int render_range_impl(iamf_hip_batch *b, const iamf_hip_render_args *a, int32_t stream0, int32_t n_streams, const LpcmIn *lp) {
+// the argument checks of a range call: IAMF_HIP_OK and the call's samples per stream in *total_out (0: nothing to do), or the error
+static int range_args_check(const iamf_hip_batch *b, const iamf_hip_render_args *a, int32_t stream0, int32_t n_streams, int64_t *total_out) {
+  *total_out = 0;
   if (!b || !a || !a->d_in || !a->d_pcm || a->n_frames < 0) return IAMF_HIP_ERR_BAD_ARG;
   if (stream0 < 0 || n_streams <= 0 || stream0 + n_streams > b->cfg.n_streams) return IAMF_HIP_ERR_BAD_ARG;
-  if (a->n_frames == 0) return 0;
+  if (a->n_frames == 0) return IAMF_HIP_OK;
   if (b->has2 && !a->d_in2) return IAMF_HIP_ERR_BAD_ARG;
   if (b->dmx && !a->d_dmx_frames) return IAMF_HIP_ERR_BAD_ARG;
   if (b->demix && a->d_in && (!a->d_demix_frames || a->demix_sample0 < 0 ||
@@ -1149,6 +1149,14 @@ static int render_range_impl(iamf_hip_batch *b, const iamf_hip_render_args *a, i
   const int64_t need = (total * sc + (b->cfg.out_channels > sc ? b->cfg.out_channels - sc : 0)) *
                        iamf_hip_format_bytes(b->cfg.out_format);
   if (b->cfg.n_streams > 1 && a->pcm_stream_stride_bytes < need) return IAMF_HIP_ERR_BUFFER_TOO_SMALL;
+  *total_out = total;
+  return IAMF_HIP_OK;
+}
+
+static int render_range_impl(iamf_hip_batch *b, const iamf_hip_render_args *a, int32_t stream0, int32_t n_streams, const LpcmIn *lp) {
+  int64_t total = 0;
+  const int rc = range_args_check(b, a, stream0, n_streams, &total);
+  if (rc != IAMF_HIP_OK || total == 0) return rc;
   return render_call(b, *a, (int)total, stream0, n_streams, lp);
 }
 
@@ -1205,9 +1213,21 @@ int iamf_hip_batch_render_lpcm_range(iamf_hip_batch *b, const iamf_hip_lpcm_inpu
     const int r = render_range_impl(b, &a, stream0, n_streams, &lp);
     if (r != kNotFused) return r;
   }
+  // Unfused: the RANGE's packets -> planar f32 in a buffer of the batch (rows indexed by the stream's number in the batch, as
+  // every buffer of a range call), then the f32 path.  Everything the render call would refuse is refused here first, so
+  // that no unpack launch precedes an error; {first, count} travel in the unpacker's kernel arguments (a device
+  // word updated by a blocking copy cost K host synchronisations per round of a group with K divergent runs).
+  {
+    a.d_in = reinterpret_cast<const float *>(in->d_raw);   // placeholder for the checks: set below
+    int64_t total = 0;
+    const int rc = range_args_check(b, &a, stream0, n_streams, &total);
+    if (rc != IAMF_HIP_OK || total == 0) return rc;
+  }
   hipStream_t st = static_cast<hipStream_t>(args->stream);
   const size_t need = (size_t)ns * nf * ch * fs;
   if (need > b->lp_in_floats) {   // grows with the largest call seen
+    const int q = quiesce(b);     // a render queued earlier may still be reading the old buffer
+    if (q != IAMF_HIP_OK) return q;
     HIPCHK(hipStreamSynchronize(st));
     (void)hipFree(b->d_lp_in);
     b->d_lp_in = nullptr;
@@ -1217,27 +1237,22 @@ int iamf_hip_batch_render_lpcm_range(iamf_hip_batch *b, const iamf_hip_lpcm_inpu
     HIPCHK(hipMemset(b->d_lp_in, 0, sizeof(float) * need));
     b->lp_in_floats = need;
   }
-  if (!b->d_lp_fc) HIPCHK(hipMalloc(&b->d_lp_fc, sizeof(int32_t) * 2));
-  if (b->lp_fc[0] != first || b->lp_fc[1] != count) {
-    const int q = quiesce(b);   // an unpacker queued earlier may still be reading the pair
-    if (q != IAMF_HIP_OK) return q;
-    b->lp_fc[0] = first;
-    b->lp_fc[1] = count;
-    HIPCHK(hipMemcpy(b->d_lp_fc, b->lp_fc, sizeof(b->lp_fc), hipMemcpyHostToDevice));
-  }
-  // one {first, count} pair for all streams (stride 0); as many frames per launch as the grid's third dimension takes
-  const int fmax = 65535 / ns > 0 ? 65535 / ns : 0;
+  // as many frames per launch as the grid's third dimension takes
+  const int fmax = 65535 / n_streams > 0 ? 65535 / n_streams : 0;
   if (fmax == 0) return IAMF_HIP_ERR_UNIMPLEMENTED;
+  const int64_t lp_stream_stride = (int64_t)nf * ch * fs;
   for (int f = 0; f < nf; f += fmax) {
-    const int r = iamf_hip_lpcm_unpack_frames(&L, static_cast<const uint8_t *>(in->d_raw) + (int64_t)f * in->raw_frame_stride,
-                                              in->raw_stream_stride, in->raw_frame_stride, nf - f < fmax ? nf - f : fmax, b->d_lp_fc, 0,
-                                              b->d_lp_in + (size_t)f * ch * fs, (int64_t)nf * ch * fs, (int64_t)ch * fs, ns, st);
+    const int r = iamf_hip_lpcm_unpack_frames(
+        &L, static_cast<const uint8_t *>(in->d_raw) + (int64_t)stream0 * in->raw_stream_stride + (int64_t)f * in->raw_frame_stride,
+        in->raw_stream_stride, in->raw_frame_stride, nf - f < fmax ? nf - f : fmax, nullptr, 0,
+        b->d_lp_in + (int64_t)stream0 * lp_stream_stride + (size_t)f * ch * fs, lp_stream_stride, (int64_t)ch * fs, n_streams, st, first,
+        count);
     if (r != IAMF_HIP_OK) return r;
   }
   a.d_in = b->d_lp_in;
-  a.in_stream_stride = (int64_t)nf * ch * fs;
+  a.in_stream_stride = lp_stream_stride;
   a.in_frame_stride = (int64_t)ch * fs;
-  return render_range_impl(b, &a, stream0, n_streams, nullptr);   // (every stream was unpacked; the range is rendered)
+  return render_range_impl(b, &a, stream0, n_streams, nullptr);
 }
 
 int iamf_hip_batch_render_ex(iamf_hip_batch *b, const iamf_hip_render_args *a) {

@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <condition_variable>
@@ -46,9 +47,16 @@ struct Rccl {
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
   Rccl() {
+    // IAMF_HIP_RCCL_LIB: the library to load instead (a site's own RCCL build; the N-device rehearsal of this file on a
+    // host without GPUs, tests/shard_stub/)
+    const char *own = getenv("IAMF_HIP_RCCL_LIB");
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (const char *n : names)
-      if ((so = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (own && *own) {
+      so = dlopen(own, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      for (const char *n : names)
+        if ((so = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    }
     if (!so) return;
 #define SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(so, name))
     SYM(GetVersion, "ncclGetVersion");
@@ -121,10 +129,41 @@ struct Dev {
   iamf_hip_batch *batch = nullptr;
   hipStream_t render = nullptr, gather = nullptr;
   hipEvent_t rendered = nullptr, gathered = nullptr;
+  hipEvent_t g_begin = nullptr, g_end = nullptr;   // (timing) around the device's share of the last gather
   ncclComm_t comm = nullptr;
   Worker w;
   int result = 0;
+  // rows of the device's streams packed back to back for the wire (and, on the root, received before they are spread
+  // over a strided destination): grows with the largest gather seen
+  void *pack = nullptr, *unpack = nullptr;
+  size_t pack_bytes = 0, unpack_bytes = 0;
+  // accounting (iamf_hip_shard_times)
+  int64_t last_sent = 0, total_sent = 0, last_received = 0;
+  double total_gather_ms = 0.0;
+  bool timed = false;   // g_begin / g_end of a gather not yet added to total_gather_ms
 };
+
+// room for `bytes` in a staging buffer of device d (current): reallocation waits for the gather stream, whose queued
+// copies may still use the old one
+int stage_room(Dev *d, void **buf, size_t *have, size_t bytes) {
+  if (bytes <= *have) return 0;
+  if (hipStreamSynchronize(d->gather) != hipSuccess) return 1;
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr;
+  *have = 0;
+  if (hipMalloc(buf, bytes) != hipSuccess) return 1;
+  *have = bytes;
+  return 0;
+}
+
+// close the books of the last gather of device d (its events have completed, or are waited for): its time -> the total
+void settle_times(Dev *d) {
+  if (!d->timed) return;
+  float ms = 0.f;
+  if (hipEventSynchronize(d->g_end) == hipSuccess && hipEventElapsedTime(&ms, d->g_begin, d->g_end) == hipSuccess)
+    d->total_gather_ms += (double)ms;
+  d->timed = false;
+}
 
 }  // namespace
 
@@ -169,6 +208,10 @@ void iamf_hip_shard_destroy(iamf_hip_shard *s) {
       if (d->batch) iamf_hip_batch_destroy(d->batch);
       if (d->rendered) (void)hipEventDestroy(d->rendered);
       if (d->gathered) (void)hipEventDestroy(d->gathered);
+      if (d->g_begin) (void)hipEventDestroy(d->g_begin);
+      if (d->g_end) (void)hipEventDestroy(d->g_end);
+      if (d->pack) (void)hipFree(d->pack);
+      if (d->unpack) (void)hipFree(d->unpack);
       if (d->render) (void)hipStreamDestroy(d->render);
       if (d->gather) (void)hipStreamDestroy(d->gather);
     }
@@ -215,7 +258,8 @@ int iamf_hip_shard_create(const iamf_hip_batch_config *cfg, const int *devices, 
     if (hipStreamCreateWithFlags(&d->render, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&d->gather, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&d->rendered, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&d->gathered, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&d->gathered, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&d->g_begin) != hipSuccess || hipEventCreate(&d->g_end) != hipSuccess) {
       rc = IAMF_HIP_ERR_DEVICE;
       break;
     }
@@ -298,17 +342,23 @@ int iamf_hip_shard_flush(iamf_hip_shard *s, void *const *d_pcm, int64_t pcm_stre
   return r;
 }
 
-// Every shard's packed PCM (bytes_per_stream bytes of each of its streams' regions) -> d_dst on device `root_index`,
-// stream s of the whole job at d_dst + s * dst_stream_stride_bytes.  Asynchronous: ordered behind the devices' last
-// render / flush on their gather streams; iamf_hip_shard_sync (or the next render's wait on `gathered`) completes it.
-int iamf_hip_shard_gather(iamf_hip_shard *s, int root_index, void *d_dst, int64_t dst_stream_stride_bytes,
-                          void *const *d_pcm, int64_t pcm_stream_stride_bytes) {
+// Every shard's packed PCM -> d_dst on device `root_index`, stream s of the whole job at d_dst + s * dst_stream_stride_bytes.
+// Only the ROWS travel: bytes_per_stream bytes of each stream's region (what the last render / flush emitted: samples x
+// channels x sample bytes), not the regions' padding — a flush sends 240 sample-frames per stream, not a 64-frame region.
+// A device whose rows are not back to back (stride != bytes_per_stream) packs them into a staging buffer on its gather
+// stream first (hipMemcpy2DAsync, device to device), the root spreads what it received the same way if its destination is
+// strided.  Asynchronous: ordered behind the devices' last render / flush on their gather streams; iamf_hip_shard_sync (or
+// the next render's wait on `gathered`) completes it.
+int iamf_hip_shard_gather_rows(iamf_hip_shard *s, int root_index, void *d_dst, int64_t dst_stream_stride_bytes,
+                               void *const *d_pcm, int64_t pcm_stream_stride_bytes, int64_t bytes_per_stream) {
   if (!s || !d_dst || !d_pcm || root_index < 0 || root_index >= (int)s->devs.size()) return IAMF_HIP_ERR_BAD_ARG;
-  // whole regions travel (stride bytes per stream): source and destination strides must agree
-  if (dst_stream_stride_bytes != pcm_stream_stride_bytes || pcm_stream_stride_bytes <= 0) return IAMF_HIP_ERR_BAD_ARG;
+  if (bytes_per_stream <= 0 || pcm_stream_stride_bytes < bytes_per_stream || dst_stream_stride_bytes < bytes_per_stream)
+    return IAMF_HIP_ERR_BAD_ARG;
+  const int n = (int)s->devs.size();
+  for (int i = 0; i < n; ++i)   // checked before any device gets work
+    if (!d_pcm[i]) return IAMF_HIP_ERR_BAD_ARG;
   Rccl &R = rccl();
   if (!R.ok) return IAMF_HIP_ERR_UNIMPLEMENTED;   // no RCCL on this host
-  const int n = (int)s->devs.size();
   int cur = -1;
   (void)hipGetDevice(&cur);
   if (!s->comms) {   // communicators on first use: one process, all the shard's devices (ncclCommInitAll)
@@ -324,14 +374,36 @@ int iamf_hip_shard_gather(iamf_hip_shard *s, int root_index, void *d_dst, int64_
     for (int i = 0; i < n; ++i) s->devs[i]->comm = comms[(size_t)i];
     s->comms = true;
   }
-  int err = 0;
-  for (int i = 0; i < n; ++i) {   // the gather streams wait for the renders that produce what they send
-    Dev *d = s->devs[i];
-    if (hipSetDevice(d->device) != hipSuccess || hipStreamWaitEvent(d->gather, d->rendered, 0) != hipSuccess) err = 1;
-  }
   Dev *root = s->devs[root_index];
-  for (int i = 0; i < n; ++i)
-    if (!d_pcm[i]) err = 1;
+  const bool pack_src = pcm_stream_stride_bytes != bytes_per_stream;
+  const bool spread_dst = dst_stream_stride_bytes != bytes_per_stream;
+  const size_t row = (size_t)bytes_per_stream;
+  int err = 0;
+  std::vector<const void *> wire((size_t)n);   // what device i sends: its rows back to back
+  for (int i = 0; i < n && !err; ++i) {
+    // the gather streams wait for the renders that produce what they send; the books of the previous gather are closed
+    Dev *d = s->devs[i];
+    if (hipSetDevice(d->device) != hipSuccess) {
+      err = 1;
+      break;
+    }
+    settle_times(d);
+    if (hipStreamWaitEvent(d->gather, d->rendered, 0) != hipSuccess || hipEventRecord(d->g_begin, d->gather) != hipSuccess) err = 1;
+    wire[(size_t)i] = d_pcm[i];
+    if (!err && pack_src && d->count > 1) {
+      if (stage_room(d, &d->pack, &d->pack_bytes, row * (size_t)d->count) ||
+          hipMemcpy2DAsync(d->pack, row, d_pcm[i], (size_t)pcm_stream_stride_bytes, row, (size_t)d->count, hipMemcpyDeviceToDevice,
+                           d->gather) != hipSuccess)
+        err = 1;
+      wire[(size_t)i] = d->pack;
+    }
+  }
+  char *landing = static_cast<char *>(d_dst);   // where the root receives: the destination itself if its rows are back to back
+  if (!err && spread_dst) {
+    if (hipSetDevice(root->device) != hipSuccess || stage_room(root, &root->unpack, &root->unpack_bytes, row * (size_t)s->n_streams))
+      err = 1;
+    landing = static_cast<char *>(root->unpack);
+  }
   bool group = false;
   if (!err) {
     group = R.GroupStart() == ncclSuccess;
@@ -339,19 +411,63 @@ int iamf_hip_shard_gather(iamf_hip_shard *s, int root_index, void *d_dst, int64_
   }
   for (int i = 0; i < n && !err; ++i) {
     Dev *d = s->devs[i];
-    const size_t bytes = (size_t)d->count * (size_t)pcm_stream_stride_bytes;
-    if (R.Send(d_pcm[i], bytes, ncclUint8, root_index, d->comm, d->gather) != ncclSuccess) err = 1;
-    if (R.Recv(static_cast<char *>(d_dst) + (size_t)d->first * (size_t)dst_stream_stride_bytes, bytes, ncclUint8, i, root->comm,
-               root->gather) != ncclSuccess)
-      err = 1;
+    const size_t bytes = (size_t)d->count * row;
+    if (R.Send(wire[(size_t)i], bytes, ncclUint8, root_index, d->comm, d->gather) != ncclSuccess) err = 1;
+    if (R.Recv(landing + (size_t)d->first * row, bytes, ncclUint8, i, root->comm, root->gather) != ncclSuccess) err = 1;
   }
   if (group && R.GroupEnd() != ncclSuccess) err = 1;   // a started group is always ended
-  for (int i = 0; i < n; ++i) {
+  if (!err && spread_dst) {
+    if (hipSetDevice(root->device) != hipSuccess ||
+        hipMemcpy2DAsync(d_dst, (size_t)dst_stream_stride_bytes, landing, row, row, (size_t)s->n_streams, hipMemcpyDeviceToDevice,
+                         root->gather) != hipSuccess)
+      err = 1;
+  }
+  for (int i = 0; i < n; ++i) {   // always: a render that waits on `gathered` must find the latest state of the stream
     Dev *d = s->devs[i];
-    if (hipSetDevice(d->device) != hipSuccess || hipEventRecord(d->gathered, d->gather) != hipSuccess) err = 1;
+    if (hipSetDevice(d->device) != hipSuccess || hipEventRecord(d->g_end, d->gather) != hipSuccess ||
+        hipEventRecord(d->gathered, d->gather) != hipSuccess)
+      err = 1;
+    if (!err) {
+      d->last_sent = (int64_t)d->count * bytes_per_stream;
+      d->total_sent += d->last_sent;
+      d->last_received = d == root ? (int64_t)s->n_streams * bytes_per_stream : 0;
+      d->timed = true;
+    }
   }
   if (cur >= 0) (void)hipSetDevice(cur);
   return err ? IAMF_HIP_ERR_DEVICE : IAMF_HIP_OK;
+}
+
+// the whole regions (stride bytes per stream, padding included): source and destination strides must agree
+int iamf_hip_shard_gather(iamf_hip_shard *s, int root_index, void *d_dst, int64_t dst_stream_stride_bytes,
+                          void *const *d_pcm, int64_t pcm_stream_stride_bytes) {
+  if (dst_stream_stride_bytes != pcm_stream_stride_bytes) return IAMF_HIP_ERR_BAD_ARG;
+  return iamf_hip_shard_gather_rows(s, root_index, d_dst, dst_stream_stride_bytes, d_pcm, pcm_stream_stride_bytes, pcm_stream_stride_bytes);
+}
+
+// What the gather cost device `index`: bytes it sent in the last gather and in all, bytes it received in the last one (the
+// root: every device's rows, its own included), and the time its gather stream spent between the last render's completion
+// and the end of its share (pack, send / receive, spread) — last gather and all of them.  Waits for that device's last gather.
+int iamf_hip_shard_times(iamf_hip_shard *s, int index, int64_t *last_sent_bytes, int64_t *total_sent_bytes,
+                         int64_t *last_received_bytes, double *last_gather_ms, double *total_gather_ms) {
+  if (!s || index < 0 || index >= (int)s->devs.size()) return IAMF_HIP_ERR_BAD_ARG;
+  Dev *d = s->devs[index];
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  if (hipSetDevice(d->device) != hipSuccess) return IAMF_HIP_ERR_DEVICE;
+  float ms = 0.f;
+  int rc = IAMF_HIP_OK;
+  if (d->g_end && (d->timed || d->total_sent > 0)) {
+    if (hipEventSynchronize(d->g_end) != hipSuccess || hipEventElapsedTime(&ms, d->g_begin, d->g_end) != hipSuccess) rc = IAMF_HIP_ERR_DEVICE;
+  }
+  settle_times(d);
+  if (cur >= 0) (void)hipSetDevice(cur);
+  if (last_sent_bytes) *last_sent_bytes = d->last_sent;
+  if (total_sent_bytes) *total_sent_bytes = d->total_sent;
+  if (last_received_bytes) *last_received_bytes = d->last_received;
+  if (last_gather_ms) *last_gather_ms = (double)ms;
+  if (total_gather_ms) *total_gather_ms = d->total_gather_ms;
+  return rc;
 }
 
 int iamf_hip_shard_sync(iamf_hip_shard *s) {

@@ -24,6 +24,7 @@ struct UnpackParams {
   int32_t n_frames;             // frames per stream in one launch (iamf_hip_batch_render_lpcm); the public entry: 1
   int64_t raw_frame_stride;     // bytes from one frame's packet row to the next
   int64_t out_frame_stride;     // floats
+  int32_t fc_uniform[2];        // first_count == nullptr: this pair for every stream, carried in the kernel arguments
 };
 
 template <int BYTES>
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(256) void lpcm_unpack_kernel(const UnpackParams p) 
   const int i0 = 4 * (blockIdx.x * 256 + threadIdx.x);
   // {first, count} come from the host per call; whatever they hold, no thread reads outside the frame's packet
   // (the bytes of samples [0, frame_size) are what iamf_hip_lpcm_unpack checked against the raw stride)
-  int first = p.first_count[s * p.fc_stride], count = p.first_count[s * p.fc_stride + 1];
+  int first = p.first_count ? p.first_count[s * p.fc_stride] : p.fc_uniform[0];
+  int count = p.first_count ? p.first_count[s * p.fc_stride + 1] : p.fc_uniform[1];
   first = first < 0 ? 0 : (first > p.lay.frame_size ? p.lay.frame_size : first);
   count = count < p.lay.frame_size - first ? count : p.lay.frame_size - first;
   if (i0 >= count) return;
@@ -90,11 +92,13 @@ extern "C" int iamf_hip_upload_by_kernel(const void *h_pinned, void *d_dst, size
 // n_frames frames per stream in one launch: frame f of stream s reads its packet row at d_raw + s * raw_stream_stride +
 // f * raw_frame_stride and writes d_out + s * out_stream_stride + f * out_frame_stride (iamf_hip_batch_render_lpcm's
 // general form; one {first, count} pair serves all frames of a stream).  The public entry below is n_frames = 1.
+// d_first_count == nullptr: {uniform_first, uniform_count} for every stream, passed with the launch (no device word to keep
+// coherent with launches still queued: iamf_hip_batch_render_lpcm_range's unfused form).
 extern "C" __attribute__((visibility("hidden"))) int iamf_hip_lpcm_unpack_frames(
     const iamf_hip_lpcm_layout *lay, const void *d_raw, int64_t raw_stream_stride, int64_t raw_frame_stride, int32_t n_frames,
     const int32_t *d_first_count, int64_t first_count_stride, float *d_out, int64_t out_stream_stride, int64_t out_frame_stride,
-    int32_t n_streams, void *stream) {
-  if (!lay || !d_raw || !d_first_count || (first_count_stride < 2 && first_count_stride != 0) || !d_out || n_streams <= 0 ||
+    int32_t n_streams, void *stream, int32_t uniform_first, int32_t uniform_count) {
+  if (!lay || !d_raw || (d_first_count && first_count_stride < 2 && first_count_stride != 0) || !d_out || n_streams <= 0 ||
       n_frames <= 0 || (int64_t)n_streams * n_frames > 65535)
     return IAMF_HIP_ERR_BAD_ARG;
   if (lay->sample_bytes < 2 || lay->sample_bytes > 4 || lay->channels <= 0 || lay->channels > IAMF_HIP_LPCM_MAX_CHANNELS ||
@@ -120,6 +124,8 @@ extern "C" __attribute__((visibility("hidden"))) int iamf_hip_lpcm_unpack_frames
   p.n_frames = n_frames;
   p.raw_frame_stride = raw_frame_stride;
   p.out_frame_stride = out_frame_stride;
+  p.fc_uniform[0] = uniform_first;
+  p.fc_uniform[1] = uniform_count;
   const dim3 grid((unsigned)((lay->frame_size / 4 + 255) / 256), (unsigned)lay->channels, (unsigned)(n_streams * n_frames));
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (lay->sample_bytes) {
@@ -134,6 +140,7 @@ extern "C" int iamf_hip_lpcm_unpack(const iamf_hip_lpcm_layout *lay, const void 
                                     const int32_t *d_first_count, int64_t first_count_stride, float *d_out,
                                     int64_t out_stream_stride, int32_t n_streams, void *stream) {
   // one frame per stream: the stream's raw region is the frame's packet row
+  if (!d_first_count) return IAMF_HIP_ERR_BAD_ARG;
   return iamf_hip_lpcm_unpack_frames(lay, d_raw, raw_stream_stride, raw_stream_stride, 1, d_first_count, first_count_stride, d_out,
-                                     out_stream_stride, out_stream_stride, n_streams, stream);
+                                     out_stream_stride, out_stream_stride, n_streams, stream, 0, 0);
 }

@@ -726,7 +726,16 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
   if (FIR && act) {
     // input history for the next call: the last 256 samples of [old history | this call's input]
     float *hn = p.fir_hist_next + (int64_t)s * M * kFirHist;
-    for (int ch = 0; ch < M; ++ch) hn[ch * kFirHist + t] = fir_input(p, in_s, fir_hist, ch, p.total - kFirHist + t);
+    // (and its copy at the input's channel stride, where the batch keeps one for fir_fft_kernel<M, true>: every stage
+    //  leaves both histories current, whichever stage takes the next call)
+    const bool has_pre = p.fir_pre_next != nullptr;
+    const int g256 = has_pre ? p.frame_size >> 8 : 1;
+    const int64_t pre_off = has_pre ? ((int64_t)(s / g256) * M) * p.frame_size + (int64_t)(s % g256) * kFirHist : 0;
+    for (int ch = 0; ch < M; ++ch) {
+      const float x = fir_input(p, in_s, fir_hist, ch, p.total - kFirHist + t);
+      hn[ch * kFirHist + t] = x;
+      if (has_pre) p.fir_pre_next[pre_off + (int64_t)ch * p.frame_size + t] = x;
+    }
   }
   // ---- persist stream state (same format as the generic kernel) ----
   if (act) {

@@ -783,8 +783,11 @@ __global__ __launch_bounds__(256, IAMF_FFT_OCC) void fir_fft_kernel(const Render
   const float *in_s = p.in + (int64_t)s * p.in_stream_stride;
   const float *hist = p.fir_hist + (int64_t)s * M * kFirHist;
   // (FAST2) the stream's rows of the history kept at the input's channel stride: G = frame size / 256 streams per slab
-  const int g256 = p.frame_size >> 8;
-  const int64_t pre_off = FAST2 ? ((int64_t)(s / g256) * M) * p.frame_size + (int64_t)(s % g256) * kFirHist : 0;
+  // Both instantiations keep BOTH copies of the history up to date: a call that ends inside a frame runs the
+  // general fetch, the whole-frame call after it the two-base fetch — which reads `fir_pre` of the call before it.
+  const bool has_pre = p.fir_pre_next != nullptr;   // the batch keeps the copy: frame size a multiple of 256, >= 1024
+  const int g256 = has_pre ? p.frame_size >> 8 : 1;
+  const int64_t pre_off = has_pre ? ((int64_t)(s / g256) * M) * p.frame_size + (int64_t)(s % g256) * kFirHist : 0;
   fir_stage_fft<M, FAST2>(p, in_s, hist, kFftSpan * (int)blockIdx.x, reinterpret_cast<fft_c32 *>(fft_lds), tw,
                           gy + (int64_t)s * gy_stream_stride, FAST2 ? p.fir_pre + pre_off : nullptr);
   if (blockIdx.x == 0) {   // input history for the next call: the last 256 samples of [old history | this call's input]
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(256, IAMF_FFT_OCC) void fir_fft_kernel(const Render
     for (int ch = 0; ch < M; ++ch) {
       const float x = fir_input(p, in_s, hist, ch, p.total - kFirHist + t);
       hn[ch * kFirHist + t] = x;
-      if (FAST2) p.fir_pre_next[pre_off + (int64_t)ch * p.frame_size + t] = x;
+      if (has_pre) p.fir_pre_next[pre_off + (int64_t)ch * p.frame_size + t] = x;
     }
   }
 }

@@ -387,7 +387,8 @@ int iamf_hip_decoder_set_variant(void *decoder_handle, int variant);
  * of a job are split into contiguous blocks, one batch per device, no exchange while rendering.  A shard owns, per
  * device: the batch, a HIP stream for rendering, a second one for the gather, and a host thread that issues that
  * device's launches.  RCCL is loaded with dlopen at the first gather (the library does not link it; a host without it
- * gets IAMF_HIP_ERR_UNIMPLEMENTED from the gather and can still render).
+ * gets IAMF_HIP_ERR_UNIMPLEMENTED from the gather and can still render; IAMF_HIP_RCCL_LIB in the environment names the
+ * library to load instead of the system's librccl).
  * ---------------------------------------------------------------------------------------- */
 typedef struct iamf_hip_shard iamf_hip_shard;
 /* block of streams of device `index` of `n_devices`: sizes differ by at most one, the larger blocks first */
@@ -411,7 +412,19 @@ int iamf_hip_shard_flush(iamf_hip_shard *s, void *const *d_pcm, int64_t pcm_stre
  * in turn waits for it before overwriting the buffers it reads.  iamf_hip_shard_sync waits for everything. */
 int iamf_hip_shard_gather(iamf_hip_shard *s, int root_index, void *d_dst, int64_t dst_stream_stride_bytes,
                           void *const *d_pcm, int64_t pcm_stream_stride_bytes);
+/* The same exchange for the ROWS only: bytes_per_stream bytes of every stream's region (what the last render or flush
+ * emitted: sample-frames x channels x bytes per sample) instead of the whole region with its padding — a flush moves 240
+ * sample-frames per stream, not a call's region.  The strides may differ (each >= bytes_per_stream): rows that are not
+ * back to back are packed / spread through staging buffers of the shard on the gather streams. */
+int iamf_hip_shard_gather_rows(iamf_hip_shard *s, int root_index, void *d_dst, int64_t dst_stream_stride_bytes,
+                               void *const *d_pcm, int64_t pcm_stream_stride_bytes, int64_t bytes_per_stream);
 int iamf_hip_shard_sync(iamf_hip_shard *s);
+/* What the gather cost device `index` (any pointer may be NULL): bytes it sent in the last gather / in all gathers, bytes it
+ * received in the last one (the root: all devices' rows), milliseconds its gather stream spent on its share (pack, send /
+ * receive, spread) in the last gather / in all.  Waits for that device's last gather.  SURVEY 8(e): the root's inbound
+ * links bound the exchange — this is where a caller reads what each peer put on the wire. */
+int iamf_hip_shard_times(iamf_hip_shard *s, int index, int64_t *last_sent_bytes, int64_t *total_sent_bytes,
+                         int64_t *last_received_bytes, double *last_gather_ms, double *total_gather_ms);
 /* "major.minor.patch" of the RCCL found on this host, "" if none (static storage) */
 const char *iamf_hip_shard_rccl_version(void);
 
@@ -495,7 +508,9 @@ int iamf_hip_upload_by_kernel(const void *h_pinned, void *d_dst, size_t bytes, v
  * IAMF_decoder_decode / _configure / _close with IAMF_ERR_INVALID_STATE; destroying the group releases the handles
  * (which are then closed with IAMF_decoder_close as usual).  Returns IAMF_OK, or for create: IAMF_ERR_BAD_ARG (handles
  * of different topologies), IAMF_ERR_INVALID_STATE (not configured / already decoding), IAMF_ERR_UNIMPLEMENTED (handles
- * that resample, or the HOA LFE generator).  The group's own return value reports device failures only.
+ * that resample, or the HOA LFE generator).  The group's own return value reports device failures only
+ * (IAMF_ERR_INTERNAL): such a round is half applied — the library waits for what it had in flight, and every later
+ * _decode of the group returns IAMF_ERR_INVALID_STATE; the valid call after a failure is _destroy.
  * ---------------------------------------------------------------------------------------- */
 typedef struct iamf_hip_decoder_group iamf_hip_decoder_group;
 int iamf_hip_decoder_group_create(void *const *handles, int n, int host_threads, iamf_hip_decoder_group **out);

@@ -2,7 +2,8 @@
  * file with N handles that do NOT advance in step: in round r handle i is starved (one byte: no complete OBU) when
  * (r + i) % 3 == 0, and a handle that has eaten its whole stream flushes while the others go on.  Prints every
  * handle's total; tests/test_facade_malformed.py compares them with the single-handle driver's.
- * usage: group_driver file.iamf <sound system id | b> bits N threads */
+ * usage: group_driver file.iamf <sound system id | b> bits N threads [other.iamf]
+ * (other.iamf: the odd handles are configured from that stream instead — what group_create says about the mix is the test) */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -21,6 +22,18 @@ int main(int argc, char **argv) {
   if (fread(buf, 1, size, f) != (size_t)size) return 2;
   fclose(f);
   const int bits = atoi(argv[3]), N = atoi(argv[4]), threads = atoi(argv[5]);
+  uint8_t *alt = 0;
+  long alt_size = 0;
+  if (argc > 6) {
+    FILE *fa = fopen(argv[6], "rb");
+    if (!fa) return 2;
+    fseek(fa, 0, SEEK_END);
+    alt_size = ftell(fa);
+    fseek(fa, 0, SEEK_SET);
+    alt = (uint8_t *)malloc(alt_size ? alt_size : 1);
+    if (fread(alt, 1, alt_size, fa) != (size_t)alt_size) return 2;
+    fclose(fa);
+  }
   int ch = 2;
   void **h = (void **)calloc(N, sizeof(void *));
   uint32_t *used = (uint32_t *)calloc(N, sizeof(uint32_t)), *rs = (uint32_t *)calloc(N, sizeof(uint32_t));
@@ -40,7 +53,8 @@ int main(int argc, char **argv) {
       ch = IAMF_layout_sound_system_channels_count((IAMF_SoundSystem)atoi(argv[2]));
     }
     uint32_t r0 = 0;
-    int r = IAMF_decoder_configure(d, buf, (uint32_t)size, &r0);
+    int r = (alt && (i & 1)) ? IAMF_decoder_configure(d, alt, (uint32_t)alt_size, &r0)
+                             : IAMF_decoder_configure(d, buf, (uint32_t)size, &r0);
     if (i == 0) printf("configure %d rsize %u\n", r, r0);
     if (r != IAMF_OK) return 0;
     used[i] = r0;
@@ -49,7 +63,14 @@ int main(int argc, char **argv) {
   iamf_hip_decoder_group *g = 0;
   int rc = iamf_hip_decoder_group_create(h, N, threads, &g);
   printf("group_create %d\n", rc);
-  if (rc) return 0;
+  if (rc) {
+    for (int i = 0; i < N; ++i) {
+      IAMF_decoder_close((IAMF_DecoderHandle)h[i]);
+      free(pcm[i]);
+    }
+    free(h); free(used); free(rs); free(total); free(done); free(pcm); free(data); free(sizes); free(res); free(buf); free(alt);
+    return 0;
+  }
   { /* a grouped handle refuses the single-handle entry points */
     uint32_t x = 0;
     printf("single_decode_while_grouped %d close %d\n", IAMF_decoder_decode((IAMF_DecoderHandle)h[0], buf, 4, &x, pcm[0]),
@@ -99,6 +120,6 @@ int main(int argc, char **argv) {
     IAMF_decoder_close((IAMF_DecoderHandle)h[i]);
     free(pcm[i]);
   }
-  free(h); free(used); free(rs); free(total); free(done); free(pcm); free(data); free(sizes); free(res); free(buf);
+  free(h); free(used); free(rs); free(total); free(done); free(pcm); free(data); free(sizes); free(res); free(buf); free(alt);
   return 0;
 }

@@ -209,3 +209,28 @@ def test_group_with_a_hostile_trim_goes_on_like_the_single_handle(driver, group_
     out = run_group(group_driver, tmp_path, s, 4, 2)
     assert [int(l.split()[2]) for l in out if l.startswith("total h")] == [want] * 4
     assert "decode -1 rsize" in "\n".join(out)   # handle 0 reported IAMF_ERR_BAD_ARG for that unit
+
+
+def test_group_refuses_handles_that_differ_in_lpcm_byte_order(group_driver, tmp_path):
+    """the batch's one unpack layout is built from handle 0, so handles that differ in the codec
+    config's sample_format_flags (pcm/IAMF_pcm_decoder.c:60-62) must not share a group: IAMF_ERR_BAD_ARG, as the
+    header promises for differing codec configuration."""
+    pd = lambda pid: W.param_definition(pid, 48000, mode=1)
+
+    def desc(le):
+        s = W.sequence_header(1) + W.codec_config_lpcm(0, FS, 16, 48000, little_endian=le)
+        s += W.audio_element_channel(1, 0, 1, [0])
+        return s + W.mix_presentation(1, [dict(eid=1, pdef=pd(100), default_q78=0)], dict(pdef=pd(101), default_q78=0), [("ss", 0)])
+
+    le = desc(True) + stereo_frame(seed=1)
+    be = desc(False) + stereo_frame(seed=1)
+    p1, p2 = os.path.join(str(tmp_path), "le.iamf"), os.path.join(str(tmp_path), "be.iamf")
+    open(p1, "wb").write(le)
+    open(p2, "wb").write(be)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0")
+    r = subprocess.run([group_driver, p1, "0", "16", "4", "2", p2], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr, r.stderr[-2000:]
+    assert "group_create -1" in r.stdout.splitlines(), r.stdout
+    # the same four handles from ONE stream form a group
+    r = subprocess.run([group_driver, p1, "0", "16", "4", "2", p1], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "group_create 0" in r.stdout.splitlines(), (r.stdout, r.stderr[-2000:])

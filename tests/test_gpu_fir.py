@@ -262,3 +262,67 @@ def test_a_call_that_ends_inside_a_frame_with_nans_behind_it(hip):
         assert y.shape == (keep, 2)
         assert np.isfinite(y).all(), s
         assert np.abs(y.T - fir64(h, x[s][:, :keep])).max() <= 2.0 ** -19, s
+
+
+def _fir_mixed_calls(A, G, h, x, fs, calls, taps):
+    """calls = [(n_frames, n_samples)]: n_samples > 0 = a call that ends inside its (single) frame.  x is the stream's
+    programme as the renderer consumes it (kept samples back to back); what lies behind a partial call's samples in its
+    frame buffer is NaN.  Returns the stage's f32 output [S][kept][2] (limiter threshold +60 dB: gains exactly 1)."""
+    import torch
+    S, m = x.shape[0], x.shape[1]
+    b = A.Batch(S, A.fir_matrix(h), 2, frame_size=fs, out_format=A.FMT_F32, limiter=True, threshold_db=60.0, fir_taps=taps)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = [[] for _ in range(S)]
+    pos = 0
+    for nf, ns in calls:
+        take = ns if ns else nf * fs
+        buf = np.full((S, nf, m, fs), np.nan, np.float32)
+        seg = x[:, :, pos:pos + take]
+        if ns:
+            buf[:, 0, :, :ns] = seg
+        else:
+            buf[:] = seg.reshape(S, m, nf, fs).transpose(0, 2, 1, 3)
+        pos += take
+        d_in = torch.from_numpy(buf).cuda()
+        cap = nf * fs * 2 * 4
+        pcm = torch.zeros((S, cap), dtype=torch.uint8, device="cuda")
+        a = A.RenderArgs()
+        a.d_in, a.in_stream_stride, a.in_frame_stride = d_in.data_ptr(), nf * m * fs, m * fs
+        a.n_frames, a.n_samples, a.d_pcm, a.pcm_stream_stride_bytes, a.stream = nf, ns, pcm.data_ptr(), cap, st
+        n = b.render_ex(a)
+        assert n >= 0, n
+        torch.cuda.synchronize()
+        hp = pcm.cpu().numpy()
+        for s in range(S):
+            outs[s].append(hp[s][:n * 2 * 4].view(np.float32).reshape(n, 2).copy())
+    pcm = torch.zeros((S, 240 * 2 * 4), dtype=torch.uint8, device="cuda")
+    n = b.flush(pcm.data_ptr(), 240 * 2 * 4, st)
+    torch.cuda.synchronize()
+    hp = pcm.cpu().numpy()
+    b.close()
+    return [np.concatenate(outs[s] + [hp[s][:n * 2 * 4].view(np.float32).reshape(n, 2)], axis=0) for s in range(S)], pos
+
+
+# m = 4 / 16: fir_fft_kernel<M> of iamf_render.hip (ambisonics); m = 6 / 12: the channel-based launcher (iamf_render_fir_m2b.hip)
+@pytest.mark.parametrize("m", [4, 16, 6, 12])
+@pytest.mark.parametrize("calls", [[(1, 512), (2, 0), (1, 960), (1, 0)], [(1, 960), (1, 0), (3, 0)], [(2, 0), (1, 64), (1, 0), (1, 512), (2, 0)]])
+def test_partial_call_then_whole_frames_hands_the_history_over(hip, monkeypatch, m, calls):
+    """a call that ends inside a frame runs the general fetch, the whole-frame call after it the two-base
+    fetch — which takes its first hop's 256 history samples from the copy kept at the input's channel stride
+    (RenderParams::fir_pre).  Every stage kernel must leave BOTH copies current: partial -> whole -> partial -> whole must
+    give the floats of the general fetch throughout, and the float64 convolution of the programme."""
+    A, G = hip
+    fs, taps, S = 1024, 256, 5            # 5 streams: G = 4 streams per history slab, the last slab partly filled
+    total = sum(ns if ns else nf * fs for nf, ns in calls)
+    x = np.stack([synth.gaussian(2300 + s, m, total, 0.1) for s in range(S)])
+    h = hrir_set(19, m, taps)
+    y2, used = _fir_mixed_calls(A, G, h, x, fs, calls, taps)
+    assert used == total
+    monkeypatch.setenv("IAMF_HIP_FIR_GENERAL_FETCH", "1")
+    yg, _ = _fir_mixed_calls(A, G, h, x, fs, calls, taps)
+    monkeypatch.delenv("IAMF_HIP_FIR_GENERAL_FETCH")
+    for s in range(S):
+        assert y2[s].shape == (total, 2)
+        assert np.isfinite(y2[s]).all(), s
+        assert np.array_equal(y2[s], yg[s]), s
+        assert np.abs(y2[s].T - fir64(h, x[s])).max() <= 2.0 ** -19, s
