@@ -173,6 +173,9 @@ def lib():
                                             C.POINTER(C.c_void_p), C.c_int64]
         L.iamf_hip_shard_flush.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int64]
         L.iamf_hip_shard_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_int64]
+        L.iamf_hip_shard_gather_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_int64, C.c_int64]
+        L.iamf_hip_shard_times.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.iamf_hip_shard_sync.argtypes = [C.c_void_p]
         L.iamf_hip_shard_rccl_version.restype = C.c_char_p
         _lib = L

@@ -186,3 +186,100 @@ def test_generated_lfe_chain_loop_is_what_the_generator_writes(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_lfe_chain_asm.py"), str(out)], env=env,
                           stdout=subprocess.DEVNULL)
     assert out.read_text() == open(os.path.join(root, "iac_amd", "csrc", "lfe_chain_asm.inc")).read()
+
+
+# ---- iamf_shard.hip's N > 1 path, run before any multi-GPU box does ----
+# iac_amd/csrc/iamf_shard.hip is host code: it is compiled here with g++ against tests/shard_stub/fake_hip.cpp (a HIP
+# runtime stand-in with 8 "devices" whose streams are real asynchronous queues and whose events have HIP's semantics) and
+# loads tests/shard_stub/fake_rccl.cpp through IAMF_HIP_RCCL_LIB (send / recv matched inside the group, copies done when
+# both streams have arrived).  Under AddressSanitizer + UBSan and under ThreadSanitizer.  What the driver checks: every
+# byte of every step's gathered buffer (rows from the right device, stream and step — step i's gather runs beside step
+# i + 1's render into the SAME PCM buffers, nothing waits in between), nothing written between the rows, the per-peer byte
+# accounting, no HIP object left behind.  The stand-ins were checked to be sensitive: without the render's wait on
+# `gathered`, without the gather's wait on `rendered`, or with the receive offsets indexed by device instead of by first
+# stream, the driver reports MISMATCH (ASan build) / a data race (TSan build).
+SHARD_STUB = os.path.join(ROOT, "tests", "shard_stub")
+
+
+def _build_shard_rehearsal(kind):
+    import subprocess
+    b = os.path.join(SHARD_STUB, "build_" + kind)
+    os.makedirs(b, exist_ok=True)
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"] if kind == "asan" else ["-fsanitize=thread"]
+    flags = ["-std=c++17", "-g", "-O1", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"),
+             "-I/opt/rocm/include"] + san
+    srcs = [os.path.join(SHARD_STUB, x) for x in ("fake_hip.cpp", "fake_rccl.cpp", "shard_driver.cpp")]
+    srcs += [os.path.join(ROOT, "iac_amd", "csrc", "iamf_shard.hip"), os.path.join(ROOT, "include", "iamf_hip.h")]
+    exe = os.path.join(b, "shard_driver")
+    if os.path.exists(exe) and all(os.path.getmtime(x) <= os.path.getmtime(exe) for x in srcs):
+        return b
+    rpath = "-Wl,-rpath,$ORIGIN"
+    subprocess.check_call(["g++"] + flags + ["-fPIC", "-shared", srcs[0], "-o", os.path.join(b, "libfakehip.so"), "-lpthread"])
+    subprocess.check_call(["g++"] + flags + ["-fPIC", "-shared", srcs[1], "-o", os.path.join(b, "librccl_fake.so"), "-L" + b, "-lfakehip", rpath])
+    subprocess.check_call(["g++"] + flags + ["-x", "c++", srcs[3], srcs[2], "-o", exe, "-L" + b, "-lfakehip", "-ldl", "-lpthread", rpath])
+    return b
+
+
+@pytest.fixture(scope="module", params=["asan", "tsan"])
+def shard_rehearsal(request):
+    return request.param, _build_shard_rehearsal(request.param)
+
+
+def _run_shard(rehearsal, args, env_extra=None):
+    import subprocess
+    kind, b = rehearsal
+    env = dict(os.environ, IAMF_HIP_RCCL_LIB=os.path.join(b, "librccl_fake.so"), ASAN_OPTIONS="detect_leaks=1:abort_on_error=0",
+               TSAN_OPTIONS="halt_on_error=1")
+    env.update(env_extra or {})
+    r = subprocess.run([os.path.join(b, "shard_driver")] + [str(a) for a in args], capture_output=True, text=True, timeout=300, env=env)
+    if "LeakSanitizer has encountered a fatal error" in r.stderr:   # LeakSanitizer cannot always stop the world in a container
+        r = subprocess.run([os.path.join(b, "shard_driver")] + [str(a) for a in args], capture_output=True, text=True, timeout=300,
+                           env=dict(env, ASAN_OPTIONS="detect_leaks=0"))
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0 and "MISMATCH" not in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    return r.stdout.strip().splitlines()
+
+
+@pytest.mark.parametrize("streams,devices,root,steps,ordinals", [
+    (10, 4, 0, 3, None),            # uneven split 3 / 3 / 2 / 2
+    (10, 4, 2, 4, "3,1,6,0"),       # root != 0, device ordinals that are not the shard indices
+    (7, 2, 1, 3, None),             # N = 2
+    (67, 8, 5, 4, None),            # N = 8
+    (8, 8, 7, 2, "7,6,5,4,3,2,1,0"),   # one stream per device
+])
+def test_shard_n_devices_gather_rows_beside_the_next_render(shard_rehearsal, streams, devices, root, steps, ordinals):
+    out = _run_shard(shard_rehearsal, [streams, devices, root, steps, "rows"] + ([ordinals] if ordinals else []))
+    assert out[0] == "create 0 devices %d" % devices
+    assert out[-2].startswith("ok %d destinations, %d streams over %d devices, root %d" % (steps + 1, streams, devices, root))
+    assert out[-1] == "clean"
+    # per-peer bytes of the last gather (the flush: 240 sample-frames x 2 channels x 2 bytes per stream), root receives all
+    sent = [int(l.split()[4]) for l in out if l.startswith("device ")]
+    recv = [int(l.split()[10]) for l in out if l.startswith("device ")]
+    q, r = divmod(streams, devices)
+    assert sent == [960 * (q + (1 if i < r else 0)) for i in range(devices)]
+    assert recv == [960 * streams if i == root else 0 for i in range(devices)]
+
+
+def test_shard_whole_region_gather_n2_and_n4(shard_rehearsal):
+    assert _run_shard(shard_rehearsal, [7, 2, 1, 3, "whole"])[-1] == "clean"
+    assert _run_shard(shard_rehearsal, [10, 4, 3, 2, "whole"])[-1] == "clean"
+
+
+def test_shard_destroy_with_a_gather_in_flight(shard_rehearsal):
+    out = _run_shard(shard_rehearsal, [10, 4, 1, 3, "destroy"])
+    assert out[-1] == "clean" and out[-2].startswith("ok 3 destinations")
+
+
+def test_shard_failing_peer_is_reported_and_the_shard_goes_on(shard_rehearsal):
+    out = _run_shard(shard_rehearsal, [10, 4, 0, 3, "fail"], {"FAKE_RCCL_FAIL_SEND_RANK": "2", "FAKE_RCCL_FAIL_AT_GROUP": "0"})
+    assert "gather step 0 under a failing peer: -100" in out   # IAMF_HIP_ERR_DEVICE
+    assert out[-2].endswith("failures seen 1") and out[-1] == "clean"
+
+
+def test_shard_refuses_more_devices_than_streams_and_comm_init_failure(shard_rehearsal):
+    assert _run_shard(shard_rehearsal, [3, 4, 0, 1, "rows"])[0].startswith("create -1")   # IAMF_HIP_ERR_BAD_ARG
+    import subprocess
+    kind, b = shard_rehearsal
+    env = dict(os.environ, IAMF_HIP_RCCL_LIB=os.path.join(b, "librccl_fake.so"), FAKE_RCCL_FAIL_INIT="1", ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([os.path.join(b, "shard_driver"), "6", "3", "0", "1", "rows"], capture_output=True, text=True, timeout=120, env=env)
+    assert "MISMATCH gather step 0 returned" in r.stdout and "ncclCommInitAll failed" in r.stderr
