@@ -167,6 +167,7 @@ typedef struct {
   uint64_t recon_pid;
 } Element;
 
+enum { MAX_ANCHORS = 16 };
 typedef struct {
   uint64_t id;
   int nel;
@@ -177,7 +178,8 @@ typedef struct {
   int16_t out_gain_q;
   int nlayouts;
   int layout_type[8], layout_ss[8];
-  IAMF_LoudnessInfo loud[8];
+  IAMF_LoudnessInfo loud[8];              /* anchor_loudness stays NULL here: the values live in anchors[] */
+  anchor_loudness_t anchors[8][MAX_ANCHORS];
 } Presentation;
 
 struct IAMF_Decoder {
@@ -256,6 +258,11 @@ struct IAMF_Decoder {
   iamf_hip_batch_config cfg_sig;        /* what setup_pipeline created the batch from (mat pointer zeroed) ... */
   const float *cfg_mat;                 /* ... and its matrix */
   iamf_hip_demix_config dc_sig;         /* the demixer configuration, if use_demix */
+  /* IAMF_decoder_get_last_metadata (IAMF_decoder.c:3619-3706,4150-4168) */
+  uint64_t meta_duration;   /* ctx->duration: samples returned since IAMF_decoder_set_pts */
+  int el_dmx_mode[2];       /* cctx->dmx_mode of the presentation's elements (batch order), -1 = none yet */
+  uint32_t meta_dmixp;      /* ctx->metadata.param->dmixp_mode */
+  int swapped;              /* the presentation's two elements were exchanged for the batch (setup_pipeline) */
   int started;      /* a configure call with data has been made: status left INIT */
   int need_reconf;  /* a new IA sequence header was met while decoding: status RECONFIGURE */
 };
@@ -580,9 +587,14 @@ static int parse_presentation(struct IAMF_Decoder *d, const Obu *o) { /* IAMF_OB
     p.loud[i].integrated_loudness = (int16_t)rd_u16(&r);
     p.loud[i].digital_peak = (int16_t)rd_u16(&r);
     if (p.loud[i].info_type & 1) p.loud[i].true_peak = (int16_t)rd_u16(&r);
-    if (p.loud[i].info_type & 2) {
+    if (p.loud[i].info_type & 2) { /* IAMF_OBU.c:890-912 */
       int n = rd_u8(&r);
-      rd_skip(&r, 3 * (uint64_t)n);
+      if (n > MAX_ANCHORS) return IAMF_ERR_UNIMPLEMENTED; /* the specification defines three anchor elements */
+      p.loud[i].num_anchor_loudness = (uint8_t)n;
+      for (int k = 0; k < n; ++k) {
+        p.anchors[i][k].anchor_element = rd_u8(&r);
+        p.anchors[i][k].anchored_loudness = (int16_t)rd_u16(&r);
+      }
     }
     if (p.loud[i].info_type & ~3) rd_skip(&r, rd_leb128(&r));
   }
@@ -677,22 +689,24 @@ static int parse_parameter_block(struct IAMF_Decoder *d, const Obu *o) {
       }
     }
   }
-  /* iamf_stream_decoder_update_parameter, IAMF_decoder.c:2130-2151: a demixing block sets the
-   * element's mode from the segment covering the middle of the current frame */
-  if (p->type == IAMF_PARAMETER_TYPE_DEMIXING && d->sel_el[0] && d->sel_el[0]->has_demix &&
-      d->sel_el[0]->demix_pid == p->id) {
+  /* iamf_stream_decoder_update_parameter, IAMF_decoder.c:2130-2151: a demixing block sets the mode of every selected
+   * channel-based element that names the parameter, from the segment covering the middle of the current frame */
+  for (int e = 0; e < 2 && p->type == IAMF_PARAMETER_TYPE_DEMIXING; ++e) {
+    if (!d->sel || e >= d->sel->nel || !d->sel_el[e] || !d->sel_el[e]->has_demix || d->sel_el[e]->demix_pid != p->id) continue;
     const uint64_t pts = d->timestamp + d->frame_size / 2;
-    d->dmx_mode = IAMF_ERR_INTERNAL;
+    int mode = IAMF_ERR_INTERNAL;
     if (pts > p->timestamp && pts <= p->timestamp + p->duration) { /* :799-841 */
       uint64_t start = pts - p->timestamp;
       for (int i = 0; i < p->qn; ++i) {
         if (start < p->q[i].interval) {
-          d->dmx_mode = p->q[i].anim;
+          mode = p->q[i].anim;
           break;
         }
         start -= p->q[i].interval;
       }
     }
+    d->el_dmx_mode[e] = mode;
+    if (e == 0) d->dmx_mode = mode; /* the element the batch's demixer / down-mixer serves */
   }
   return IAMF_OK;
 }
@@ -880,6 +894,9 @@ static void reset_descriptors(struct IAMF_Decoder *d) {
   d->el_gain_p[0] = d->el_gain_p[1] = d->out_gain_p = d->demix_p = 0;
   d->use_dmx = d->use_demix = 0;
   d->dmx_mode = -1;
+  d->el_dmx_mode[0] = d->el_dmx_mode[1] = -1;
+  d->meta_dmixp = 0;
+  d->swapped = 0;
   d->rec_flags = 0;
   d->rec_n = 0;
   memset(d->layer_rec_flags, 0, sizeof(d->layer_rec_flags));
@@ -984,6 +1001,56 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   d->pcm_stride = d->tv ? 12 : d->out_channels;
   d->pcm_extra = d->out_channels > d->pcm_stride ? d->out_channels - d->pcm_stride : 0;
   cfg.projection = IAMF_HIP_PROJ_EXACT; /* a single decoder handle is not throughput bound */
+  /* Which layer of every channel-based element is decoded (iamf_stream_set_output_layout, IAMF_decoder.c:1776-1822) */
+  for (int i = 0; i < p->nel; ++i) {
+    Element *e = d->sel_el[i];
+    if (e->type != AUDIO_ELEMENT_CHANNEL_BASED) continue;
+    e->layout = e->layer[select_layer(d, e)].layout;
+    e->channels = k_layout_channels[e->layout];
+  }
+  /* The batch has ONE pre-stage in front of ONE element: the demixer of a scalable / output-gained channel element
+   * (IAMF_decoder.c:2351-2386), the parametric down-mixer (:2448-2478), the projection de-mapping (IAMF_core_decoder.c:
+   * 116-130) or the LFE generator's source (:2625-2636); its second element is a plain matrix.  The reference runs all
+   * of these per STREAM and then mixes  0 + frame_0 + frame_1  (iamf_mixer_mix, :2702-2733) — an f32 sum that does not
+   * depend on the order of the two frames (0 + a is a; a + b is b + a in IEEE arithmetic; two -0 terms give +0 either
+   * way, which no PCM word can tell).  So a presentation whose SECOND element needs the pre-stage is rendered with its
+   * two elements exchanged: every per-element item (mix-gain definition and default, parameter streams, packets) is
+   * indexed through the presentation entry that is exchanged here.  Both elements needing one: not built
+   * (IAMF_ERR_UNIMPLEMENTED below). */
+  {
+    const int out_layout = d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION ? k_ss_layout[d->out_ss] : -1;
+    int needs[2] = {0, 0};
+    for (int i = 0; i < p->nel; ++i) {
+      const Element *e = d->sel_el[i];
+      if (e->type == AUDIO_ELEMENT_CHANNEL_BASED) {
+        int lay = select_layer(d, e), gains = 0;
+        for (int k = 0; k <= lay; ++k) gains |= e->layer[k].out_gain_flag;
+        needs[i] = e->nlayers > 1 || gains || (e->has_demix && out_layout >= 0 && iamf_hip_dmx_valid(e->layout, out_layout));
+      } else {
+        needs[i] = e->amb_projection || (d->lfe_hoa && d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION);
+      }
+    }
+    if (p->nel == 2 && needs[1] && !needs[0]) {
+      const uint64_t id = p->el_id[0];
+      const ParamDef pd = p->el_gain_def[0];
+      const int16_t q = p->el_gain_q[0];
+      Element *e = d->sel_el[0];
+      Param *gp = d->el_gain_p[0];
+      p->el_id[0] = p->el_id[1];
+      p->el_gain_def[0] = p->el_gain_def[1];
+      p->el_gain_q[0] = p->el_gain_q[1];
+      d->sel_el[0] = d->sel_el[1];
+      d->el_gain_p[0] = d->el_gain_p[1];
+      p->el_id[1] = id;
+      p->el_gain_def[1] = pd;
+      p->el_gain_q[1] = q;
+      d->sel_el[1] = e;
+      d->el_gain_p[1] = gp;
+      d->swapped ^= 1; /* (a second configuration of the same descriptors finds them exchanged already) */
+    } else if (p->nel == 2 && needs[1]) {
+      return IAMF_ERR_UNIMPLEMENTED;
+    }
+  }
   /* IAMF_decoder.c:2625-2633: scene-based element, LFE generator compiled in, layout with an LFE.  The
    * reference keeps ONE filter per output layout, so two scene-based elements would run their W
    * channels through the same histories in turn; only the single-filter case is taken here */
@@ -998,16 +1065,13 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   d->use_dmx = 0;
   d->demix_p = 0;
   d->use_demix = 0;
-  for (int i = 0; i < p->nel; ++i) {
-    Element *e = d->sel_el[i];
-    if (e->type != AUDIO_ELEMENT_CHANNEL_BASED) continue;
-    {
+  d->el_dmx_mode[0] = d->el_dmx_mode[1] = -1; /* cctx->dmx_mode = INVALID_VALUE at stream creation, :1728 */
+  {
+    Element *e = d->sel_el[0];
+    if (e->type == AUDIO_ELEMENT_CHANNEL_BASED) {
       int lay = select_layer(d, e), gains = 0;
       for (int k = 0; k <= lay; ++k) gains |= e->layer[k].out_gain_flag;
-      e->layout = e->layer[lay].layout;
-      e->channels = k_layout_channels[e->layout];
       if (e->nlayers > 1 || gains) {
-        if (i > 0) return IAMF_ERR_UNIMPLEMENTED; /* the batch runs the demixer in front of element 0 only */
         d->use_demix = 1;
         d->demix_layer = lay;
       }
@@ -1018,7 +1082,6 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
     int out_layout = d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION ? k_ss_layout[d->out_ss] : -1;
     if (e0->type == AUDIO_ELEMENT_CHANNEL_BASED && e0->has_demix && out_layout >= 0 &&
         iamf_hip_dmx_valid(e0->layout, out_layout)) {
-      if (p->nel > 1) return IAMF_ERR_UNIMPLEMENTED;
       d->use_dmx = 1;
       cfg.matrix.kind = IAMF_HIP_KIND_DMX;
       cfg.matrix.in_id = e0->layout;
@@ -1092,7 +1155,6 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
       if (e0->has_demix && d->param[i].id == e0->demix_pid) d->demix_p = &d->param[i];
     if (hipHostMalloc((void **)&d->h_demix, sizeof(iamf_hip_demix_frame), 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
   }
-  if (p->nel == 2 && d->sel_el[1]->amb_projection) return IAMF_ERR_UNIMPLEMENTED;
   if (p->nel == 2) {
     iamf_hip_matrix m2;
     float one = 1.f;
@@ -1217,6 +1279,8 @@ int IAMF_decoder_configure(IAMF_DecoderHandle d, const uint8_t *data, uint32_t s
      * across the rebuild of the pipeline. */
     const uint64_t ts = d->timestamp;
     const int dmx_mode = d->dmx_mode, use_demix = d->use_demix;
+    const int was_swapped = d->swapped, el_mode0 = d->el_dmx_mode[0], el_mode1 = d->el_dmx_mode[1];
+    const int had_limiter = d->limiter_on && d->configured;
     const iamf_hip_demix_state dmst = d->dmst;
     const uint32_t rec_flags = d->rec_flags;
     const int rec_n = d->rec_n;
@@ -1232,6 +1296,14 @@ int IAMF_decoder_configure(IAMF_DecoderHandle d, const uint8_t *data, uint32_t s
     if (rc == IAMF_OK) {
       d->timestamp = ts;
       d->dmx_mode = dmx_mode;
+      /* the stream contexts (and their demixing modes) live on; if this layout exchanges the elements the other way
+       * round, the modes follow their elements */
+      d->el_dmx_mode[0] = was_swapped == d->swapped ? el_mode0 : el_mode1;
+      d->el_dmx_mode[1] = was_swapped == d->swapped ? el_mode1 : el_mode0;
+      if (had_limiter) { /* IAMF_decoder.c:3837-3842: the limiter's delayed samples are counted as delivered */
+        d->meta_duration += 240;
+        d->last_frame += 240;
+      }
       memcpy(d->layer_rec_flags, lrf, sizeof(lrf));
       memcpy(d->layer_rec_gain, lrg, sizeof(lrg));
       if (use_demix && d->use_demix) { /* the demixer is part of the stream decoder, which is not re-opened */
@@ -1360,6 +1432,31 @@ static int tu_complete(const struct IAMF_Decoder *d) { /* IAMF_decoder.c:2854-28
   return 1;
 }
 
+/* time_transform, IAMF_decoder.c:91-95 */
+static int64_t time_transform(int64_t t1, int s1, int s2) {
+  double r;
+  if (s1 == s2) return t1;
+  r = (double)(t1 * s2);
+  return (int64_t)(r / s1 + 0.5f);
+}
+
+/* What a decoded temporal unit leaves for IAMF_decoder_get_last_metadata, as the reference's frame loop does
+ * (IAMF_decoder.c:3410-3415: the caller's pts moves on by the samples trimmed from the START of a frame;
+ * :3436-3442: the demixing mode of the last channel-based element, in presentation order, that has one) */
+static void meta_note_frame(struct IAMF_Decoder *d, int s0, uint64_t trim_end) {
+  const int fs = (int)d->frame_size;
+  if (s0 > 0 && s0 != fs && trim_end != (uint64_t)fs) d->pts += time_transform(s0, (int)d->rate, (int)d->pts_base);
+  for (int k = 0; k < d->sel->nel; ++k) {
+    const int e = d->swapped ? d->sel->nel - 1 - k : k;
+    if (d->sel_el[e]->type == AUDIO_ELEMENT_CHANNEL_BASED && d->el_dmx_mode[e] >= 0) d->meta_dmixp = (uint32_t)d->el_dmx_mode[e];
+  }
+}
+/* ctx->duration / ctx->last_frame_size, IAMF_decoder.c:3521-3522 */
+static void meta_note_output(struct IAMF_Decoder *d, int n) {
+  d->meta_duration += (uint64_t)(n > 0 ? n : 0);
+  d->last_frame = (uint32_t)(n > 0 ? n : 0);
+}
+
 static int render_tu(struct IAMF_Decoder *d, void *pcm) {
   iamf_hip_render_args a;
   const int fs = (int)d->frame_size, bytes = (int)d->bit_depth / 8;
@@ -1397,6 +1494,7 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     d->timestamp += fs;
     return 0;
   }
+  meta_note_frame(d, s0, d->tu_trim_end);
   /* mix gains of this frame */
   {
     const uint64_t pt = d->timestamp + (uint64_t)s0;
@@ -1502,17 +1600,29 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
   if (n > 0) memcpy(pcm, d->h_pcm, ((size_t)n * d->pcm_stride + d->pcm_extra) * bytes);
   params_time_elapse(d, (uint64_t)keep); /* IAMF_decoder.c:3471: the mixed frame's length */
   d->timestamp += fs;
-  d->last_frame = (uint32_t)n;
+  meta_note_output(d, n);
   return n;
 }
 
 static int flush_tail(struct IAMF_Decoder *d, void *pcm) { /* iamf_delay_buffer_handle, IAMF_decoder.c:3250-3301 */
   const int bytes = (int)d->bit_depth / 8;
   int n = 0;
-  if (d->flushed) return 0;
+  if (d->flushed) {
+    /* Every further flush call of the reference pushes another 240 zeros through the limiter and hands out what they
+     * displace (iamf_delay_buffer_handle, :3284-3299): the zeros of the flush before, times a positive gain — 240
+     * sample-frames of zero PCM.  (With a resampler it also drains 35-odd more samples of filter tail per call: not
+     * mirrored, 0.)  Either way the call ends at :3521-3522. */
+    n = (!d->rs && d->limiter_on) ? 240 : 0;
+    if (n) memset(pcm, 0, ((size_t)n * d->pcm_stride + d->pcm_extra) * bytes);
+    meta_note_output(d, n);
+    return n;
+  }
   d->flushed = 1;
   if (!d->rs) {
-    if (!d->limiter_on) return 0;
+    if (!d->limiter_on) {
+      meta_note_output(d, 0);
+      return 0;
+    }
     n = iamf_hip_batch_flush(d->batch, d->h_pcm, (int64_t)d->pcm_cap, d->stream);
   } else {
     const int cap = iamf_hip_resampler_flush_capacity(d->rs);
@@ -1526,6 +1636,7 @@ static int flush_tail(struct IAMF_Decoder *d, void *pcm) { /* iamf_delay_buffer_
   if (n < 0) return IAMF_ERR_INTERNAL;
   if (hipStreamSynchronize(d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
   if (n > 0) memcpy(pcm, d->h_pcm, ((size_t)n * d->pcm_stride + d->pcm_extra) * bytes);
+  meta_note_output(d, n);
   return n;
 }
 
@@ -1676,44 +1787,79 @@ int IAMF_decoder_set_sampling_rate(IAMF_DecoderHandle d, uint32_t rate) { /* IAM
   return IAMF_ERR_BAD_ARG;
 }
 IAMF_StreamInfo *IAMF_decoder_get_stream_info(IAMF_DecoderHandle d) { return d ? &d->info : 0; }
-int IAMF_decoder_set_pts(IAMF_DecoderHandle d, int64_t pts, uint32_t time_base) {
+int IAMF_decoder_set_pts(IAMF_DecoderHandle d, int64_t pts, uint32_t time_base) { /* IAMF_decoder.c:4136-4148 */
   if (!d) return IAMF_ERR_BAD_ARG;
   d->pts = pts;
   d->pts_base = time_base;
+  d->meta_duration = 0;
   return IAMF_OK;
 }
+
+/* iamf_presentation_get_output_sound_mode + iamf_sound_mode_combine, IAMF_decoder.c:241-254,1555-1578 */
+static IAMF_SoundMode sound_mode_of(const struct IAMF_Decoder *d) {
+  IAMF_SoundMode mode = IAMF_SOUND_MODE_NONE;
+  for (int i = 0; i < d->sel->nel; ++i) {
+    const Element *e = d->sel_el[i];
+    IAMF_SoundMode sm;
+    if (e->type == AUDIO_ELEMENT_SCENE_BASED) /* iamf_layout_get_sound_mode of the output layout, :358-369 */
+      sm = d->out_type == IAMF_LAYOUT_TYPE_BINAURAL ? IAMF_SOUND_MODE_BINAURAL
+           : d->out_ss == SOUND_SYSTEM_A            ? IAMF_SOUND_MODE_STEREO
+                                                    : IAMF_SOUND_MODE_MULTICHANNEL;
+    else /* the layer that is decoded (cctx->layout, :1726) */
+      sm = (e->layout == IA_CHANNEL_LAYOUT_MONO || e->layout == IA_CHANNEL_LAYOUT_STEREO) ? IAMF_SOUND_MODE_STEREO
+           : e->layout == IA_CHANNEL_LAYOUT_BINAURAL                                      ? IAMF_SOUND_MODE_BINAURAL
+                                                                                          : IAMF_SOUND_MODE_MULTICHANNEL;
+    if (mode == IAMF_SOUND_MODE_NONE) mode = sm;
+    else if (sm == IAMF_SOUND_MODE_NONE || mode == sm) ;
+    else if (mode == IAMF_SOUND_MODE_BINAURAL || sm == IAMF_SOUND_MODE_BINAURAL) mode = IAMF_SOUND_MODE_NA;
+    else mode = IAMF_SOUND_MODE_MULTICHANNEL;
+  }
+  return mode;
+}
+
+/* IAMF_decoder.c:3619-3706 (what the metadata holds), :4150-4168 (the call).  Everything handed out is the caller's to
+ * free: loudness_layout, loudness, param — and every loudness[i].anchor_loudness.  (The reference hands out ITS OWN
+ * anchor arrays through two shallow copies, :3644-3645 and :3688, and its player frees loudness[0]'s,
+ * iamfplayer.c:309-321 — a double free there; a copy per call is the form of that contract that is safe to follow.) */
 int IAMF_decoder_get_last_metadata(IAMF_DecoderHandle d, int64_t *pts, IAMF_extradata *m) {
-  if (!d || !pts || !m || !d->configured) return IAMF_ERR_BAD_ARG;
+  if (!d || !pts || !m) return IAMF_ERR_BAD_ARG;
   memset(m, 0, sizeof(*m));
-  *pts = d->pts + (int64_t)((double)(d->timestamp - d->frame_size) * d->pts_base / d->rate + 0.5);
-  m->output_sound_system = d->out_type == IAMF_LAYOUT_TYPE_BINAURAL ? SOUND_SYSTEM_INVALID : d->out_ss;
+  *pts = d->pts + time_transform((int64_t)(d->meta_duration - d->last_frame), (int)d->out_rate, (int)d->pts_base);
   m->number_of_samples = d->last_frame;
+  if (!d->configured || !d->sel) return IAMF_OK; /* an open handle: the zeroed context (observed on the reference) */
+  m->output_sound_system = d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION ? d->out_ss : SOUND_SYSTEM_INVALID;
   m->bitdepth = d->bit_depth;
-  m->sampling_rate = d->out_rate;
-  m->output_sound_mode = d->out_type == IAMF_LAYOUT_TYPE_BINAURAL ? IAMF_SOUND_MODE_BINAURAL
-                         : d->out_ss == SOUND_SYSTEM_A             ? IAMF_SOUND_MODE_STEREO
-                                                                   : IAMF_SOUND_MODE_MULTICHANNEL;
+  m->sampling_rate = 48000; /* OUTPUT_SAMPLERATE, whatever IAMF_decoder_set_sampling_rate chose (:3628) */
+  m->output_sound_mode = sound_mode_of(d);
   m->num_loudness_layouts = d->sel->nlayouts;
   if (d->sel->nlayouts) {
     m->loudness_layout = (IAMF_Layout *)calloc((size_t)d->sel->nlayouts, sizeof(IAMF_Layout));
     m->loudness = (IAMF_LoudnessInfo *)calloc((size_t)d->sel->nlayouts, sizeof(IAMF_LoudnessInfo));
     if (!m->loudness_layout || !m->loudness) return IAMF_ERR_ALLOC_FAIL;
     for (int i = 0; i < d->sel->nlayouts; ++i) {
-      m->loudness_layout[i].sound_system.type = (uint8_t)d->sel->layout_type[i];
-      m->loudness_layout[i].sound_system.sound_system = (uint8_t)d->sel->layout_ss[i];
+      m->loudness_layout[i].type = (uint8_t)d->sel->layout_type[i]; /* iamf_layout_copy2, :324-331 */
+      if (d->sel->layout_type[i] == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION)
+        m->loudness_layout[i].sound_system.sound_system = (IAMF_SoundSystem)d->sel->layout_ss[i];
       m->loudness[i] = d->sel->loud[i];
       m->loudness[i].anchor_loudness = 0;
-      m->loudness[i].num_anchor_loudness = 0;
+      if (d->sel->loud[i].num_anchor_loudness) {
+        const size_t n = d->sel->loud[i].num_anchor_loudness;
+        m->loudness[i].anchor_loudness = (anchor_loudness_t *)calloc(n, sizeof(anchor_loudness_t));
+        if (!m->loudness[i].anchor_loudness) return IAMF_ERR_ALLOC_FAIL;
+        memcpy(m->loudness[i].anchor_loudness, d->sel->anchors[i], n * sizeof(anchor_loudness_t));
+      }
     }
   }
-  if (d->use_dmx) {
-    m->num_parameters = 1;
-    m->param = (IAMF_Param *)calloc(1, sizeof(IAMF_Param));
-    if (!m->param) return IAMF_ERR_ALLOC_FAIL;
-    m->param->parameter_length = 8;
-    m->param->parameter_definition_type = IAMF_PARAMETER_TYPE_DEMIXING;
-    m->param->dmixp_mode = (uint32_t)d->dmx.mode;
-  }
+  for (int i = 0; i < d->sel->nel; ++i)
+    if (d->sel_el[i]->has_demix) { /* an element with demixing info: one DEMIXING record (:3647-3662) */
+      m->num_parameters = 1;
+      m->param = (IAMF_Param *)calloc(1, sizeof(IAMF_Param));
+      if (!m->param) return IAMF_ERR_ALLOC_FAIL;
+      m->param->parameter_length = 8;
+      m->param->parameter_definition_type = IAMF_PARAMETER_TYPE_DEMIXING;
+      m->param->dmixp_mode = d->meta_dmixp;
+      break;
+    }
   return IAMF_OK;
 }
 

@@ -47,3 +47,21 @@ def generate(ref, manifest, gold_dir, synth):
         manifest["e2e/" + name] = {k: v for k, v in case.items() if k != "builder"}
         print("  e2e %-28s -> %s, calls %s..." % (name, pcm.shape, rets[:3]))
     np.savez_compressed(os.path.join(gold_dir, "e2e.npz"), **out)
+    generate_meta(ref, manifest, gold_dir)
+
+
+def generate_meta(ref, manifest, gold_dir):
+    """IAMF_decoder_get_last_metadata of the reference (IAMF_decoder.c:3619-3706,4150-4168) while it decodes: one row
+    after configure, one per delivered frame, one per flush call (decoder_driver.last_metadata)"""
+    out = {}
+    for name, mc in e2e_cases.META_CASES.items():
+        case = e2e_cases.CASES[name]
+        stream, _ = e2e_cases.build(name)
+        md = dict(rows=[], owns_anchors=False, **{k: v for k, v in mc.items() if k != "pts"})
+        ref_decode(ref, stream, case["layout"], bit_depth=case.get("bit_depth", 16), out_rate=case.get("out_rate", 0),
+                   loudness=case.get("loudness", 0.0), limiter=case.get("limiter", True), threshold=case.get("threshold", -1.0),
+                   metadata=md, pts=mc["pts"])
+        out[name] = np.array(md["rows"], dtype=np.int64)
+        manifest["meta/" + name] = dict(rows=len(md["rows"]), **{k: list(v) if isinstance(v, tuple) else v for k, v in mc.items()})
+        print("  meta %-28s -> %s" % (name, out[name].shape))
+    np.savez_compressed(os.path.join(gold_dir, "meta.npz"), **out)

@@ -5,8 +5,63 @@ import ctypes as C
 import numpy as np
 
 
+class _Anchor(C.Structure):
+    _fields_ = [("anchor_element", C.c_uint8), ("anchored_loudness", C.c_int16)]
+
+
+class _Loudness(C.Structure):
+    _fields_ = [("info_type", C.c_uint8), ("integrated_loudness", C.c_int16), ("digital_peak", C.c_int16),
+                ("true_peak", C.c_int16), ("num_anchor_loudness", C.c_uint8), ("anchor_loudness", C.POINTER(_Anchor))]
+
+
+class _Param(C.Structure):
+    _fields_ = [("parameter_length", C.c_int), ("parameter_definition_type", C.c_uint32), ("dmixp_mode", C.c_uint32)]
+
+
+class _Extradata(C.Structure):   # IAMF_extradata, include/IAMF_decoder.h:222-235
+    _fields_ = [("output_sound_system", C.c_int), ("number_of_samples", C.c_uint32), ("bitdepth", C.c_uint32),
+                ("sampling_rate", C.c_uint32), ("output_sound_mode", C.c_int), ("num_loudness_layouts", C.c_int),
+                ("loudness_layout", C.POINTER(C.c_uint8)), ("loudness", C.POINTER(_Loudness)),
+                ("num_parameters", C.c_uint32), ("param", C.POINTER(_Param))]
+
+
+META_COLUMNS = 64
+
+
+def last_metadata(ref, d, owns_anchors):
+    """IAMF_decoder_get_last_metadata -> one row of int64 (fixed width, -9999 padded): pts, sound system, samples, bit depth,
+    rate, sound mode, layouts, then per layout (layout byte: type << 6 | sound system << 2, info type, integrated, peak,
+    true peak, anchors, then (element, loudness) per anchor), then parameters, then (length, type, demixing mode) per
+    parameter.  Frees what the call hands out the way the reference's contract says (IAMF_decoder.c:3668-3706; the
+    reference itself lends its anchor arrays, this library copies them: owns_anchors)."""
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    ref.IAMF_decoder_get_last_metadata.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(_Extradata)]
+    pts, m = C.c_int64(-1), _Extradata()
+    rc = ref.IAMF_decoder_get_last_metadata(d, C.byref(pts), C.byref(m))
+    assert rc == 0, rc
+    row = [pts.value, m.output_sound_system, m.number_of_samples, m.bitdepth, m.sampling_rate, m.output_sound_mode,
+           m.num_loudness_layouts]
+    for i in range(m.num_loudness_layouts):
+        lo = m.loudness[i]
+        row += [m.loudness_layout[i], lo.info_type, lo.integrated_loudness, lo.digital_peak,
+                lo.true_peak if lo.info_type & 1 else 0, lo.num_anchor_loudness]
+        for k in range(lo.num_anchor_loudness):
+            row += [lo.anchor_loudness[k].anchor_element, lo.anchor_loudness[k].anchored_loudness]
+        if owns_anchors and lo.num_anchor_loudness:
+            libc.free(C.cast(lo.anchor_loudness, C.c_void_p))
+    row.append(m.num_parameters)
+    for i in range(m.num_parameters):
+        row += [m.param[i].parameter_length, m.param[i].parameter_definition_type, m.param[i].dmixp_mode]
+    for ptr in (m.loudness_layout, m.loudness, m.param):
+        if ptr:
+            libc.free(C.cast(ptr, C.c_void_p))
+    assert len(row) <= META_COLUMNS
+    return row + [-9999] * (META_COLUMNS - len(row))
+
+
 def decode_stream(ref, stream_bytes, layout, bit_depth=16, out_rate=0, loudness=0.0, limiter=True,
-               threshold=-1.0, pcm_channels=None):
+               threshold=-1.0, pcm_channels=None, metadata=None, pts=(0, 90000)):
     # pcm_channels: channel stride of the PCM the decoder writes (a -DSAMSUNG_TV build: always 12)
     """layout: ('ss', IAMF_SoundSystem enum value) or ('binaural',). Returns (pcm ndarray
     [n][ch] (24-bit: [n][ch][3] bytes), list of per-call return values)."""
@@ -42,10 +97,14 @@ def decode_stream(ref, stream_bytes, layout, bit_depth=16, out_rate=0, loudness=
     ch_layout = ch
     if pcm_channels:
         ch = pcm_channels
-    ref.IAMF_decoder_set_pts(d, 0, 90000)
+    # metadata: dict(rows=[], owns_anchors=bool) — a row (last_metadata) after configure and after every decode call
+    # that delivered a frame or flushed
+    ref.IAMF_decoder_set_pts(d, pts[0], pts[1])
     rsize = C.c_uint32(0)
     r = ref.IAMF_decoder_configure(d, stream_bytes, len(stream_bytes), C.byref(rsize))
     assert r == 0, "configure failed: %d" % r
+    if metadata is not None:
+        metadata["rows"].append(last_metadata(ref, d, metadata["owns_anchors"]))
     used = rsize.value
     bps = bit_depth // 8
     pcm = C.create_string_buffer(bps * 6144 * 6 * max(ch, ch_layout))
@@ -67,6 +126,10 @@ def decode_stream(ref, stream_bytes, layout, bit_depth=16, out_rate=0, loudness=
         if n > 0:
             chunks.append(pcm.raw[:n * ch * bps])
             rets.append(n)
+            if metadata is not None:
+                metadata["rows"].append(last_metadata(ref, d, metadata["owns_anchors"]))
+                if metadata.get("set_pts_after") == len(rets):   # the caller re-bases its clock mid-stream
+                    ref.IAMF_decoder_set_pts(d, *metadata["set_pts_to"])
         used += rsize.value
         if not rsize.value:
             break
@@ -75,6 +138,15 @@ def decode_stream(ref, stream_bytes, layout, bit_depth=16, out_rate=0, loudness=
     if n > 0:
         chunks.append(pcm.raw[:n * ch * bps])
     rets.append(n)
+    if metadata is not None:
+        metadata["rows"].append(last_metadata(ref, d, metadata["owns_anchors"]))
+        if not out_rate:   # a second flush: another 240 sample-frames of zeros (not mirrored behind a resampler)
+            rsize.value = 0
+            n = ref.IAMF_decoder_decode(d, None, 0, C.byref(rsize), pcm)
+            rets.append(n)
+            if n > 0:
+                assert not any(pcm.raw[:n * ch * bps]), "a second flush hands out zeros"
+            metadata["rows"].append(last_metadata(ref, d, metadata["owns_anchors"]))
     ref.IAMF_decoder_close(d)
     raw = np.frombuffer(b"".join(chunks), dtype=np.uint8)
     if bit_depth == 16:

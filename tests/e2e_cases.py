@@ -135,6 +135,30 @@ CASES = {
     # 3.1.2 output: no layer matches -> 5.1.2 is decoded and demixed, then the parametric down-mixer
     # renders 5.1.2 -> 3.1.2 with the same demixing modes
     "scalable_312_dmx_s16": dict(layout=("ss", 11), bit_depth=16, frames=8, fs=1024, seed=56, scalable=True),
+    # ---- round 4: presentations of TWO elements where one of them needs the per-stream stage the batch has
+    # only once — the demixer of a scalable / output-gained element (IAMF_decoder.c:2351-2386), the parametric down-mixer
+    # (:2448-2478), the projection de-mapping (IAMF_core_decoder.c:116-130) — in either position, mixed at :2702-2733
+    "stereo_plus_scalable_J": dict(layout=_ss_layout("J"), bit_depth=16, frames=8, fs=1024, seed=201,
+                                   pair=("stereo", "scalable"), element_gain_q78=-512, element2_gain_q78=-256),
+    "scalable_plus_stereo_A": dict(layout=_ss_layout("A"), bit_depth=16, frames=8, fs=1024, seed=202,
+                                   pair=("scalable", "stereo"), element_gain_q78=-300, element2_gain_q78=-700),
+    "stereo_plus_scalable_C": dict(layout=_ss_layout("C"), bit_depth=24, frames=8, fs=1024, seed=203,
+                                   pair=("stereo", "scalable"), element2_gain_q78=-384),
+    "l714dmx_plus_stereo_C": dict(layout=_ss_layout("C"), bit_depth=16, frames=8, fs=1024, seed=204,
+                                  pair=("l714dmx", "stereo"), element_gain_q78=-256, element2_gain_q78=-512,
+                                  dmx_modes=[1, 1, 2, 4, 5, 6, 0, 0]),
+    "stereo_plus_l714dmx_C": dict(layout=_ss_layout("C"), bit_depth=16, frames=8, fs=1024, seed=205,
+                                  pair=("stereo", "l714dmx"), element_gain_q78=-512, element2_gain_q78=-256,
+                                  dmx_modes=[2, 4, 5, 6, 0, 0, 1, 1]),
+    "stereo_plus_l714dmx_312": dict(layout=("ss", 11), bit_depth=16, frames=8, fs=1024, seed=206,
+                                    pair=("stereo", "l714dmx"), element2_gain_q78=-200, dmx_modes=[0, 1, 2, 4, 5, 6, 2, 1]),
+    "stereo_plus_projection_B": dict(layout=_ss_layout("B"), bit_depth=16, frames=6, fs=1024, seed=207,
+                                     pair=("stereo", "toa_projection"), element_gain_q78=-256, element2_gain_q78=-400),
+    "l51_plus_projection_binaural": dict(layout=("binaural",), bit_depth=32, frames=6, fs=1024, seed=208,
+                                         pair=("l51", "toa_projection"), element2_gain_q78=-300),
+    # a presentation that says more about itself (two layouts, true peak, anchored loudness): what
+    # IAMF_decoder_get_last_metadata hands out (IAMF_decoder.c:3619-3706)
+    "stereo_loudness_info": dict(layout=_ss_layout("A"), bit_depth=16, frames=4, fs=1024, seed=209, loudness_infos=True),
 }
 
 SCALABLE_LAYERS = [1, 3, 7]
@@ -165,6 +189,81 @@ def _toa_element(eid, x, first_sid, sample_size):
     return desc, xq
 
 
+# ---- one element of a two-element presentation: descriptor, per-frame (parameter blocks, sub-streams), what the renderer sees ----
+def _pair_element(kind, eid, sid0, pid0, seed, n, fs, ss, rate, c):
+    """returns (descriptor obus, frame -> (parameter block obus, [(sub-stream id, bytes)]), info element, sub-streams used)"""
+    if kind in ("stereo", "l51"):
+        lay = 1 if kind == "stereo" else 2
+        x = np.clip(synth.hot(seed, W.LAYOUT_CHANNELS[lay], n, sigma=0.18, burst_amp=0.5, burst_phase=350, burst_period=3100),
+                    -1, 1 - 2 ** -15).astype(np.float32)
+        desc, x_al, xq = _channel_element(eid, lay, x, sid0, ss)
+        return (desc, lambda f: (b"", W.channel_element_substreams(lay, x_al[:, f * fs:(f + 1) * fs], sid0, ss)),
+                dict(kind="channel", layout=lay, x=xq), W.LAYOUT_SUBSTREAMS[lay][0])
+    if kind == "l714dmx":
+        x = np.clip(synth.hot(seed, 12, n, sigma=0.18, burst_amp=0.5, burst_phase=500, burst_period=3000),
+                    -1, 1 - 2 ** -15).astype(np.float32)
+        xq = W.quantize(x, ss)
+        x_al = np.empty_like(xq)
+        for p_, a_ in enumerate(al_index_of_playback(7)):
+            x_al[a_] = xq[p_]
+        desc = W.audio_element_channel(eid, 0, 7, list(range(sid0, sid0 + 7)),
+                                       demixing=dict(pid=pid0, rate=rate, frame=fs, mode=1, w=3))
+        return (desc, lambda f: (W.demixing_block(pid0, c["dmx_modes"][f]),
+                                 W.channel_element_substreams(7, x_al[:, f * fs:(f + 1) * fs], sid0, ss)),
+                dict(kind="channel", layout=7, x=xq), 7)
+    if kind == "scalable":
+        import demix_cases as D
+        layers = SCALABLE_LAYERS
+        order, per_layer = D.channels_order(layers)
+        xd = W.quantize(synth.hot(seed, len(order), n, sigma=0.13, burst_amp=0.4, burst_phase=600,
+                                  burst_period=2700).clip(-1, 1 - 2 ** -15).astype(np.float32), ss)
+        wl = []
+        for li, (lay, pl) in enumerate(zip(layers, per_layer)):
+            rf = D.recon_flags(layers[0], lay) if li else 0
+            wl.append(dict(layout=lay, nsub=pl["substreams"], ncoupled=pl["coupled"],
+                           out_gain=SCALABLE_GAINS.get(li), recon=bool(rf), recon_flags=rf))
+        nsub = sum(l["nsub"] for l in wl)
+        desc = W.audio_element_scalable(eid, 0, wl, list(range(sid0, sid0 + nsub)),
+                                        demixing=dict(pid=pid0, rate=rate, frame=fs, mode=1, w=3),
+                                        recon=dict(pid=pid0 + 1, rate=rate, frame=fs))
+
+        def frame(f):
+            blocks = W.demixing_block(pid0, SCALABLE_MODES[f])
+            blocks += W.recon_gain_block(pid0 + 1, [(l["recon_flags"], scalable_recon_bytes(f, bin(l["recon_flags"]).count("1")))
+                                                    for l in wl if l["recon"]])
+            subs, ch, sid = [], 0, sid0
+            for l in wl:
+                for k in range(l["nsub"]):
+                    w = 2 if k < l["ncoupled"] else 1
+                    subs.append((sid, W.lpcm_bytes(xd[ch:ch + w, f * fs:(f + 1) * fs], ss)))
+                    ch += w
+                    sid += 1
+            return blocks, subs
+        return desc, frame, dict(kind="scalable", layers=layers, order=order, x=xd, wl=wl, gains=SCALABLE_GAINS), nsub
+    if kind == "toa_projection":
+        subs_n, coupled = 10, 6
+        rng = np.random.default_rng(seed)
+        pq = rng.integers(-9000, 9000, size=(subs_n + coupled, 16)).astype(np.int16)
+        pq[np.arange(16), np.arange(16)] = 29000
+        xd = W.quantize(synth.hot(seed, 16, n, sigma=0.1, burst_amp=0.4, burst_phase=700, burst_period=2500)
+                        .clip(-1, 1 - 2 ** -15).astype(np.float32), ss)
+        desc = W.audio_element_ambisonics_projection(eid, 0, 16, list(range(sid0, sid0 + subs_n)), coupled, pq)
+        pf = pq.astype(np.float32) * np.float32(2.0 ** -15)
+        xa = np.zeros((16, n), np.float32)
+        for l in range(subs_n + coupled):
+            xa = (xa + (xd[l][None, :] * pf[l][:, None]).astype(np.float32)).astype(np.float32)
+
+        def frame(f):
+            subs, ch = [], 0
+            for i in range(subs_n):
+                w = 2 if i < coupled else 1
+                subs.append((sid0 + i, W.lpcm_bytes(xd[ch:ch + w, f * fs:(f + 1) * fs], ss)))
+                ch += w
+            return b"", subs
+        return desc, frame, dict(kind="scene", order=3, x=xa), subs_n
+    raise KeyError(kind)
+
+
 def build(name):
     c = CASES[name]
     if c.get("concat"):   # several IA sequences back to back: the decoder must be reconfigured at each header
@@ -185,6 +284,34 @@ def build(name):
     def frames_of(subs_fn):
         return subs_fn
 
+    if c.get("pair"):
+        ka, kb = c["pair"]
+        da, fa, ia, na = _pair_element(ka, 1, 0, 200, c["seed"], n, fs, ss, rate, c)
+        db, fb, ib, nb = _pair_element(kb, 2, na, 210, c["seed"] + 1, n, fs, ss, rate, c)
+        stream += da + db
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100, rate), default_q78=eg),
+                                         dict(eid=2, pdef=_pdef_static(102, rate), default_q78=c.get("element2_gain_q78", 0))],
+                                     dict(pdef=_pdef_static(101, rate), default_q78=og), layouts_field)
+        info["elements"] += [ia, ib]
+        for f in range(F):
+            ba, sa = fa(f)
+            bb, sb = fb(f)
+            stream += W.temporal_delimiter() + ba + bb + W.audio_frames(sa + sb)
+        return stream, info
+    if name == "stereo_loudness_info":
+        x = synth.uniform(c["seed"], 2, n, 0.7)
+        desc, x_al, xq = _channel_element(1, 1, x, 0, ss)
+        stream += desc
+        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100, rate), default_q78=eg)],
+                                     dict(pdef=_pdef_static(101, rate), default_q78=og), [("ss", 0), ("binaural",), ("ss", 9)],
+                                     loudness_infos=[dict(integrated=-6144, peak=-512, true_peak=-300, anchors=[(1, -5888), (2, -6400)]),
+                                                     dict(integrated=-5632, peak=-256),
+                                                     dict(integrated=-6400, peak=-700, anchors=[(0, -6100)])])
+        info["elements"].append(dict(kind="channel", layout=1, x=xq))
+        for f in range(F):
+            stream += W.temporal_delimiter()
+            stream += W.audio_frames(W.channel_element_substreams(1, x_al[:, f * fs:(f + 1) * fs], 0, ss))
+        return stream, info
     if name in ("stereo_A_s16", "stereo_441_to_48k", "stereo_trim", "stereo_fs128", "stereo_fs2048", "stereo_96k_to_48k",
                 "stereo_32k_to_48k", "stereo_16k_to_48k", "stereo_48k_to_441"):
         x = synth.uniform(c["seed"], 2, n, 0.9)
@@ -376,3 +503,26 @@ def build(name):
     else:
         raise KeyError(name)
     return stream, info
+
+
+# What IAMF_decoder_get_last_metadata reports while these streams decode (tests/golden/meta.npz, rows by
+# decoder_driver.last_metadata from the REAL reference): pts arithmetic with another time base and a start offset, a
+# re-based clock mid-stream, trims, the resampler's rates, binaural / multichannel / mixed sound modes, loudness records
+# with true peak and anchors, the DEMIXING record and its mode per frame.
+META_CASES = {
+    "stereo_A_s16": dict(pts=(0, 90000)),
+    "stereo_loudness_info": dict(pts=(123456, 44100), set_pts_after=2, set_pts_to=(777, 1000)),
+    "stereo_trim": dict(pts=(1000, 90000)),
+    "stereo_441_to_48k": dict(pts=(5, 90000)),
+    "stereo_48k_to_441": dict(pts=(0, 48000)),
+    "toa_binaural_s16": dict(pts=(0, 90000)),
+    "two_elements_A_s32": dict(pts=(0, 1000)),
+    "l714_C_dmx": dict(pts=(0, 90000)),
+    "scalable_A_s16": dict(pts=(0, 90000)),
+    "scalable_J_s16": dict(pts=(0, 90000)),
+    "stereo_plus_scalable_J": dict(pts=(0, 90000)),
+    "stereo_plus_l714dmx_C": dict(pts=(0, 90000)),
+    "l714dmx_plus_stereo_C": dict(pts=(0, 90000)),
+    "l51_plus_projection_binaural": dict(pts=(0, 90000)),
+    "stereo_fs128": dict(pts=(0, 90000)),
+}

@@ -79,7 +79,7 @@ def run_case(info):
     out_id = out_id_of(c["layout"])
     ch = O.OUT_CH[out_id]
     fs = c["fs"]
-    gains_q = [c.get("element_gain_q78", 0)] + [0] * (len(info["elements"]) - 1)
+    gains_q = [c.get("element_gain_q78", 0), c.get("element2_gain_q78", 0)][:len(info["elements"])]
     ys = []
     for el, gq in zip(info["elements"], gains_q):
         if el["kind"] == "scalable":

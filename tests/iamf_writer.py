@@ -108,9 +108,11 @@ def audio_element_ambisonics_projection(eid, cid, channels, substream_ids, coupl
     return obu(OBU_AUDIO_ELEMENT, p)
 
 
-def mix_presentation(mid, elements, output_gain, layouts, loudness_q78=0):
+def mix_presentation(mid, elements, output_gain, layouts, loudness_q78=0, loudness_infos=None):
     """elements: list of dict(eid, gain_pdef(bytes), default_gain_q78, headphones_mode);
-    output_gain: dict(pdef, default_q78); layouts: list of ('ss', n) / ('binaural',)"""
+    output_gain: dict(pdef, default_q78); layouts: list of ('ss', n) / ('binaural',);
+    loudness_infos: per layout dict(integrated, peak[, true_peak][, anchors=[(element, q78), ...]]) — loudness_info()
+    with info_type bit 0 (true peak) / bit 1 (anchored loudness), IAMF_OBU.c:869-913"""
     p = leb128(mid) + leb128(0)         # no labels
     p += leb128(1)                      # one sub-mix
     p += leb128(len(elements))
@@ -126,7 +128,18 @@ def mix_presentation(mid, elements, output_gain, layouts, loudness_q78=0):
             p += bytes([(2 << 6) | (lay[1] << 2)])
         else:
             p += bytes([3 << 6])
-        p += bytes([0]) + struct.pack(">hh", loudness_q78, 0)  # info_type 0, loudness, digital peak
+        li = loudness_infos[layouts.index(lay)] if loudness_infos else None
+        if li is None:
+            p += bytes([0]) + struct.pack(">hh", loudness_q78, 0)  # info_type 0, loudness, digital peak
+        else:
+            it = (1 if "true_peak" in li else 0) | (2 if "anchors" in li else 0)
+            p += bytes([it]) + struct.pack(">hh", li["integrated"], li["peak"])
+            if it & 1:
+                p += struct.pack(">h", li["true_peak"])
+            if it & 2:
+                p += bytes([len(li["anchors"])])
+                for el, q in li["anchors"]:
+                    p += bytes([el]) + struct.pack(">h", q)
     return obu(OBU_MIX_PRESENTATION, p)
 
 

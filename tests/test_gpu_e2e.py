@@ -20,7 +20,7 @@ def hip():
 
 
 SINGLE = [n for n, c in sorted(e2e_cases.CASES.items()) if n != "two_elements_A_s32" and
-          not (c.get("ramps") or c.get("concat") or c.get("dmx_modes") or c.get("out_rate") or c.get("trims") or c.get("scalable"))]
+          not (c.get("ramps") or c.get("concat") or c.get("dmx_modes") or c.get("out_rate") or c.get("trims") or c.get("scalable") or c.get("pair"))]
 
 
 @pytest.mark.parametrize("name", SINGLE)

@@ -49,6 +49,48 @@ def test_facade_host_unpack_form_of_the_fused_streams(lib, golden, name, monkeyp
     assert pcm.shape == want.shape and np.array_equal(pcm, want), name
 
 
+@pytest.mark.parametrize("name", sorted(e2e_cases.META_CASES))
+def test_get_last_metadata_matches_the_reference(lib, golden, name):
+    """IAMF_decoder_get_last_metadata, one of the 19 boundary functions, had no test.  Rows recorded from
+    the REAL reference (oracle/gen_golden_extra.py: generate_meta) after configure, after every delivered frame and after
+    each of two flush calls: pts (another time base, a start offset, a clock re-based mid-stream, trims, the resampler's
+    rates: IAMF_decoder.c:3410-3415,3521-3522,4150-4160), sound system and sound mode (:241-254,1555-1578), the
+    presentation's loudness records incl. true peak and anchored loudness (:3632-3645), the DEMIXING record and the mode
+    each frame used (:3436-3442,3647-3662).  The PCM of the same run is checked once more on the way."""
+    case, mc = e2e_cases.CASES[name], e2e_cases.META_CASES[name]
+    stream, _ = e2e_cases.build(name)
+    md = dict(rows=[], owns_anchors=True, **{k: v for k, v in mc.items() if k != "pts"})
+    pcm, rets = decode_stream(lib, stream, case["layout"], bit_depth=case.get("bit_depth", 16), out_rate=case.get("out_rate", 0),
+                              loudness=case.get("loudness", 0.0), limiter=case.get("limiter", True),
+                              threshold=case.get("threshold", -1.0), metadata=md, pts=mc["pts"])
+    want = golden.npz("meta")[name]
+    got = np.array(md["rows"], dtype=np.int64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g, w), (name, "row %d" % i, [int(v) for v in g if v != -9999], [int(v) for v in w if v != -9999])
+    assert np.array_equal(pcm, golden.npz("e2e")[name])
+
+
+def test_metadata_before_configure_and_bad_arguments(lib):
+    from decoder_driver import _Extradata
+    lib.IAMF_decoder_open.restype = C.c_void_p
+    lib.IAMF_decoder_close.argtypes = [C.c_void_p]
+    lib.IAMF_decoder_get_last_metadata.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(_Extradata)]
+    d = lib.IAMF_decoder_open()
+    pts, m = C.c_int64(-1), _Extradata()
+    assert lib.IAMF_decoder_get_last_metadata(d, None, C.byref(m)) == -1
+    assert lib.IAMF_decoder_get_last_metadata(d, C.byref(pts), None) == -1
+    assert lib.IAMF_decoder_get_last_metadata(None, C.byref(pts), C.byref(m)) == -1
+    # an open handle that has not been configured: the zeroed context, nothing to free (what the reference returns:
+    # [0, 0, 0, 0, 0, 0, 0, 0] through decoder_driver.last_metadata, and the pts of IAMF_decoder_set_pts alone)
+    assert lib.IAMF_decoder_get_last_metadata(d, C.byref(pts), C.byref(m)) == 0
+    assert (pts.value, m.output_sound_system, m.output_sound_mode, m.num_loudness_layouts, m.num_parameters) == (0, 0, 0, 0, 0)
+    lib.IAMF_decoder_set_pts.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
+    lib.IAMF_decoder_set_pts(d, 55, 1000)
+    assert lib.IAMF_decoder_get_last_metadata(d, C.byref(pts), C.byref(m)) == 0 and pts.value == 55
+    lib.IAMF_decoder_close(d)
+
+
 def test_facade_api_surface(lib):
     lib.IAMF_decoder_open.restype = C.c_void_p
     lib.IAMF_decoder_close.argtypes = [C.c_void_p]
