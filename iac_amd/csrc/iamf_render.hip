@@ -416,6 +416,11 @@ bool fast_path_ok(const RenderParams &p, bool down_mixer = false) {
   if ((p.pos0 & 15) || (p.total & 63) || (p.frame_size & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
+  {  // the kernel addresses a stream's input of one call with 32-bit byte offsets (buffer loads, render_fast.hpp)
+    const int64_t frames = (int64_t)p.total / p.frame_size + 2;
+    if (frames * p.in_frame_stride * 4 + 100 * (int64_t)p.frame_size >= (int64_t)1 << 31) return false;
+    if (p.lpcm && frames * p.lpcm_frame_stride + ((int64_t)1 << 24) >= (int64_t)1 << 31) return false;
+  }
   return true;
 }
 

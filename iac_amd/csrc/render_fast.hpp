@@ -181,7 +181,7 @@ __host__ __device__ constexpr int fast_lds_floats(int oc, int m, int fir = 0) {
   // The MFMA HRTF variants read the table from global memory; the FFT one (fir == 3) stages the window like the
   // matrix variant: a hot programme walks the limiter chain in most chunks, and every table look-up of the walk
   // was an L2 round trip.
-  return oc * kFRing + 2 * kFRing + kFRing / 16 + 2 * kFChunk + ((fir && fir != 3) ? 0 : 2 * kFWin) + ((oc * m + 15) & ~15) + 16 +
+  return oc * kFRing + 2 * kFRing + 2 * (kFRing / 16) + 2 * kFChunk + ((fir && fir != 3) ? 0 : 2 * kFWin) + ((oc * m + 15) & ~15) + 16 +
          (fir == 3 ? kFftLdsFloats : (fir == 2 ? kF16LdsFloats : (fir ? kFirLdsFloats : 16 /* second element's matrix rows */)));
 }
 
@@ -206,7 +206,11 @@ constexpr int kFIn2 = 4;
 // LP:   element 0 arrives as 16-bit little-endian LPCM packets (RenderParams::lpcm) instead of planar f32: the
 //       reference's LPCM "decoder" (pcm/IAMF_pcm_decoder.c:64-83: sample / 32768.f) runs where the samples are loaded,
 //       8 bytes per lane and channel instead of 16, and the f32 copy of the element never exists in HBM.
-template <int M, int OC, int FIR = 0, bool DOWN = false, bool IN2 = false, bool LP = false>
+// EARLY: (plain matrix variants) channel m of the NEXT chunk is requested as soon as channel m of this one has been
+//       consumed by the projection, instead of all channels behind the projection.  Longer in flight: what a launch
+//       of few workgroups per CU waits for (512 streams: f32 +4 %, LPCM +8 %); a launch that fills every wave slot is
+//       bound by its instruction stream and loses to the per-channel issue (LPCM, 4096 streams: -6 %) — the host picks.
+template <int M, int OC, int FIR = 0, bool DOWN = false, bool IN2 = false, bool LP = false, bool EARLY = true>
 __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <= 16 && !IN2)) ? 4 : 2)) void render_fast_kernel(const RenderParams p) {
   static_assert(!(FIR && DOWN), "one renderer");
   static_assert(!(LP && (FIR || DOWN || IN2)) && (!LP || M <= 16), "the LPCM input feeds the plain matrix variant");
@@ -218,12 +222,16 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
   float *ring_y = lds;                  // [OC][R]   rendered samples (limiter delay line)
   float *ring_pm = ring_y + OC * R;     // [R]       max |y| over channels
   float *ring_suf = ring_pm + R;        // [R]       suffix maxima of pm inside aligned 16-blocks
-  float *ring_bm = ring_suf + R;        // [R/16]    maxima of aligned 16-blocks
-  float *arr_p = ring_bm + NB;          // [1024]    window maxima of the chunk
+  float *ring_bm = ring_suf + R;        // [2][R/16] maxima of aligned 16-blocks, stored twice: entry b also at b + NB, so
+                                        //           that the 14 blocks before any block are 14 CONSECUTIVE words
+  float *arr_p = ring_bm + 2 * NB;      // [1024]    window maxima of the chunk
   float *arr_g = arr_p + kFChunk;       // [1024]    gains from the limiter wave
-  float *win = arr_g + kFChunk;         // [kFWin]   ctab[min(n_st + i, n_end)] (not in the HRTF variant)
+  float *win = arr_g + kFChunk;         // [kFWin]   ctab[min(n_st + 1 + i, n_end)] (not in the HRTF variant)
   float *head = win + kFWin;            // [kFWin]   ctab[i]                     (not in the HRTF variant)
   constexpr bool kTab = FIR == 0 || FIR == 3;   // the limiter-table window and head are staged in LDS
+  // the matrix variant reads its weights four input channels at a time (one 16-byte LDS read per output slot and group)
+  constexpr bool kWG = !FIR && !DOWN && (M % 4) == 0;
+  constexpr bool kEarly = EARLY && !FIR && !DOWN && !IN2;
   float *mat = win + (kTab ? 2 * kFWin : 0);  // [OC*M]  feed-major matrix rows of the OC slots
   float *misc = mat + ((OC * M + 15) & ~15);  // [16]
   float *mat2 = misc + 16;              // [OC][kFIn2]  second element's matrix rows (IN2 only; aliases fir)
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
     // __shfl_down hands back the caller's own value past the end of the 16-lane segment, which
     // leaves the running maximum unchanged
     ring_suf[rp] = sfx;
-    if ((t & 15) == 0) ring_bm[rp >> 4] = sfx;
+    if ((t & 15) == 0) ring_bm[rp >> 4] = ring_bm[(rp >> 4) + NB] = sfx;
     if constexpr (kTab)
       for (int i = t; i < kFWin; i += 256) head[i] = p.ctab[i < n_end ? i : n_end];
     if (!FIR && !DOWN && t < OC * M) {
@@ -330,22 +338,50 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
   using lp_u2 = __attribute__((ext_vector_type(2))) unsigned;
   lp_u2 xr[LP ? M : 1];
   const uint8_t *lp_s = LP ? p.lpcm + (int64_t)s * p.lpcm_stream_stride : nullptr;
-  auto load_lp = [&](int f, int i) {
-    if constexpr (LP) {
-      const uint8_t *src = lp_s + (int64_t)f * p.lpcm_frame_stride + 2 * i;
-#pragma unroll
-      for (int m = 0; m < M; ++m) xr[m] = __builtin_nontemporal_load(reinterpret_cast<const lp_u2 *>(src + p.lpcm_off[m]));
+  // The element's input goes through BUFFER loads: one resource per stream (base = the stream's region), the lane's byte
+  // offset in one register for all channels, the channel's offset as the instruction's scalar offset — no address
+  // arithmetic per load (a 64-bit pointer per channel cost an add each and, for the packets' sixteen run offsets, sixteen
+  // scalar register pairs that did not fit).  Offsets are 32-bit: the host sends longer calls elsewhere (fast_path_ok).
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(LP ? static_cast<const void *>(lp_s) : static_cast<const void *>(in_s)), 0, 0x7fffffff, 0x00020000);
+  // Frames that are whole chunks (frame size a multiple of 1024 — the usual 1024): a chunk lies in ONE frame, its frame
+  // number and position are workgroup-uniform counters; otherwise each lane divides.
+  const bool fr_uni = (fs & (kFChunk - 1)) == 0;
+  int fu = 0, iu = 0;   // frame / position of the first sample of the chunk the next prefetch fetches (fr_uni)
+  auto frame_pos = [&](int kq, int &f, int &i) {
+    if (fr_uni) {
+      f = fu;
+      i = iu + 4 * t;
+    } else {
+      f = kq / fs;
+      i = kq - f * fs;
     }
   };
-  auto convert_lp = [&]() {
+  // (a resource of zero records: every load through it is out of range — answered with zeros, no memory access.  The
+  //  projection's requests for "the next chunk" go through it when there is none, instead of through a branch per channel)
+  const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(LP ? static_cast<const void *>(lp_s) : static_cast<const void *>(in_s)), 0, 0, 0x00020000);
+  auto load_lp_one = [&](int m, int f, int i, __amdgpu_buffer_rsrc_t rs) {
     if constexpr (LP) {
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        const unsigned a = xr[m].x, b = xr[m].y;
-        x[m] = make_float4((float)(int)(short)(a & 0xffffu) * (1.0f / 32768.0f), (float)((int)a >> 16) * (1.0f / 32768.0f),
-                           (float)(int)(short)(b & 0xffffu) * (1.0f / 32768.0f), (float)((int)b >> 16) * (1.0f / 32768.0f));
-      }
+      const int vo = f * (int)p.lpcm_frame_stride + 2 * i;
+      const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, p.lpcm_off[m], 2 /* nt */);
+      xr[m] = lp_u2{v[0], v[1]};
     }
+  };
+  auto load_f32_one = [&](int m, int f, int i, __amdgpu_buffer_rsrc_t rs) {
+    if constexpr (!LP && !FIR) {
+      const int vo = 4 * (f * (int)p.in_frame_stride + i);
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 4 * m * fs, 2 /* nt */);
+      x[m] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    }
+  };
+  auto load_lp = [&](int f, int i) {
+#pragma unroll
+    for (int m = 0; m < (LP ? M : 0); ++m) load_lp_one(m, f, i, rs_in);
+  };
+  auto load_f32 = [&](int f, int i) {
+#pragma unroll
+    for (int m = 0; m < ((!LP && !FIR) ? M : 0); ++m) load_f32_one(m, f, i, rs_in);
   };
   float drec[DOWN ? 11 : 1];  // DOWN: the frame record of the lane's samples, fetched with them
   const int dmx_nfr = DOWN ? (p.total + fs - 1) / fs : 0;
@@ -359,15 +395,10 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
   if constexpr (!FIR) {
     const int k = 4 * t;
     if (k < p.total) {
-      const int f = k / fs;
-      const int i = k - f * fs;
-      if constexpr (LP) {
-        load_lp(f, i);
-      } else {
-        const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
-#pragma unroll
-        for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
-      }
+      int f, i;
+      frame_pos(k, f, i);
+      load_lp(f, i);
+      load_f32(f, i);
       load_x2(f, i);
     } else {
 #pragma unroll
@@ -382,7 +413,9 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
   __syncthreads();
   const int cw = chain_wave_pick(misc + 12);
 
-  // Table window the next chunk can reach without a trigger: win[i] = ctab[min(n_st + i, n_end)].
+  // Table window the next chunk can reach without a trigger: win[i] = ctab[min(n_st + 1 + i, n_end)] — the value sample i
+  // of the chunk needs if nothing triggers before it (its step count n_st + i, the curve read one step on), so that a
+  // lane's four consecutive samples read four consecutive, 16-byte aligned words.
   // Fetched BEFORE the chunk's PCM stores are issued and written to LDS BEFORE the next input
   // prefetch is issued: vector-memory operations retire in order, so a wait for these values at
   // any later point would drain the stores / the prefetch as well.
@@ -391,7 +424,7 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
     if constexpr (kTab) {
 #pragma unroll
       for (int r = 0; r < 5; ++r) {
-        const int i = n0 + t + 256 * r;
+        const int i = n0 + 1 + t + 256 * r;
         wv[r] = 1.0f;
         if (n0 < n_end && t + 256 * r < kFWin) wv[r] = p.ctab[i < n_end ? i : n_end];
       }
@@ -406,10 +439,87 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
     const int64_t gk = p.pos0 + k;
     const int rp = ring_wrap(base + 4 * t);
 
+    // kEarly: the table window goes to LDS first (its loads are older than anything still in flight), then the place of
+    // the next chunk is worked out: the projection below requests it channel by channel
+    int pf_f = 0, pf_i = 0;
+    __amdgpu_buffer_rsrc_t rs_pf = rs_none;
+    if constexpr (kEarly) {
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+        if (t + 256 * r < kFWin) win[t + 256 * r] = wv[r];
+      const int kn = k + kFChunk;
+      iu += kFChunk;
+      if (iu >= fs) {
+        iu -= fs;
+        ++fu;
+      }
+      if (c0 + kFChunk < p.total) rs_pf = rs_in;   // workgroup-uniform: there is a next chunk
+      frame_pos(kn, pf_f, pf_i);
+      if (kn >= p.total) pf_f = pf_i = 0;   // a lane past the end of the call requests the stream's first samples (unused)
+    }
+
     // ---- element renderer + gains (reference operation order) ----
     float4 y[OC];
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
-    convert_lp();   // LP: the chunk's packets -> f32 (lanes past the end of the call keep what they hold: never used)
+    // The matrix variant's projection, input channel by input channel: every output slot still sums its products in
+    // ascending channel order (the reference's order), and an LPCM channel is converted where it is consumed — the 64
+    // registers of a converted element never exist beside the 32 of the packets (lanes past the end of the call
+    // convert what they hold: never used).
+    // (written on pairs of samples: two f32 products or sums per packed instruction, each rounded on its own)
+    using f2 = __attribute__((ext_vector_type(2))) float;
+    f2 prj[(!FIR && !DOWN) ? 2 * OC : 1];
+    if constexpr (!FIR && !DOWN) {
+#pragma unroll
+      for (int c = 0; c < 2 * OC; ++c) prj[c] = f2{0.f, 0.f};
+      float wg[OC][4];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        f2 xa, xb;
+        if constexpr (kWG) {
+          if ((m & 3) == 0) {
+#pragma unroll
+            for (int c = 0; c < OC; ++c) {
+              const float4 w4 = *reinterpret_cast<const float4 *>(&mat[c * M + m]);
+              wg[c][0] = w4.x, wg[c][1] = w4.y, wg[c][2] = w4.z, wg[c][3] = w4.w;
+            }
+          }
+        }
+        if constexpr (LP) {
+          // (the packets of channel m are "produced" here, after channel m - 1 has been added up: left to itself the
+          //  scheduler converts all sixteen channels first and spills what does not fit — 127 registers' worth)
+          if constexpr (OC == 2)
+            asm volatile("" : "+v"(xr[m].x), "+v"(xr[m].y), "+v"(prj[0]), "+v"(prj[1]), "+v"(prj[2]), "+v"(prj[3]));
+          else
+            asm volatile("" : "+v"(xr[m].x), "+v"(xr[m].y), "+v"(prj[0]), "+v"(prj[1]));
+          const unsigned a = xr[m].x, b = xr[m].y;
+          const f2 sc = {1.0f / 32768.0f, 1.0f / 32768.0f};
+          xa = f2{(float)(int)(short)(a & 0xffffu), (float)((int)a >> 16)} * sc;
+          xb = f2{(float)(int)(short)(b & 0xffffu), (float)((int)b >> 16)} * sc;
+        } else {
+          // (the same ordering for the f32 element: channel m is taken up when channel m - 1 has been added up, so that the
+          //  weights of one group of four channels are all that is live beside the samples)
+          if constexpr (OC == 2)
+            asm volatile("" : "+v"(x[m].x), "+v"(x[m].y), "+v"(x[m].z), "+v"(x[m].w), "+v"(prj[0]), "+v"(prj[1]), "+v"(prj[2]), "+v"(prj[3]));
+          else
+            asm volatile("" : "+v"(x[m].x), "+v"(x[m].y), "+v"(x[m].z), "+v"(x[m].w), "+v"(prj[0]), "+v"(prj[1]));
+          xa = f2{x[m].x, x[m].y};
+          xb = f2{x[m].z, x[m].w};
+        }
+#pragma unroll
+        for (int c = 0; c < OC; ++c) {
+          const float w = kWG ? wg[c][m & 3] : mat[c * M + m];
+          const f2 w2 = {w, w};
+          prj[2 * c] = prj[2 * c] + w2 * xa;
+          prj[2 * c + 1] = prj[2 * c + 1] + w2 * xb;
+        }
+        // channel m's registers are free: its samples of the NEXT chunk are requested now (kEarly), in flight under the
+        // rest of the projection and everything behind it
+        if constexpr (kEarly) {
+          if constexpr (LP) load_lp_one(m, pf_f, pf_i, rs_pf);
+          else load_f32_one(m, pf_f, pf_i, rs_pf);
+        }
+      }
+    }
     if constexpr (FIR == 2) {  // both ears of this chunk AND the next three -> LDS (one pass per four chunks)
       if (((c0 >> 10) & 3) == 0) fir_stage16<M>(p, in_s, fir_hist, c0, fir, fir);
     }
@@ -452,16 +562,7 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
       } else if constexpr (DOWN) {
         v = yd[c];
       } else if (live[c]) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int m = 0; m < (FIR ? 0 : M); ++m) {
-          const float w = mat[c * M + m];
-          acc.x = acc.x + w * x[m].x;
-          acc.y = acc.y + w * x[m].y;
-          acc.z = acc.z + w * x[m].z;
-          acc.w = acc.w + w * x[m].w;
-        }
-        v = acc;
+        if constexpr (!FIR && !DOWN) v = make_float4(prj[2 * c].x, prj[2 * c].y, prj[2 * c + 1].x, prj[2 * c + 1].y);
       }
       if constexpr (IN2) {
         // element gain, mixer (0 + y, then + y2), output and loudness gains in the reference's order;
@@ -513,21 +614,21 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
       for (int r = 0; r < 5; ++r)
         if (t + 256 * r < kFWin) win[t + 256 * r] = wv[r];
     }
-    if constexpr (!FIR) {
+    if constexpr (!FIR && !kEarly) {
 #pragma unroll
       for (int r = 0; r < 5; ++r)
         if (t + 256 * r < kFWin) win[t + 256 * r] = wv[r];
       const int kn = k + kFChunk;
+      iu += kFChunk;   // (fr_uni) the next chunk's place: one frame on when this one ended its frame
+      if (iu >= fs) {
+        iu -= fs;
+        ++fu;
+      }
       if (kn < p.total) {
-        const int f = kn / fs;
-        const int i = kn - f * fs;
-        if constexpr (LP) {
-          load_lp(f, i);
-        } else {
-          const float *src = in_s + (int64_t)f * p.in_frame_stride + i;
-#pragma unroll
-          for (int m = 0; m < M; ++m) x[m] = ld_stream4(src + (int64_t)m * fs);
-        }
+        int f, i;
+        frame_pos(kn, f, i);
+        load_lp(f, i);
+        load_f32(f, i);
         load_drec(f);
         load_x2(f, i);
       }
@@ -540,8 +641,9 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
       const float s3 = pm.w, s2 = fmaxf(pm.z, s3), s1 = fmaxf(pm.y, s2), s0 = fmaxf(pm.x, s1);
       const float qa = dpp_quad_bcast0(i3), qb = dpp_quad_bcast1(i3), qc = dpp_quad_bcast2(i3),
                   qd = dpp_quad_bcast3(i3);
-      const float before = q == 0 ? 0.f : (q == 1 ? qa : (q == 2 ? fmaxf(qa, qb) : fmaxf(fmaxf(qa, qb), qc)));
-      const float after = q == 3 ? 0.f : (q == 2 ? qd : (q == 1 ? fmaxf(qc, qd) : fmaxf(fmaxf(qb, qc), qd)));
+      // maxima of the quad's lanes before / after this one (all values are >= 0: 0 is the identity); selects, no branches
+      const float before = fmaxf(fmaxf(q >= 1 ? qa : 0.f, q >= 2 ? qb : 0.f), q >= 3 ? qc : 0.f);
+      const float after = fmaxf(fmaxf(q <= 2 ? qd : 0.f, q <= 1 ? qc : 0.f), q <= 0 ? qb : 0.f);
       pre_ex = make_float4(before, fmaxf(before, i0), fmaxf(before, i1), fmaxf(before, i2));
       if (valid) {
 #pragma unroll
@@ -549,7 +651,7 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
         *reinterpret_cast<float4 *>(&ring_pm[rp]) = pm;
         *reinterpret_cast<float4 *>(&ring_suf[rp]) =
             make_float4(fmaxf(s0, after), fmaxf(s1, after), fmaxf(s2, after), fmaxf(s3, after));
-        if (q == 0) ring_bm[rp >> 4] = fmaxf(fmaxf(qa, qb), fmaxf(qc, qd));
+        if (q == 0) ring_bm[rp >> 4] = ring_bm[(rp >> 4) + NB] = fmaxf(fmaxf(qa, qb), fmaxf(qc, qd));
       }
     }
     __syncthreads();
@@ -559,14 +661,12 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
     float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
     float4 pk4 = make_float4(0.f, 0.f, 0.f, 0.f);  // the lane's four window maxima
     if (act) {
-      const int bpos = rp >> 4;
-      float w14 = 0.f;
-#pragma unroll
-      for (int j = 1; j <= 14; ++j) {
-        int bi = bpos - j;
-        bi = bi < 0 ? bi + NB : bi;
-        w14 = fmaxf(w14, ring_bm[bi]);
-      }
+      // blocks b-14 .. b-1: 14 consecutive words of the mirrored ring.  The four lanes of a quad belong to one block:
+      // each reads four of the words (the last lane's overlap the third's), two quad exchanges give all four the maximum
+      const float *bm = ring_bm + ((rp >> 4) + NB - 14 + (q < 3 ? 4 * q : 10));
+      float w14 = fmaxf(fmaxf(bm[0], bm[1]), fmaxf(bm[2], bm[3]));
+      w14 = fmaxf(w14, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w14), 0xB1, 0xf, 0xf, true)));  // quad_perm [1,0,3,2]
+      w14 = fmaxf(w14, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w14), 0x4E, 0xf, 0xf, true)));  // quad_perm [2,3,0,1]
       const float4 so = *reinterpret_cast<const float4 *>(&ring_suf[rd]);
       float4 pk;
       pk.x = fmaxf(fmaxf(so.x, w14), pre_ex.x);
@@ -587,7 +687,9 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
       if constexpr (!kTab) {
         return p.ctab[ci];
       } else {
-        const int d = ci - n_chunk;
+        // (ci == n_chunk — d == -1 — only occurs past the head's range when ci is n_end itself, where gain_at returns 1
+        //  whatever the coefficient: every step count after a trigger in this chunk stays below kFWin)
+        const int d = ci - n_chunk - 1;
         return (d >= 0 && d < kFWin) ? win[d] : head[ci < kFWin ? ci : kFWin - 1];
       }
     };
@@ -596,21 +698,55 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
     while (true) {
       if (act) {
         int kfirst = kBig;
-        if (4 * t >= 64 * bs) {
-          float gh[4];
+        const int o0 = 4 * t - 64 * bs;   // the lane's first sample, counted from the round's start state
+        if (o0 >= 0) {
+          // Hypothesis gains of the lane's four samples: sample j has made np = n_st + o0 + j steps since the state was
+          // set and reads the curve at np + 1 (gain_at / look above, audio_effect_peak_limiter.c:241-255).  Below n_end no
+          // clamp applies, at and past it the gain is 1 whatever is read.  The four coefficients are CONSECUTIVE words
+          // of one staged table — round 0: the shifted window from its start; a later round: the head from n_st + 1 (a
+          // walk has just ended, so n_st + 1 + o0 + 3 < kFWin) — one wave-uniform base, four reads, no index arithmetic.
+          // Which formula applies is decided per ROUND where it can be (a chunk that starts idle; a chunk wholly inside
+          // the 200 ms release — the two common cases), per sample otherwise.
+          const int n0 = __builtin_amdgcn_readfirstlane(n_st);
+          const int last = n0 + (cnt - 64 * bs) - 1;   // step count of the chunk's last sample under the hypothesis
+          float gh[4] = {1.f, 1.f, 1.f, 1.f};
+          if constexpr (kTab) {
+            if (n0 < n_end) {
+              const float *tb = (bs == 0 ? win : head + (n0 + 1)) + o0;
+              const float c0v = tb[0], c1v = tb[1], c2v = tb[2], c3v = tb[3];
+              const float cf[4] = {c0v, c1v, c2v, c3v};
+              if (n0 >= n_atk && last < n_end) {   // release throughout: ge + c * (1 - ge)
+                const float r1 = 1.0f - ge;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            int np = n_st + (4 * t + j - 64 * bs);
-            np = np < n_end ? np : n_end;
-            const int ci = np + 1 < n_end ? np + 1 : n_end;
-            gh[j] = gain_at(np, gs, ge, look(ci), n_atk, n_end);
+                for (int j = 0; j < 4; ++j) gh[j] = ge + cf[j] * r1;
+              } else {
+                const int nb = n0 + o0;
+                const float a1 = gs - ge, r1 = 1.0f - ge;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const float ga = gs - cf[j] * a1, gr = ge + cf[j] * r1;
+                  gh[j] = nb + j < n_atk ? ga : (nb + j < n_end ? gr : 1.0f);
+                }
+              }
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              int np = n_st + o0 + j;
+              np = np < n_end ? np : n_end;
+              const int ci = np + 1 < n_end ? np + 1 : n_end;
+              gh[j] = gain_at(np, gs, ge, look(ci), n_atk, n_end);
+            }
           }
           g = make_float4(gh[0], gh[1], gh[2], gh[3]);
-          if (valid) {
-            if (pk4.w * g.w > thr) kfirst = 4 * t + 3;
-            if (pk4.z * g.z > thr) kfirst = 4 * t + 2;
-            if (pk4.y * g.y > thr) kfirst = 4 * t + 1;
-            if (pk4.x * g.x > thr) kfirst = 4 * t + 0;
+          // the first sample that contradicts the hypothesis: sought only in a wave that has one
+          const float px = pk4.x * g.x, py = pk4.y * g.y, pz = pk4.z * g.z, pw = pk4.w * g.w;
+          const bool hit = valid && fmaxf(fmaxf(px, py), fmaxf(pz, pw)) > thr;
+          if (__ballot(hit) != 0ull && hit) {
+            if (pw > thr) kfirst = 4 * t + 3;
+            if (pz > thr) kfirst = 4 * t + 2;
+            if (py > thr) kfirst = 4 * t + 1;
+            if (px > thr) kfirst = 4 * t + 0;
           }
           if (4 * t + 4 == cnt) misc[8] = g.w;  // gain of the chunk's last sample under the hypothesis
         }

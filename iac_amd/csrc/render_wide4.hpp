@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
   float *ring_bm = ring_suf + R;                    // [2][R/16] maxima of aligned 16-blocks, stored twice so
                                                     //           that 'block b - j' needs no wrap
   float *arr_g = ring_bm + 2 * NB;                  // [1024]  limiter gains of the chunk
-  float *win = arr_g + kFChunk;                     // [kW4Win] ctab[min(n_st + i, n_end)]
+  float *win = arr_g + kFChunk;                     // [kW4Win] ctab[min(n_st + 1 + i, n_end)]
   float *head = win + kW4Win;                       // [kW4Win] ctab[i]
   float *mat = head + kW4Win;                       // [M][C4] weights, input-major
   float *misc = mat + C4 * M;                       // [16]
@@ -558,14 +558,15 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
   __syncthreads();
   const int cw = chain_wave_pick(misc + 12);
 
-  // Table window the next chunk can reach without a trigger: win[i] = ctab[min(n_st + i, n_end)].
+  // Table window the next chunk can reach without a trigger: win[i] = ctab[min(n_st + 1 + i, n_end)] (what sample i of
+  // the chunk reads if nothing triggers before it: a lane's four samples are four consecutive, 16-byte aligned words).
   // Fetched BEFORE the chunk's PCM stores are issued: vector-memory operations retire in order, so
   // a load issued after the stores could only be waited for by draining the stores as well.
   float wv[5];
   auto fetch_window = [&](int n0, int tt) {
 #pragma unroll
     for (int r = 0; r < 5; ++r) {  // five loads, always (ctab[n_end] is 1: the idle limiter)
-      const int i = n0 + tt + 256 * r;
+      const int i = n0 + 1 + tt + 256 * r;
       wv[r] = p.ctab[i < n_end ? i : n_end];
     }
   };
@@ -788,8 +789,9 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
     const float s3 = pm.w, s2 = fmaxf(pm.z, s3), s1 = fmaxf(pm.y, s2), s0 = fmaxf(pm.x, s1);
     const float qa = dpp_quad_bcast0(i3), qb = dpp_quad_bcast1(i3), qc = dpp_quad_bcast2(i3),
                 qd = dpp_quad_bcast3(i3);
-    const float before = q == 0 ? 0.f : (q == 1 ? qa : (q == 2 ? fmaxf(qa, qb) : fmaxf(fmaxf(qa, qb), qc)));
-    const float after = q == 3 ? 0.f : (q == 2 ? qd : (q == 1 ? fmaxf(qc, qd) : fmaxf(fmaxf(qb, qc), qd)));
+    // maxima of the quad's lanes before / after this one (all values are >= 0: 0 is the identity); selects, no branches
+    const float before = fmaxf(fmaxf(q >= 1 ? qa : 0.f, q >= 2 ? qb : 0.f), q >= 3 ? qc : 0.f);
+    const float after = fmaxf(fmaxf(q <= 2 ? qd : 0.f, q <= 1 ? qc : 0.f), q <= 0 ? qb : 0.f);
     const float4 pre_ex = make_float4(before, fmaxf(before, i0), fmaxf(before, i1), fmaxf(before, i2));
     if (valid) {
       *reinterpret_cast<float4 *>(&ring_pm[rp]) = pm;
@@ -800,10 +802,12 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
     __syncthreads();  // (1) maxima and table window visible
 
     // ---- 240-sample window maximum = tail of block b-15, blocks b-14..b-1, head of block b ----
-    const float *bmp = ring_bm + (rp >> 4) + NB;  // the copy at +NB: bmp[-j] is block b - j
-    float w14 = 0.f;
-#pragma unroll
-    for (int j = 1; j <= 14; ++j) w14 = fmaxf(w14, bmp[-j]);
+    // blocks b-14 .. b-1 are 14 consecutive words of the mirrored ring; the four lanes of a quad (one block) read four
+    // of them each (the last lane's overlap the third's) and exchange their maxima
+    const float *bmp = ring_bm + ((rp >> 4) + NB - 14 + (q < 3 ? 4 * q : 10));
+    float w14 = fmaxf(fmaxf(bmp[0], bmp[1]), fmaxf(bmp[2], bmp[3]));
+    w14 = fmaxf(w14, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w14), 0xB1, 0xf, 0xf, true)));  // quad_perm [1,0,3,2]
+    w14 = fmaxf(w14, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(w14), 0x4E, 0xf, 0xf, true)));  // quad_perm [2,3,0,1]
     const int rd = ring_wrap(base + 4 * tv - kDelay);
     const float4 so = *reinterpret_cast<const float4 *>(&ring_suf[rd]);
     float4 pk;
@@ -819,29 +823,46 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
     {
       const int n_chunk = n_st;
       auto look = [win, head, n_chunk](int ci) {
-        const int d = ci - n_chunk;
+        const int d = ci - n_chunk - 1;   // (the window starts one step on: render_fast.hpp)
         return (d >= 0 && d < kW4Win) ? win[d] : head[ci < kW4Win ? ci : kW4Win - 1];
       };
       const int nblk = cnt >> 6;
       int bs = 0;
       while (IAMF_W4_EXP != 3 && IAMF_W4_EXP != 5) {
         int kfirst = kBig;
-        if (4 * tv >= 64 * bs) {
-          float gh[4];
+        const int o0 = 4 * tv - 64 * bs;   // the lane's first sample, counted from the round's start state
+        if (o0 >= 0) {
+          // hypothesis gains, as in render_fast.hpp: four consecutive words of one staged table (round 0: the window;
+          // later: the head from n_st + 1), the formula chosen per round where the whole round is idle or in release
+          const int n0 = __builtin_amdgcn_readfirstlane(n_st);
+          const int last = n0 + (cnt - 64 * bs) - 1;
+          float gh[4] = {1.f, 1.f, 1.f, 1.f};
+          if (n0 < n_end) {
+            const float *tb = (bs == 0 ? win : head + (n0 + 1)) + o0;
+            const float cf[4] = {tb[0], tb[1], tb[2], tb[3]};
+            if (n0 >= n_atk && last < n_end) {
+              const float r1 = 1.0f - ge;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            int np = n_st + (4 * tv + j - 64 * bs);
-            np = np < n_end ? np : n_end;
-            const int ci = np + 1 < n_end ? np + 1 : n_end;
-            gh[j] = gain_at(np, gs, ge, look(ci), n_atk, n_end);
+              for (int j = 0; j < 4; ++j) gh[j] = ge + cf[j] * r1;
+            } else {
+              const int nb = n0 + o0;
+              const float a1 = gs - ge, r1 = 1.0f - ge;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float ga = gs - cf[j] * a1, gr = ge + cf[j] * r1;
+                gh[j] = nb + j < n_atk ? ga : (nb + j < n_end ? gr : 1.0f);
+              }
+            }
           }
           const float4 g = make_float4(gh[0], gh[1], gh[2], gh[3]);
           const float4 pq = *reinterpret_cast<const float4 *>(&arr_p[4 * tv]);  // the lane's own maxima, back from LDS
-          if (valid) {
-            if (pq.w * g.w > thr) kfirst = 4 * tv + 3;
-            if (pq.z * g.z > thr) kfirst = 4 * tv + 2;
-            if (pq.y * g.y > thr) kfirst = 4 * tv + 1;
-            if (pq.x * g.x > thr) kfirst = 4 * tv + 0;
+          const float px = pq.x * g.x, py = pq.y * g.y, pz = pq.z * g.z, pw = pq.w * g.w;
+          const bool hit = valid && fmaxf(fmaxf(px, py), fmaxf(pz, pw)) > thr;
+          if (__ballot(hit) != 0ull && hit) {
+            if (pw > thr) kfirst = 4 * tv + 3;
+            if (pz > thr) kfirst = 4 * tv + 2;
+            if (py > thr) kfirst = 4 * tv + 1;
+            if (px > thr) kfirst = 4 * tv + 0;
           }
           *reinterpret_cast<float4 *>(&arr_g[4 * tv]) = g;
           if (4 * tv + 4 == cnt) misc[8] = g.w;  // gain of the chunk's last sample under the hypothesis
