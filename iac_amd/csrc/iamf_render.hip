@@ -590,8 +590,9 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int
   for (int i = s0; i < s0 + cnt; ++i)
     if (b->spos[(size_t)i] != pos || b->sflushed[(size_t)i]) return IAMF_HIP_ERR_INVALID_STATE;
   const bool whole = s0 == 0 && cnt == b->cfg.n_streams;
-  // per-batch (not per-stream) state: the FIR history ping-pong, the LFE pre-pass blocks of 64 streams, the restride scratch
-  if (!whole && (b->fir || b->lfe)) return IAMF_HIP_ERR_UNIMPLEMENTED;
+  // per-batch (not per-stream) state: the FIR history ping-pong.  (The LFE generator's pre-pass takes the range: streams
+  // outside it keep their filter state, round 4.)
+  if (!whole && b->fir) return IAMF_HIP_ERR_UNIMPLEMENTED;
   RenderParams p;
   memset(&p, 0, sizeof(p));
   p.stream0 = s0;
@@ -747,6 +748,8 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int
     lp.state = b->d_lfe_state;
     lp.state_next = b->d_lfe_next;
     lp.u_t = reinterpret_cast<float4 *>(b->d_lfe_u);
+    lp.s_first = s0;
+    lp.s_count = cnt;
     hipLaunchKernelGGL(lfe_ff_kernel, dim3((unsigned)((t4 + kLfeTileQ - 1) / kLfeTileQ), (unsigned)nb), dim3(256), 0, st, lp);
     hipLaunchKernelGGL(lfe_chain_kernel, dim3((unsigned)nb), dim3(64), 0, st, lp);
     HIPCHK(hipGetLastError());

@@ -41,6 +41,7 @@ struct RsParams {
   uint32_t fr0;
   const float *table4;    // interpolated mode: [oversample][N][4] = the four table values a tap multiplies, per offset
   int32_t win_cap;        // resample_tile_kernel: samples of [hist | in] one workgroup stages
+  int32_t s0;             // first stream of this launch (blockIdx.y + s0): a range of streams that share one phase
 };
 
 // resample.c:246-256
@@ -52,7 +53,7 @@ __device__ __forceinline__ void cubic_coef(float frac, float interp[4]) {
 }
 
 __global__ __launch_bounds__(256) void resample_kernel(const RsParams p) {
-  const int s = blockIdx.y;
+  const int s = blockIdx.y + p.s0;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // flat (output, channel)
   const int hist_len = p.N - 1;
   const float *in = p.in ? p.in + (int64_t)s * p.in_stream_stride : nullptr;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const RsParams p) {
 constexpr int kRsTile = 1024;  // (output, channel) elements per workgroup: 4 per thread
 __global__ __launch_bounds__(256) void resample_tile_kernel(const RsParams p) {
   extern __shared__ float rs_lds[];
-  const int s = blockIdx.y;
+  const int s = blockIdx.y + p.s0;
   const int64_t e0 = (int64_t)blockIdx.x * kRsTile;
   const int hist_len = p.N - 1;
   const int N = p.N, ch = p.ch;
@@ -250,19 +251,28 @@ struct iamf_hip_resampler {
   unsigned num = 0, den = 0, filt_len = 0, oversample = 0, int_adv = 0, frac_adv = 0;
   int direct = 0;
   float cutoff = 0.f;
-  int last_sample = 0;
-  unsigned frac = 0;
+  // per stream (round 4: a group of decoder handles resamples streams that do not advance in step): the phase the
+  // stream's next call starts from and which of the two history buffers holds its past
+  std::vector<int> last_sample;
+  std::vector<unsigned> frac;
+  std::vector<uint8_t> cur;
   float *d_table = nullptr, *d_table4 = nullptr, *d_hist[2] = {nullptr, nullptr};
-  int cur = 0;
 };
 
 namespace {
 
+// streams [s0, s0 + cnt): they must share one state (phase and history buffer) — one launch, uniform parameters
 int rs_run(iamf_hip_resampler *r, const float *d_in, int64_t in_stride, int ns, float *d_out,
-           int64_t out_stride, int out_len, void *stream) {
+           int64_t out_stride, int out_len, void *stream, int s0, int cnt) {
+  if (s0 < 0 || cnt <= 0 || s0 + cnt > r->n_streams) return IAMF_HIP_ERR_BAD_ARG;
+  for (int i = s0 + 1; i < s0 + cnt; ++i)
+    if (r->last_sample[(size_t)i] != r->last_sample[(size_t)s0] || r->frac[(size_t)i] != r->frac[(size_t)s0] ||
+        r->cur[(size_t)i] != r->cur[(size_t)s0])
+      return IAMF_HIP_ERR_INVALID_STATE;
   // host replica of the phase walk (resample.c:269-303): how many outputs this call yields
-  int ls = r->last_sample;
-  unsigned fr = r->frac;
+  int ls = r->last_sample[(size_t)s0];
+  unsigned fr = r->frac[(size_t)s0];
+  const int cur = r->cur[(size_t)s0];
   int n_out = 0;
   while (!(ls >= ns || n_out >= out_len)) {
     ++n_out;
@@ -278,8 +288,9 @@ int rs_run(iamf_hip_resampler *r, const float *d_in, int64_t in_stride, int ns, 
   memset(&p, 0, sizeof(p));
   p.in = d_in;
   p.in_stream_stride = in_stride;
-  p.hist = r->d_hist[r->cur];
-  p.hist_next = r->d_hist[r->cur ^ 1];
+  p.hist = r->d_hist[cur];
+  p.hist_next = r->d_hist[cur ^ 1];
+  p.s0 = s0;
   p.out = d_out;
   p.out_stream_stride = out_stride;
   p.table = r->d_table;
@@ -293,10 +304,10 @@ int rs_run(iamf_hip_resampler *r, const float *d_in, int64_t in_stride, int ns, 
   p.num = r->num;
   p.den = r->den;
   p.int_adv = r->int_adv;
-  p.ls0 = r->last_sample;
-  p.fr0 = r->frac;
+  p.ls0 = r->last_sample[(size_t)s0];
+  p.fr0 = r->frac[(size_t)s0];
   const int64_t work = (int64_t)(n_out > (int)r->filt_len - 1 ? n_out : (int)r->filt_len - 1) * r->ch;
-  dim3 grid((unsigned)((work + 255) / 256), (unsigned)r->n_streams);
+  dim3 grid((unsigned)((work + 255) / 256), (unsigned)cnt);
   // the LDS-tiled kernel where its operands fit: 256 / ch outputs advance num / den samples each, plus the taps
   const int outs = kRsTile / r->ch + 2;
   const int64_t win_cap = ((int64_t)outs * r->num + r->den - 1) / r->den + (int64_t)r->filt_len + 2;
@@ -305,15 +316,17 @@ int rs_run(iamf_hip_resampler *r, const float *d_in, int64_t in_stride, int ns, 
   if ((r->direct ? (r->filt_len & 7) == 0 : r->d_table4 != nullptr) && lds <= 48 * 1024 && !getenv("IAMF_HIP_RESAMPLE_PLAIN")) {
     p.table4 = r->d_table4;
     p.win_cap = (int)win_cap;
-    dim3 tgrid((unsigned)((work + kRsTile - 1) / kRsTile), (unsigned)r->n_streams);
+    dim3 tgrid((unsigned)((work + kRsTile - 1) / kRsTile), (unsigned)cnt);
     hipLaunchKernelGGL(resample_tile_kernel, tgrid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
   } else {
     hipLaunchKernelGGL(resample_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
   }
   RS_HIPCHK(hipGetLastError());
-  r->last_sample = ls - consumed;
-  r->frac = fr;
-  r->cur ^= 1;
+  for (int i = s0; i < s0 + cnt; ++i) {
+    r->last_sample[(size_t)i] = ls - consumed;
+    r->frac[(size_t)i] = fr;
+    r->cur[(size_t)i] = (uint8_t)(cur ^ 1);
+  }
   return n_out;
 }
 
@@ -375,8 +388,9 @@ int iamf_hip_resampler_create(int n_streams, int channels, int in_rate, int out_
         for (int q = 0; q < 4; ++q)
           tab4[((size_t)o * r->filt_len + j) * 4 + q] = tab[4 + (size_t)(j + 1) * r->oversample - o + (q - 2)];
   }
-  r->last_sample = (int)(r->filt_len / 2);  // speex_resampler_skip_zeros (IAMF_decoder.c:1902)
-  r->frac = 0;
+  r->last_sample.assign((size_t)n_streams, (int)(r->filt_len / 2));  // speex_resampler_skip_zeros (IAMF_decoder.c:1902)
+  r->frac.assign((size_t)n_streams, 0u);
+  r->cur.assign((size_t)n_streams, 0);
   const size_t hist_bytes = sizeof(float) * (size_t)n_streams * (r->filt_len - 1) * channels;
   if (hipMalloc(&r->d_table, sizeof(float) * tab.size()) != hipSuccess ||
       hipMalloc(&r->d_hist[0], hist_bytes) != hipSuccess || hipMalloc(&r->d_hist[1], hist_bytes) != hipSuccess ||
@@ -413,13 +427,35 @@ int iamf_hip_resampler_process(iamf_hip_resampler *r, const float *d_in, int64_t
   if (!r || !d_in || !d_out || ns < 0) return IAMF_HIP_ERR_BAD_ARG;
   const int cap = iamf_hip_resampler_out_capacity(r, ns);
   if (r->n_streams > 1 && out_stream_stride < (int64_t)cap * r->ch) return IAMF_HIP_ERR_BUFFER_TOO_SMALL;
-  return rs_run(r, d_in, in_stream_stride, ns, d_out, out_stream_stride, cap, stream);
+  return rs_run(r, d_in, in_stream_stride, ns, d_out, out_stream_stride, cap, stream, 0, r->n_streams);
 }
 
 int iamf_hip_resampler_flush(iamf_hip_resampler *r, float *d_out, int64_t out_stream_stride, void *stream) {
   if (!r || !d_out) return IAMF_HIP_ERR_BAD_ARG;
   const int cap = iamf_hip_resampler_flush_capacity(r);
-  return rs_run(r, nullptr, 0, (int)(r->filt_len / 2), d_out, out_stream_stride, cap, stream);
+  return rs_run(r, nullptr, 0, (int)(r->filt_len / 2), d_out, out_stream_stride, cap, stream, 0, r->n_streams);
+}
+
+// the same for the streams [stream0, stream0 + n_streams) only; buffers and strides are indexed by the stream's number
+int iamf_hip_resampler_process_range(iamf_hip_resampler *r, const float *d_in, int64_t in_stream_stride, int ns, float *d_out,
+                                     int64_t out_stream_stride, void *stream, int32_t stream0, int32_t n_streams) {
+  if (!r || !d_in || !d_out || ns < 0) return IAMF_HIP_ERR_BAD_ARG;
+  const int cap = iamf_hip_resampler_out_capacity(r, ns);
+  if (r->n_streams > 1 && out_stream_stride < (int64_t)cap * r->ch) return IAMF_HIP_ERR_BUFFER_TOO_SMALL;
+  return rs_run(r, d_in, in_stream_stride, ns, d_out, out_stream_stride, cap, stream, stream0, n_streams);
+}
+
+int iamf_hip_resampler_flush_range(iamf_hip_resampler *r, float *d_out, int64_t out_stream_stride, void *stream, int32_t stream0,
+                                   int32_t n_streams) {
+  if (!r || !d_out) return IAMF_HIP_ERR_BAD_ARG;
+  const int cap = iamf_hip_resampler_flush_capacity(r);
+  return rs_run(r, nullptr, 0, (int)(r->filt_len / 2), d_out, out_stream_stride, cap, stream, stream0, n_streams);
+}
+
+int iamf_hip_resampler_same_state(const iamf_hip_resampler *r, int32_t a, int32_t b) {
+  if (!r || a < 0 || b < 0 || a >= r->n_streams || b >= r->n_streams) return 0;
+  return r->last_sample[(size_t)a] == r->last_sample[(size_t)b] && r->frac[(size_t)a] == r->frac[(size_t)b] &&
+         r->cur[(size_t)a] == r->cur[(size_t)b];
 }
 
 }  // extern "C"

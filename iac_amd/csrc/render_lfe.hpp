@@ -33,6 +33,7 @@ struct LfeParams {
   float *state;               // [n_streams][4]: w1, w2, y1, y2
   float *state_next;          // [n_streams][2]: w1, w2 after this call (adopted by the chain kernel)
   float4 *u_t;                // [n_blocks64][t4][64] quads: u from the ff kernel, y after the chain kernel
+  int32_t s_first, s_count;   // the streams this call renders (iamf_hip_batch_render_range): the others keep their state
 };
 
 // where the render kernel finds the generator's output for sample k of stream s (floats into u_t)
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void lfe_ff_kernel(const LfeParams p) {
     const int q = t & 15, sl = (t >> 4) + 16 * pass;
     const int s = sb * 64 + sl, k0 = 4 * (q_base + q);
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (s < p.n_streams && k0 < p.total) {
+    if (s >= p.s_first && s < p.s_first + p.s_count && k0 < p.total) {
       const float h1 = p.state[4 * s + 0], h2 = p.state[4 * s + 1];
       float wm1, wm2, w[4], uu[4];
       const bool quick = !p.pre_matrix && ((p.frame_size | p.in_stream_stride | p.in_frame_stride) & 3) == 0 &&
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(256) void lfe_ff_kernel(const LfeParams p) {
 __global__ __launch_bounds__(64) void lfe_chain_kernel(const LfeParams p) {
   const int lane = threadIdx.x, sb = blockIdx.x;
   const int s = sb * 64 + lane;
-  const bool active = s < p.n_streams;
-  const int sc = active ? s : p.n_streams - 1;
+  const bool active = s >= p.s_first && s < p.s_first + p.s_count;
+  const int sc = active ? s : p.s_first;
   float y1 = p.state[4 * sc + 2], y2 = p.state[4 * sc + 3];
   const float b1 = p.b1, b2 = p.b2;
   float4 *row = p.u_t + (int64_t)sb * p.t4 * 64 + lane;   // this lane's quad q sits at row[64 q]

@@ -327,6 +327,15 @@ int iamf_hip_resampler_process(iamf_hip_resampler *r, const float *d_in, int64_t
                                int ns, float *d_out, int64_t out_stream_stride, void *stream);
 /* end of stream (rest_flag 2, IAMF_decoder.c:3227-3232): drains the filter latency */
 int iamf_hip_resampler_flush(iamf_hip_resampler *r, float *d_out, int64_t out_stream_stride, void *stream);
+/* The same for the streams [stream0, stream0 + n_streams) only (buffers and strides are indexed by the stream's number in
+ * the resampler): every stream keeps its own phase and history, so streams need not advance in step — a range must consist
+ * of streams in ONE state (iamf_hip_resampler_same_state; IAMF_HIP_ERR_INVALID_STATE otherwise): streams that have
+ * consumed the same sequence of call lengths always are. */
+int iamf_hip_resampler_process_range(iamf_hip_resampler *r, const float *d_in, int64_t in_stream_stride, int ns, float *d_out,
+                                     int64_t out_stream_stride, void *stream, int32_t stream0, int32_t n_streams);
+int iamf_hip_resampler_flush_range(iamf_hip_resampler *r, float *d_out, int64_t out_stream_stride, void *stream, int32_t stream0,
+                                   int32_t n_streams);
+int iamf_hip_resampler_same_state(const iamf_hip_resampler *r, int32_t stream_a, int32_t stream_b);
 
 /* Forgets all stream state (new IA sequence: limiter re-initialised as in
  * iamf_decoder_internal_configure, IAMF_decoder.c:3809-3815).  Synchronous. */

@@ -205,6 +205,18 @@ int iamf_hip_resampler_process(iamf_hip_resampler *r, const float *in, int64_t i
 int iamf_hip_resampler_flush(iamf_hip_resampler *r, float *out, int64_t oss, void *st) {
   (void)r; (void)out; (void)oss; (void)st; return 0;
 }
+int iamf_hip_resampler_process_range(iamf_hip_resampler *r, const float *in, int64_t iss, int n, float *out, int64_t oss, void *st,
+                                     int32_t s0, int32_t cnt) {
+  (void)in; (void)iss; (void)st;
+  int m = (int)((int64_t)n * r->out / r->in);
+  if ((int64_t)m * r->ch > oss) return IAMF_HIP_ERR_BAD_ARG;
+  for (int s = s0; s < s0 + cnt; ++s) memset(out + (int64_t)s * oss, 0, sizeof(float) * (size_t)m * r->ch); /* the rows a kernel would write */
+  return m;
+}
+int iamf_hip_resampler_flush_range(iamf_hip_resampler *r, float *out, int64_t oss, void *st, int32_t s0, int32_t cnt) {
+  (void)r; (void)out; (void)oss; (void)st; (void)s0; (void)cnt; return 0;
+}
+int iamf_hip_resampler_same_state(const iamf_hip_resampler *r, int32_t a, int32_t b) { (void)r; (void)a; (void)b; return 1; }
 void iamf_hip_dmx_state_init(iamf_hip_dmx_state *s) { memset(s, 0, sizeof(*s)); }
 int iamf_hip_dmx_set_mode_weight(iamf_hip_dmx_state *s, int mode, int w) { (void)w; s->mode = mode; return 0; }
 void iamf_hip_dmx_coefficients(const iamf_hip_dmx_state *s, float *c) { (void)s; memset(c, 0, 5 * sizeof(float)); }

@@ -234,3 +234,18 @@ def test_group_refuses_handles_that_differ_in_lpcm_byte_order(group_driver, tmp_
     # the same four handles from ONE stream form a group
     r = subprocess.run([group_driver, p1, "0", "16", "4", "2", p1], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0 and "group_create 0" in r.stdout.splitlines(), (r.stdout, r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("n,threads", [(1, 1), (5, 3), (9, 2)])
+def test_group_of_resampling_handles_matches_the_single_handle_totals(driver, group_driver, tmp_path, n, threads):
+    """round 4: handles whose stream rate differs from the output rate (IAMF_decoder.c:3193-3199) form a group — three stages
+    per launch run (render -> resample -> limiter / pack).  Here: the host side under ASan / UBSan against the stub, handles
+    out of step; the PCM itself is checked on the GPU (tests/test_gpu_group.py)."""
+    frames = [stereo_frame(seed=1), stereo_frame(trim=(3, 0), seed=2), stereo_frame(seed=3), stereo_frame(trim=(0, 5), seed=4),
+              stereo_frame(seed=5)]
+    s = descriptors(rate=44100) + b"".join(frames)
+    want = int(run(driver, tmp_path, s)[-1].split()[1])
+    out = run_group(group_driver, tmp_path, s, n, threads)
+    assert "group_create 0" in out
+    totals = [int(l.split()[2]) for l in out if l.startswith("total h")]
+    assert totals == [want] * n, (totals, want)

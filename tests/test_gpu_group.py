@@ -47,6 +47,9 @@ def lib():
 
 def open_handle(L, case, stream):
     d = L.IAMF_decoder_open()
+    if case.get("lfe_hoa"):
+        L.iamf_hip_decoder_set_hoa_lfe.argtypes = [C.c_void_p, C.c_int]
+        assert L.iamf_hip_decoder_set_hoa_lfe(d, 1) == 0
     if not case.get("limiter", True):
         L.IAMF_decoder_peak_limiter_enable(d, 0)
     else:
@@ -147,12 +150,46 @@ def test_group_of_handles_matches_reference_decoder(lib, golden, name):
         pytest.skip("a stream that reconfigures mid-way is a single-handle protocol (the group refuses new sequences)")
     n = 7
     rc, outs = group_decode_all(lib, case, stream, n, 3, starve=lambda r, i: (r + 2 * i) % 5 == 0 and i % 2 == 1)
-    if case.get("out_rate", 0) and rc == ERR_UNIMPLEMENTED:
-        return   # resampling handles are not grouped (documented): create says so instead of rendering something else
+    assert rc == 0, rc   # (round 4: handles that resample form groups too — render -> resample -> limiter per launch run)
+    for i, (pcm, rets) in enumerate(outs):
+        assert rets == want_rets, (name, i, rets, want_rets)
+        assert pcm.shape == want.shape and np.array_equal(pcm, want), (name, i)
+
+
+def _lfe_names():
+    import lfe_cases as LC
+    return sorted(LC.E2E)
+
+
+@pytest.mark.parametrize("name", _lfe_names())
+def test_group_of_handles_with_the_hoa_lfe_generator(lib, golden, name):
+    """round 4: handles with the HOA LFE generator on (the reference built -DDISABLE_LFE_HOA=0, goldens of
+    oracle/_ref_lfe) form groups: the generator's pre-pass renders the launch's range of streams and leaves the other
+    streams' filter histories alone.  Seven handles out of step, incl. the 44.1 -> 48 kHz and the projection-mode stream."""
+    import lfe_cases as LC
+    c = LC.E2E[name]
+    stream, _ = LC.build(name)
+    case = dict(layout=("ss", LC.SS_ENUM[c["ss"]]), bit_depth=c["bit_depth"], lfe_hoa=True)
+    want, want_rets = golden.npz("lfe")["e2e_" + name], list(golden.npz("lfe")["e2e_" + name + "_rets"])
+    rc, outs = group_decode_all(lib, case, stream, 7, 3, starve=lambda r, i: (r + i) % 4 == 0 and i % 3 != 0)
     assert rc == 0, rc
     for i, (pcm, rets) in enumerate(outs):
         assert rets == want_rets, (name, i, rets, want_rets)
         assert pcm.shape == want.shape and np.array_equal(pcm, want), (name, i)
+
+
+def test_group_of_resampling_handles_far_out_of_step(lib, golden):
+    """handles that resample, starved so that neighbours sit in different phases of the 147 / 160 resampler for most of the
+    stream: every launch run is then a single stream or a pair — each handle's PCM must still be the reference's"""
+    name = "stereo_441_to_48k"
+    case = e2e_cases.CASES[name]
+    stream, _ = e2e_cases.build(name)
+    want, want_rets = golden.npz("e2e")[name], list(golden.npz("e2e")[name + "_rets"])
+    rc, outs = group_decode_all(lib, case, stream, 9, 2, starve=lambda r, i: (r * (i + 1)) % 3 == 1)
+    assert rc == 0, rc
+    for i, (pcm, rets) in enumerate(outs):
+        assert rets == want_rets, (i, rets, want_rets)
+        assert np.array_equal(pcm, want), i
 
 
 @pytest.mark.parametrize("unpack_first", [False, True])
