@@ -114,6 +114,23 @@ def measured_traffic(kernel_tag, sf_per_step, workload=None):
     return best
 
 
+def measured_mfma(workload, kernel_tags):
+    """matrix-pipe busy fraction of this workload's kernel from the newest committed SQ-counter summary
+    (profiles/r*_sq_counters.json: tools/sq_all.sh + tools/sq_summary.py, rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES)"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")), reverse=True):
+        try:
+            d = json.load(open(f)).get(workload, {})
+        except Exception:
+            continue
+        tags = kernel_tags if isinstance(kernel_tags, tuple) else (kernel_tags,)
+        for name, v in d.items():
+            if any(t in name for t in tags) and "mfma_busy_frac_at_2p4GHz" in v:
+                return {"busy_frac": v["mfma_busy_frac_at_2p4GHz"], "kernel": name, "source": os.path.basename(f),
+                        "note": "SQ_VALU_MFMA_BUSY_CYCLES / (dispatch duration x 2.4 GHz), a separate rocprofv3 --pmc pass of this workload"}
+    return None
+
+
 def cpu_share():
     """(threads to use, how that was decided): the cores this process may run on, capped by the container's CPU quota
     (cgroup v2 cpu.max / v1 cfs quota) when there is one.  The box's nproc is reported beside it."""
@@ -443,11 +460,12 @@ class Workload:
             Pm[np.arange(in_ch), np.arange(in_ch)] += np.float32(0.5)
             batch.set_projection(Pm.astype(np.float32))
             self.proj = Pm.astype(np.float32)
-        self.placement = None
+        self.placement = {"candidates_msamples_s": [], "picked": 0,
+                          "note": "no search for this workload / --placement-tries <= 1: the buffers as they came"}
         self.x = None
         self.x_first = None
         self.pcm_first = None
-        self.pcm_placement = None
+        self.pcm_placement = {"candidate_pairs_msamples_s": [], "picked": 0, "note": "no search: the first two PCM buffers"}
         if args.placement_tries > 1 and kind in ("h2m", "m2m", "fir", "h2m_lfe", "h2m_proj"):
             self.pick_placement(args.placement_tries, dev)
             if args.pcm_placement_tries > 2:
@@ -731,6 +749,7 @@ class Workload:
         """the dominant kernel's roofline entry from its mean launch duration (HIP events)"""
         achieved = self.bytes_per_sf * self.sf_per_step / (kernel_ms * 1e-3) / 1e9
         traffic = measured_traffic(self.ktag, self.sf_per_step, self.name)
+        mfma = measured_mfma(self.name, self.ktag)
         r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(achieved / HBM_PEAK_GBS, 4),
              "traffic": round(traffic[0]) if traffic else None,
@@ -740,6 +759,8 @@ class Workload:
              "kernel": self.ktag if isinstance(self.ktag, str) else self.ktag[0], "kernel_ms": round(kernel_ms, 4),
              "algorithmic_bytes_per_sample_frame": self.bytes_per_sf,
              "frac_of_measured_copy_6290": round(achieved / 6290.0, 4)}
+        if mfma:   # north_star: "MFMA utilisation on the HOA path" — the projection runs on the f32 matrix cores (cfg3)
+            r["mfma"] = mfma
         dtype = "f32"
         if not isinstance(self.ktag, str):
             r["kernels"] = list(self.ktag)
@@ -948,8 +969,14 @@ def main():
         gather_to_rank0(wl.pcm[0], final_recv)
 
     regions = []
-    for r in range(max(1, args.repeats)):
+    # one region more than reported: the first one runs on clocks that have just come up from idle (sclk reads 158 MHz
+    # between regions) and is dropped — listed as repeats.discarded_first_ms_per_step, never the reported value
+    discarded = None
+    for r in range(max(1, args.repeats) + 1):
         elapsed, kernel_ms, emitted = timed_region(wl, pipe, args.steps, world, dist)
+        if r == 0:
+            discarded = elapsed
+            continue
         assert emitted >= args.steps * F * fs - 240, "every step must emit its F*fs sample-frames per stream"
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         if world > 1:
@@ -961,7 +988,7 @@ def main():
         # It happens once per job whatever the number of steps, so it is timed on its own and
         # reported beside the K-step rate instead of being folded into it.
         tg = time.perf_counter()
-        gather_to_rank0(wl.pcm[(args.steps * len(regions) - 1) % 2], final_recv)
+        gather_to_rank0(wl.pcm[(args.steps * (len(regions) + 1) - 1) % 2], final_recv)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -1020,7 +1047,10 @@ def main():
             "ranks_seen": ranks_seen, "rccl_version": rccl,
             "launched_by": os.environ.get("IAMF_LAUNCHED_BY", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
             "device": dev_info,
+            "value_min": round(total_sf / max(e for e, _ in regions) / 1e6, 2),
+            "value_max": round(total_sf / min(e for e, _ in regions) / 1e6, 2),
             "repeats": {"n": len(regions), "steps_each": args.steps, "reported": "median",
+                        "discarded_first_ms_per_step": None if discarded is None else round(discarded / args.steps * 1e3, 4),
                         "ms_per_step": [round(e / args.steps * 1e3, 4) for e, _ in regions],
                         "value_min": round(total_sf / max(e for e, _ in regions) / 1e6, 2),
                         "value_median": round(value, 2),

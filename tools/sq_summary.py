@@ -21,19 +21,25 @@ def main():
             continue
         acc = collections.defaultdict(lambda: collections.defaultdict(float))
         cnt = collections.Counter()
+        dur = collections.defaultdict(float)
         for r in csv.DictReader(open(files[0])):
             k = r["Kernel_Name"]
-            if "render" not in k:
+            if "render" not in k and "fir_fft" not in k:
                 continue
-            m = re.search(r"render_\w+<[^>]*>", k)
+            m = re.search(r"(render_\w+|fir_fft_kernel)<[^>]*>", k)
             k = m.group(0) if m else k[:60]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Counter_Name"] == "SQ_WAVE_CYCLES":
                 cnt[k] += 1
+                dur[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])   # ns, under the counters (slower than unprofiled)
         for k, v in acc.items():
             n = max(cnt[k], 1)
             wc = v.get("SQ_WAVE_CYCLES", 0.0) or 1.0
-            e = {"dispatches": n}
+            e = {"dispatches": n, "avg_ns_under_counters": dur[k] / n}
+            if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) > 0 and dur[k] > 0:
+                # busy cycles of the matrix pipes against the dispatch's own duration at the nominal 2.4 GHz (the card holds
+                # ~2.1 under load: DESIGN 4.2) — the convention of DESIGN 4.2's "69 % busy"
+                e["mfma_busy_frac_at_2p4GHz"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (dur[k] * 2.4), 4)
             for c, x in sorted(v.items()):
                 e[c + "_per_dispatch"] = x / n
                 if c != "SQ_WAVE_CYCLES" and not c.startswith("SQ_INSTS") and c != "SQ_VALU_MFMA_BUSY_CYCLES":
