@@ -558,7 +558,7 @@ class Workload:
 
     def pick_placement(self, tries, dev):
         """Setup, untimed.  The same kernel on the same bytes runs in one of two modes depending on WHICH
-        allocation holds the element PCM (tools/placement_probe*.py: e.g. 79 or 91 Gsamples/s quiet, 73 or 86
+        allocation holds the element PCM (tools/debug/placement_probe*.py: e.g. 79 or 91 Gsamples/s quiet, 73 or 86
         hot; not the stride, not the base offset inside the allocation, not the PCM / state buffers; a plain
         streaming read gets 7.0 TB/s from either).  A long-lived serving buffer is allocated once, so the
         harness does what a deployment would: it allocates up to `tries` candidates, measures a few launches
@@ -583,7 +583,7 @@ class Workload:
             rates.append(round(self.sf_per_step / (ms * 1e-3) / 1e6, 1))
             if i >= 2 and rates[-1] >= 0.97 * max(rates) and max(rates) > 1.07 * min(rates):
                 break   # both modes showed and the current candidate is in the fast one; else all `tries` are looked at
-                        # (the first PCM buffer may be of the same kind as every input candidate of a long run)
+                        # (the first PCM buffer may be of the same kind as every input candidate of a long run, NOTEBOOK.md 3)
         best = int(np.argmax(rates))
         self.x = cands[best]
         self.x_first = cands[0] if best != 0 else None   # what an unsearched deployment gets: timed after the regions
@@ -595,8 +595,8 @@ class Workload:
 
     def pick_pcm_placement(self, tries, dev):
         """Setup, untimed: the same search for the two PCM output buffers.  What is slow is a PAIR: an input region and an
-        output region of the same kind (tools/placement_va_probe.hip `out`: every input buffer is slow with one group of
-        output buffers and fast with the other, or fast with both — DESIGN.md 3), and the timed region alternates
+        output region of the same kind (tools/debug/placement_va_probe.hip `out`: every input buffer is slow with one group of
+        output buffers and fast with the other, or fast with both — NOTEBOOK.md 3), and the timed region alternates
         between two PCM buffers, so BOTH have to suit the chosen input.  Candidates are therefore pairs: the two buffers
         already allocated, and `tries` - 1 more, each pair ONE allocation cut in two (neighbours share their kind of region;
         with single buffers as candidates a run found one fast buffer among six and timed every other step on a slow one).
@@ -789,7 +789,7 @@ class Workload:
                           "note": "bound = HBM by count (68 B per sample-frame + 16 for y between the two kernels): the FFT stage "
                                   "issues %.0f flop per sample-frame where the direct form needs %d; what limits it as measured: "
                                   "the stage kernel's VALU issue at 2 waves per SIMD (~240 VGPRs) and the limiter kernel's chain "
-                                  "(DESIGN.md 4.2c)" % (flop_sf, flop_direct)})
+                                  "(NOTEBOOK.md 4.2c)" % (flop_sf, flop_direct)})
             else:
                 tf = flop_direct * rate / 1e12
                 peak = F32_MFMA_PEAK_TFLOPS if f32_stage else F16_MFMA_PEAK_TFLOPS
@@ -829,7 +829,7 @@ def timed_region(wl, pipe, steps, world, dist):
 
 def device_info():
     """What rocm-smi says about this rank's card (memory vendor and clocks): the render kernels' rate differs by
-    ~13 % between MI355X devices, and this is what can be read in-band about the one measured."""
+    ~13 % between MI355X devices (NOTEBOOK.md 5), and this is what can be read in-band about the one measured."""
     import subprocess
     if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any("ROCPROF" in k.upper() for k in os.environ):
         # the profiler's preloaded library has initialised the GPU before this process started: no fork + exec here

@@ -6,7 +6,7 @@
 // render_fast.hpp (rows 16, pieces 1) and render_wide4.hpp (cfg2: 12 / 6, cfg3: 16 / 12).
 // Round-2 findings: read-only this pattern runs at 7.1 TB/s; with a share of writes at 6.2-6.5 TB/s (headline shape)
 // when input and output lie in memory regions of different kinds and at 5.45 TB/s when they lie in regions of the
-// same kind (tools/placement_va_probe.hip) — iamf_hip_pick_buffer_pair below finds a fast pair among
+// same kind (NOTEBOOK.md 3, tools/debug/placement_va_probe.hip) — iamf_hip_pick_buffer_pair below finds a fast pair among
 // candidates.  Nothing here is used by the render path.
 #include <hip/hip_runtime.h>
 

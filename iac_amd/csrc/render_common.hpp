@@ -190,7 +190,7 @@ __device__ __forceinline__ float w4_quot(float n, float d, float r, bool &ok) {
 // which HRTF stage a FIR call runs (host): 3 = overlap-save FFT (default), 2 = split-f16 MFMA, 1 = f32 MFMA
 // 4 = the FFT stage as a kernel of its own + the two-channel matrix kernel behind it (default); IAMF_HIP_FIR_FUSED=1 keeps
 // the FFT stage inside render_fast_kernel<M, 2, 3> (one pass over HBM, but the hops of a stream run one pass after the other
-// and the limiter stages at two workgroups per CU: 29 instead of the split's rate)
+// and the limiter stages at two workgroups per CU: 29 instead of the split's rate, NOTEBOOK.md 4.2c)
 inline int fir_stage_choice(const RenderParams &p) {
   if (getenv("IAMF_HIP_FIR_F32")) return 1;
   if (getenv("IAMF_HIP_FIR_F16") && p.fir_h16) return 2;

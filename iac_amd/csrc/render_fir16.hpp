@@ -25,11 +25,11 @@
 // tiles per wave (LDS reads per MFMA halved): 9.3; two chunks per pass: 12.5; four chunks per pass with
 // single-buffered tables (what fits 80 KB): 15.4.  Tried: ONE table copy per channel read at its
 // 2-byte boundary, all 16 channels resident in LDS (no table traffic at all) — correct, but a
-// ds_read_b128 that is not 16-byte aligned is served one lane per cycle (tools/lds_unaligned_probe.hip:
+// ds_read_b128 that is not 16-byte aligned is served one lane per cycle (tools/debug/lds_unaligned_probe.hip:
 // 64 instead of 23 cycles per wave-read at 2, 4 or 8 bytes off): 3.7; with the reads forced aligned
 // (wrong taps) 13.5 at one chunk per pass.
 // Round 2: four waves x (2 ears x 4 tiles), two operand sets, branch-free prefetch, no scratch: 18.2-18.8
-// (see fir_stage16 below); from there on the kernel is power-limited (profiles/r02_fir16/).
+// (see fir_stage16 below); from there on the kernel is power-limited (NOTEBOOK.md 4.2, profiles/r02_fir16/).
 #pragma once
 
 // IAMF_F16_EXP: timing-only elimination builds (WRONG results; the product is 0):
@@ -39,7 +39,7 @@
 #ifndef IAMF_F16_EXP
 #define IAMF_F16_EXP 0
 #endif
-// hooks of tools/fir16_stage_probe.hip (per-phase s_memtime stamps); nothing in the product
+// hooks of tools/debug/fir16_stage_probe.hip (per-phase s_memtime stamps); nothing in the product
 #ifndef IAMF_F16_STAMP
 #define IAMF_F16_STAMP_DECL
 #define IAMF_F16_STAMP(k)
@@ -65,7 +65,7 @@ using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 // slice reads (16 bytes per lane each) feed 24 MFMAs, and the reads of step s + 1 are issued before the MFMAs
 // of step s (two operand sets).  [The first version ran 8 waves x (2 ears x 2 tiles) at 128 VGPRs: the table
 // prefetch was spilled to scratch behind a vmcnt(0) and the K loop waited for every LDS read where it was
-// issued — tools/f16_exp.sh, profiles/r02_fir16/.]
+// issued — tools/debug/f16_exp.sh, profiles/r02_fir16/.]
 // y[e][c0 .. c0+4096) goes to part ([2 ears][4 chunks][1024 + 32] floats, padded by one per 32; aliases the
 // staging area, which is dead by then).  All 256 threads must call it.
 template <int M>
@@ -109,7 +109,7 @@ __device__ __forceinline__ void fir_stage16(const RenderParams &p, const float *
   u4 hr[NH];
   // Every thread issues the same ten loads for every channel, no branches: with the loads in conditional blocks
   // the compiler separated them by s_waitcnt vmcnt(0) (a quarter of the kernel's time went to ISSUING them —
-  // tools/fir16_stage_probe.hip).  A quad that is padding or lies past the end of the call loads the channel's
+  // tools/debug/fir16_stage_probe.hip).  A quad that is padding or lies past the end of the call loads the channel's
   // first quad instead and is zeroed when it is stored to LDS.
   auto fetch = [&](int ch) {  // global -> registers
     const float *in_c = in_s + (int64_t)ch * p.frame_size;

@@ -9,7 +9,7 @@
 //
 // Why.  The direct form costs 16 384 flop per sample-frame at 16 channels x 256 taps; on the f16 matrix cores with
 // split operands that is 49 152 issued flop and the kernel ends up power-limited at 0.12 of the f16 peak (18.5
-// Gsamples/s).  Overlap-save with N = 1024, hop 768 (N - hop = 256 >= L) costs ~770 flop per
+// Gsamples/s, NOTEBOOK.md 4.2).  Overlap-save with N = 1024, hop 768 (N - hop = 256 >= L) costs ~770 flop per
 // sample-frame on the vector ALU and moves the stage towards the HBM bound of the whole kernel (68 B per sample-frame).
 //
 // Algebra.  Two real channels a, b ride one complex FFT, z_p = x_a + i x_b, and both ears ride one inverse FFT,
@@ -44,7 +44,7 @@
 #define IAMF_FFT_NT 1                // 0: the sample fetch with the default cache policy throughout (A/B builds)
 #endif
 #ifndef IAMF_FFT_X2_LDS
-#define IAMF_FFT_X2_LDS 0            // 1: exchange 2 through LDS (the first form; kept for A/B builds, tools/fft_exp.sh)
+#define IAMF_FFT_X2_LDS 0            // 1: exchange 2 through LDS (the first form; kept for A/B builds, tools/debug/fft_exp.sh)
 #endif
 constexpr int kFftN = 1024;          // FFT size
 constexpr int kFftHop = 768;         // new samples per hop; kFftN - kFftHop = 256 >= taps
@@ -454,7 +454,7 @@ inline int fft_build_tables(const float *hrir, int m, int taps, std::vector<floa
 #endif
 
 #if defined(__HIPCC__)
-// IAMF_FFT_EXP: timing-only elimination builds (WRONG results), tools/fft_exp.sh:
+// IAMF_FFT_EXP: timing-only elimination builds (WRONG results), tools/debug/fft_exp.sh:
 //   1 = no spectra-table loads (the accumulation multiplies by a constant)   2 = the next pair's samples are not fetched
 //   3 = no LDS exchanges (the register stages run on whatever they hold)     4 = the stage returns at once
 //   5 = no accumulation at all (transforms only)
@@ -541,7 +541,7 @@ __device__ __forceinline__ const float *fft_y_ptr(const float *scratch_all, int 
 // addresses: a scalar compare + select per run, the run's 256 n1 in the instruction's offset field and the channel in the
 // lane's offset register (two additions per pair).  The general form above spends per LOAD two v_readlane, the wait states
 // between a VALU-written SGPR and its use as an address, and a 64-bit scalar multiply-add — 240 of the ~660 instruction
-// slots of a pair step; without its sample fetch the stage kernel took 1.06 instead of 1.51 ms (tools/fft_exp.sh).
+// slots of a pair step; without its sample fetch the stage kernel took 1.06 instead of 1.51 ms (tools/debug/fft_exp.sh).
 template <int M, int N1A, int N1B>
 __device__ __forceinline__ void fft_fetch2(int pr, fft_c32 (&z)[16], uint64_t base1, uint64_t base2p, int kseg, unsigned cs4,
                                            unsigned lo4) {
@@ -649,7 +649,7 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
   // One pair: transform za (fetched a whole pair earlier), accumulate, then fetch the pair after next into the same
   // registers.  Vector-memory loads return IN ORDER per wave, so a short load issued behind a long one waits for it: with
   // the sample fetch (HBM, microseconds under load) at the top of the step, the second half of the spectra table (L2)
-  // queued behind it and every pair paid an HBM round trip (tools/fft_exp.sh: removing the fetch halved the kernel's
+  // queued behind it and every pair paid an HBM round trip (tools/debug/fft_exp.sh: removing the fetch halved the kernel's
   // time).  Order now: table half 1 -> transform -> accumulate half 1 / table half 2 -> accumulate half 2 -> samples of
   // pair p + 2.  The table reads only ever queue behind a fetch that is a whole step old.
   auto pair_step = [&](int pr, fft_c32 (&za)[16]) {
@@ -771,7 +771,7 @@ __device__ __forceinline__ void fir_stage_fft(const RenderParams &p, const float
 // traffic (y written and read once) and wins back what the fused kernel lost by running the limiter stages at two
 // workgroups per CU and the hops of a stream one pass after the other.
 #ifndef IAMF_FFT_OCC
-#define IAMF_FFT_OCC 2   // workgroups per CU the stage kernel is compiled for (tools/fft_exp.sh: 3 = 168 registers)
+#define IAMF_FFT_OCC 2   // workgroups per CU the stage kernel is compiled for (tools/debug/fft_exp.sh: 3 = 168 registers)
 #endif
 template <int M, bool FAST2 = false>
 __global__ __launch_bounds__(256, IAMF_FFT_OCC) void fir_fft_kernel(const RenderParams p, float *gy, int64_t gy_stream_stride) {

@@ -13,7 +13,7 @@
 //                     u read as coalesced 1 KiB rows prefetched two blocks ahead, y written IN PLACE over u
 //                     (first version: y stored per stream, 64 scattered 16-byte transactions per store
 //                     instruction in front of the prefetch loads in the in-order memory pipe — 53 cycles per
-//                     step, 1.44 ms per 64-frame call; in place: see DESIGN.md 4.6);
+//                     step, 1.44 ms per 64-frame call; in place: see NOTEBOOK.md 4.6);
 //   the scaling (y * 0.5 or y / sqrt(n), both double expressions in the reference, h2m_rdr.c:1157-1163)
 //   is done by the render kernel where it reads the slot.
 // State per stream between calls: w[-1], w[-2], y[-1], y[-2] (lfe_filter_t's two histories).
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void lfe_chain_kernel(const LfeParams p) {
   // tools/gen_lfe_chain_asm.py): per step v_sub, v_sub and ONE v_pk_mul_f32 that makes b1*y and b2*y from y where it
   // lies in the output quad; registers by hand, loads a rotation ahead, stores in place.  (As C++ the same loop is
   // 4.65 instruction slots per step: the compiler pairs the two products too and pays with copies into aligned pairs
-  // and into the store's quad)
+  // and into the store's quad, NOTEBOOK.md 4.6.)
   int q_done = 0;
   {
     const int nrot = nfull / IAMF_LFE_RING;

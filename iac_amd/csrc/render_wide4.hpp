@@ -43,7 +43,7 @@ __host__ __device__ constexpr int wide4_base_floats(int c, int m, int extra) {
          extra;  // 0, kW4DmxFloats or kW4MixFloats
 }
 // Workgroups per CU the kernel is sized for.  The kernels are bound by (chunk latency) x (workgroups resident per
-// CU) — DESIGN.md 4.3 — so the light variants (no demixer / mixer, at most 12 output channels) are kept within a third
+// CU) — NOTEBOOK.md 4.3 — so the light variants (no demixer / mixer, at most 12 output channels) are kept within a third
 // of the CU: <= 52 KiB of LDS here, <= 168 VGPRs by themselves or (M, C <= 12: the 7.1.4 -> 7.1.4 VALU variant sits at
 // 171) by __launch_bounds__; asking the same of the 16-input and down-mixer variants makes them spill.
 __host__ __device__ constexpr int wide4_wgs(int c, int extra) { return (extra == 0 && c <= 12) ? 3 : 2; }
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
               // which is what lets the compiler wait for the prefetched input with a COUNTED s_waitcnt
               // vmcnt(5 + stores) at the top of the loop instead of vmcnt(0): vector-memory operations retire in
               // order, and vmcnt(0) there drained this chunk's PCM stores — a store round trip (~2 us) exposed
-              // on every chunk, 25-35 % of cfg2 / cfg3 (tools/w4_exp.sh).
+              // on every chunk, 25-35 % of cfg2 / cfg3 (tools/debug/w4_exp.sh).
               // (the dump address is rebuilt from the per-chunk thread index: two registers that do not stay live)
               uint8_t *to = emit ? pcm + (uint32_t)((rel + lead) * (C * 2) + k * 16)
                                  : p.dump + (uint32_t)((s * 256 + tv) * 16);

@@ -357,7 +357,7 @@ const char *iamf_hip_version(void);
 int iamf_hip_probe_traffic(int n_streams, int chunks, int rows, int pieces, const void *d_in,
                            int64_t in_stream_stride_bytes, void *d_out, int64_t out_stream_stride_bytes,
                            void *stream);
-/* Where the stream buffers live matters: a batch whose input and PCM output lie in
+/* Where the stream buffers live matters (NOTEBOOK.md 3): a batch whose input and PCM output lie in
  * device-memory regions of the same kind runs ~14 % slower than one whose buffers lie in regions of different kinds,
  * and hipMalloc does not say which is which.  This times iamf_hip_probe_traffic on every (input candidate, output
  * candidate) pair — one untimed and three timed launches each, the median — and reports the fastest pair in

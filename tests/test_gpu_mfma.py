@@ -35,7 +35,7 @@ def test_mfma_projection_pcm_within_1lsb(hip, order, out):
     assert got.shape == want.shape
     d = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert d.max() <= 1, (order, out, int(d.max()))
-    # measured on the bench programme (tools/flip_rates.py): 0.013-0.018 % of PCM words, always 1 LSB
+    # measured on the bench programme (tools/debug/flip_rates.py): 0.013-0.018 % of PCM words, always 1 LSB
     assert (d != 0).mean() < 0.005  # only rounding ties may move
 
 

@@ -3,7 +3,7 @@
 n_devices = 1 must be the plain batch bit for bit, and the gather — ncclCommInitAll over the shard's devices, ncclSend /
 ncclRecv in one group on the gather stream, RCCL loaded with dlopen — must have executed at least once before the first
 8-GPU run: with one device the root sends to and receives from itself.  (The 8-GPU scaling itself cannot be measured on
-this pool; DESIGN.md 6 says so.)"""
+this pool; NOTEBOOK.md 6 says so.)"""
 import ctypes as C
 
 import numpy as np

@@ -1,6 +1,6 @@
-// device_class_probe.hip — what distinguishes the "fast" and "slow" MI355X devices of DESIGN.md 5?  Plain grid-stride
+// device_class_probe.hip — what distinguishes the "fast" and "slow" MI355X devices of NOTEBOOK.md 5?  Plain grid-stride
 // read / write / copy of 2 GiB against the render kernels' one-workgroup-per-stream traffic shapes, in one run.
-//   hipcc --offload-arch=gfx950 -O3 tools/device_class_probe.hip -o /tmp/dcp && /tmp/dcp
+//   hipcc --offload-arch=gfx950 -O3 tools/debug/device_class_probe.hip -o /tmp/dcp && /tmp/dcp
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

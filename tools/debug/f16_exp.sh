@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing-only elimination builds of render_fir16.hpp (IAMF_F16_EXP=n, WRONG results by construction):
-#   tools/f16_exp.sh build  -> iac_amd/lib/f16exp<n>/libiamf_hip.so        (run in the authoring container)
-#   tools/f16_exp.sh run    -> gpurun_out/f16_exp.txt: product and every variant on the HRTF workload, same box
+#   tools/debug/f16_exp.sh build  -> iac_amd/lib/f16exp<n>/libiamf_hip.so        (run in the authoring container)
+#   tools/debug/f16_exp.sh run    -> gpurun_out/f16_exp.txt: product and every variant on the HRTF workload, same box
 set -e
 cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then

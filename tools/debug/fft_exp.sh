@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing-only elimination builds of render_fir_fft.hpp (IAMF_FFT_EXP=n, WRONG results by construction):
-#   tools/fft_exp.sh build  -> iac_amd/lib/fftexp<n>/libiamf_hip.so        (run in the authoring container)
-#   tools/fft_exp.sh run    -> gpurun_out/fft_exp.txt: product and every variant on the HRTF workload, same box
+#   tools/debug/fft_exp.sh build  -> iac_amd/lib/fftexp<n>/libiamf_hip.so        (run in the authoring container)
+#   tools/debug/fft_exp.sh run    -> gpurun_out/fft_exp.txt: product and every variant on the HRTF workload, same box
 set -e
 cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then

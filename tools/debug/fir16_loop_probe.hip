@@ -2,7 +2,7 @@
 // step, two operand sets, one wave per SIMD and workgroup, WGS workgroups per CU.  Reports, per variant, shader
 // cycles per MFMA per SIMD (s_memtime), the in-kernel clock (s_memtime / s_memrealtime) and wall time: what the
 // loop can reach with nothing else in the kernel, and at which clock.
-//   hipcc -O3 --offload-arch=gfx950 tools/fir16_loop_probe.hip -o gpurun_out/fir16_loop_probe && gpurun_out/fir16_loop_probe
+//   hipcc -O3 --offload-arch=gfx950 tools/debug/fir16_loop_probe.hip -o gpurun_out/fir16_loop_probe && gpurun_out/fir16_loop_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -2,7 +2,7 @@
 // runs it (256 threads, 66 KB of LDS so that two workgroups share a CU, 16 passes of 4096 samples, 256 taps),
 // with s_memtime stamps around its phases (hooks IAMF_F16_STAMP in the header).  Prints, per phase, the median over
 // waves of the cycles spent there, the in-kernel clock and the wall time.
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/fir16_stage_probe.hip -o /tmp/p && /tmp/p [streams]
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/debug/fir16_stage_probe.hip -o /tmp/p && /tmp/p [streams]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

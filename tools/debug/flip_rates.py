@@ -2,7 +2,7 @@
    cfg3:  TOA -> Sound System H, PROJ_AUTO (f32 MFMA, k-ordered fma chain) vs PROJ_EXACT (the reference's separately
           rounded multiply and add), bench "hot" programme, s16
    N3:    projection-mode TOA -> binaural / 5.1, PROJ_AUTO (one composed matrix) vs PROJ_EXACT (two exact stages)
-Prints the fraction of PCM words that differ and the largest difference.   python tools/flip_rates.py"""
+Prints the fraction of PCM words that differ and the largest difference.   python tools/debug/flip_rates.py"""
 import os
 import sys
 

@@ -1,7 +1,7 @@
 // hbm_read_probe.hip — how fast can the render kernel's HBM access pattern go with no compute?
 // Same geometry as render_fast_kernel<16,2>: one 256-thread workgroup per stream, per 1024-sample
 // chunk every thread reads 16 x 16 B (16 channel rows, 4 KiB apart) and writes 16 B.
-//   hipcc --offload-arch=gfx950 -O3 tools/hbm_read_probe.hip -o gpurun_out/hbm_probe && ./hbm_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/debug/hbm_read_probe.hip -o gpurun_out/hbm_probe && ./hbm_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,6 +1,6 @@
 // Probe: ds_read_b128 from LDS addresses that are not 16-byte aligned (gfx950, unaligned access
 // mode).  (1) data check at 2-byte granularity; (2) throughput: 8 independent reads per iteration,
-// lane l at byte l*16 + mis, for mis = 0, 2, 4, 8.   Result on MI355X: see DESIGN.md 4.2.
+// lane l at byte l*16 + mis, for mis = 0, 2, 4, 8.   Result on MI355X: see NOTEBOOK.md 4.2.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

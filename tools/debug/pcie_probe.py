@@ -2,7 +2,7 @@
 """PCIe-inclusive rate of the batch path: host-resident element PCM -> H2D -> render -> D2H of the
 packed PCM, double-buffered on two HIP streams so that the copies of one step overlap the render
 of the other.  NOT what bench.py reports (its inputs are resident in HBM); this number goes into
-DESIGN.md as the rate a host-fed deployment sees.  Run on the GPU box:  python tools/pcie_probe.py"""
+DESIGN.md as the rate a host-fed deployment sees.  Run on the GPU box:  python tools/debug/pcie_probe.py"""
 import json
 import os
 import sys

@@ -1,7 +1,7 @@
 """Does the headline's rate depend on WHERE the input lies and on the stream stride?  One process, quiet
 and hot programmes (512 streams x 64 frames x 1024), for several paddings of the stream stride and several
 fresh allocations of the same size (a spacer allocation of varying size shifts the base address).
-   python tools/placement_probe.py > gpurun_out/placement.txt"""
+   python tools/debug/placement_probe.py > gpurun_out/placement.txt"""
 import os
 import sys
 

@@ -1,4 +1,4 @@
-"""Which buffer's placement makes the headline bimodal (tools/placement_probe.py: ~79 or ~90 Gsamples/s quiet
+"""Which buffer's placement makes the headline bimodal (tools/debug/placement_probe.py: ~79 or ~90 Gsamples/s quiet
 for the same stride and the same low address bits)?  Re-allocate ONE of {input, PCM, batch state} at a time."""
 import os
 import sys

@@ -1,7 +1,7 @@
-// placement_read_probe.hip — is the slow / fast mode of an allocation (tools/placement_probe*.py) visible to a
+// placement_read_probe.hip — is the slow / fast mode of an allocation (tools/debug/placement_probe*.py) visible to a
 // plain streaming read that saturates HBM (grid-stride float4 loads, 2048 workgroups, nothing else)?
 // A large early arena, then fresh 2.1 GB allocations; GB/s of reading 2.1 GB from each.
-//   hipcc --offload-arch=gfx950 -O3 tools/placement_read_probe.hip -o tools/bin/placement_read_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/debug/placement_read_probe.hip -o tools/bin/placement_read_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

@@ -1,6 +1,6 @@
-// placement_va_probe.hip — the two placement modes of DESIGN.md 3 outside the bench: a dozen 2.1 GB allocations of the
+// placement_va_probe.hip — the two placement modes of NOTEBOOK.md 3 outside the bench: a dozen 2.1 GB allocations of the
 // input (kept alive), the headline traffic shape timed on each, with the virtual address hipMalloc returned.
-//   hipcc --offload-arch=gfx950 -O3 tools/placement_va_probe.hip -o /tmp/pvp && /tmp/pvp
+//   hipcc --offload-arch=gfx950 -O3 tools/debug/placement_va_probe.hip -o /tmp/pvp && /tmp/pvp
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the resampler kernel (iamf_resample.hip): S streams x ch channels x ns input samples
-per call, interleaved f32 in HBM.   python tools/resample_probe.py [in_rate out_rate]"""
+per call, interleaved f32 in HBM.   python tools/debug/resample_probe.py [in_rate out_rate]"""
 import os
 import sys
 import time

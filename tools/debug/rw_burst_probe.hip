@@ -9,8 +9,8 @@
 //          are one contiguous 2 MiB region instead of 512 regions 256 KiB apart
 //   w0     the burst issued by wave 0 alone (through LDS): 4 x K KiB contiguous per wave-instruction sequence
 // First the plain shape is timed on every (input, output) allocation pair to find a FAST and a SLOW pair on this card
-// ("kinds of region"); the variants run on both.
-//   hipcc --offload-arch=gfx950 -O3 tools/rw_burst_probe.hip -o tools/bin/rw_burst_probe
+// (NOTEBOOK §3: "kinds of region"); the variants run on both.
+//   hipcc --offload-arch=gfx950 -O3 tools/debug/rw_burst_probe.hip -o tools/bin/rw_burst_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

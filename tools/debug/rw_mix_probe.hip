@@ -4,7 +4,7 @@
 //   cfg2: ROWS 12, PIECES 6 (72 B per sample-frame)    cfg3: ROWS 16, PIECES 12 (112 B)    headline: 16, 1
 // Variants: stores off / plain / non-temporal; stores issued right after the loads or at the end of the iteration
 // behind a dependent delay (as the kernel does: limiter phases between prefetch and stores).
-//   hipcc --offload-arch=gfx950 -O3 tools/rw_mix_probe.hip -o tools/bin/rw_mix_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/debug/rw_mix_probe.hip -o tools/bin/rw_mix_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

@@ -1,7 +1,7 @@
-// store_policy_probe.hip — the render kernels' traffic shape (tools/rw_mix_probe.hip) with every cache-policy
+// store_policy_probe.hip — the render kernels' traffic shape (tools/debug/rw_mix_probe.hip) with every cache-policy
 // combination gfx950 offers on the STORES (sc0 / sc1 / nt bits) and two on the loads: does any of them lift the
 // read + write regime above what plain / non-temporal stores reach?
-//   hipcc --offload-arch=gfx950 -O3 tools/store_policy_probe.hip -o /tmp/spp && /tmp/spp
+//   hipcc --offload-arch=gfx950 -O3 tools/debug/store_policy_probe.hip -o /tmp/spp && /tmp/spp
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

@@ -1,7 +1,7 @@
 // sweep_probe.hip — cycles per step of the limiter's trigger-run recurrence
 //   G <- shr(G) - a1 * (shr(G) - ep)
 // for different ways of moving G one lane up (tools only; not part of the library).
-//   hipcc -O3 --offload-arch=gfx950 -o /tmp/sweep_probe tools/sweep_probe.hip && /tmp/sweep_probe
+//   hipcc -O3 --offload-arch=gfx950 -o /tmp/sweep_probe tools/debug/sweep_probe.hip && /tmp/sweep_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 

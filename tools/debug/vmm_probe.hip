@@ -1,9 +1,9 @@
-// vmm_probe.hip — can a large stream buffer be ASSEMBLED from device-memory chunks of one kind?
+// vmm_probe.hip — can a large stream buffer be ASSEMBLED from device-memory chunks of one kind (NOTEBOOK.md 3)?
 // Physical 2 GiB chunks from hipMemCreate, each mapped on its own and classified by the headline traffic shape
 // against one small reference output (fast = another kind than the reference, slow = the reference's kind); then
 // a 14 GiB input made of "fast" chunks and an 8 GiB output made of "slow" chunks (= a clean different-kind pair), the
 // opposite assignment, and plain hipMalloc buffers, all timed with the cfg3 shape at 2048 streams.
-//   hipcc --offload-arch=gfx950 -O3 tools/vmm_probe.hip -o /tmp/vmm && /tmp/vmm
+//   hipcc --offload-arch=gfx950 -O3 tools/debug/vmm_probe.hip -o /tmp/vmm && /tmp/vmm
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing-only elimination builds of render_wide4.hpp (IAMF_W4_EXP=n, WRONG results by construction):
-#   tools/w4_exp.sh build   -> iac_amd/lib/exp<n>/libiamf_hip.so for n = 1..4   (run in the authoring container)
-#   tools/w4_exp.sh run     -> gpurun_out/w4_exp.txt: product and every variant on cfg2 / cfg3, quiet and hot, same box
+#   tools/debug/w4_exp.sh build   -> iac_amd/lib/exp<n>/libiamf_hip.so for n = 1..4   (run in the authoring container)
+#   tools/debug/w4_exp.sh run     -> gpurun_out/w4_exp.txt: product and every variant on cfg2 / cfg3, quiet and hot, same box
 set -e
 cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then

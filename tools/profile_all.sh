@@ -17,7 +17,7 @@ for WS in ${WORKLOADS:-toa_binaural_limiter_s16:512 714_ssJ_limiter_s16:3072 toa
   W=${WS%%:*}; S=${WS##*:}
   P=$R/gpurun_out/prof_$W
   rm -rf "$P"
-  # the placement search of the default line: the timed launches run on the buffers the bench line is measured on
+  # the placement search of the default line (NOTEBOOK.md 3): the timed launches run on the buffers the bench line is measured on
   CMD="bench.py --workload $W --streams $S --no-cpu-baseline --no-extra-configs --no-verify --no-facade --repeats 1 --steps 10 --warmup 2"
   rocprofv3 --kernel-trace --stats -d "$P/trace" -o t --output-format csv -- python3 $R/$CMD > "$P.trace.log" 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$P/pmc_fetch" -o t --output-format csv -- python3 $R/$CMD > "$P.fetch.log" 2>&1

@@ -38,7 +38,7 @@ def main():
             e = {"dispatches": n, "avg_ns_under_counters": dur[k] / n}
             if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) > 0 and dur[k] > 0:
                 # busy cycles of the matrix pipes against the dispatch's own duration at the nominal 2.4 GHz (the card holds
-                # ~2.1 under load: DESIGN 4.2) — the convention of DESIGN 4.2's "69 % busy"
+                # ~2.1 under load: NOTEBOOK 4.2) — the convention of NOTEBOOK 4.2's "69 % busy"
                 e["mfma_busy_frac_at_2p4GHz"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (dur[k] * 2.4), 4)
             for c, x in sorted(v.items()):
                 e[c + "_per_dispatch"] = x / n

@@ -1,7 +1,7 @@
 """How often and how long the limiter re-triggers on bench.py's synthetic programmes (CPU model of the
 reference's recurrence, audio_effect_peak_limiter.c:237-265, on the bench's own signal recipe).
 A "run" = maximal stretch of consecutive trigger samples = what the kernels' chain wave walks serially.
-Round-2 finding: runs are LONG (~240 samples = the look-ahead) but RARE - hot headline 0.2
+Round-2 finding (NOTEBOOK.md 4): runs are LONG (~240 samples = the look-ahead) but RARE - hot headline 0.2
 per 1024-sample chunk (3.4 % of samples), sparse 0.7, cfg2 hot 0.5 - so the chain is about 7 % / 20 % /
 12 % of a stream's time, not what bounds it.      python tools/trigger_stats.py"""
 import sys, numpy as np
