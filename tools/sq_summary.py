@@ -37,9 +37,9 @@ def main():
             wc = v.get("SQ_WAVE_CYCLES", 0.0) or 1.0
             e = {"dispatches": n, "avg_ns_under_counters": dur[k] / n}
             if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) > 0 and dur[k] > 0:
-                # busy cycles of the matrix pipes against the dispatch's own duration at the nominal 2.4 GHz (the card holds
-                # ~2.1 under load: NOTEBOOK 4.2) — the convention of NOTEBOOK 4.2's "69 % busy"
-                e["mfma_busy_frac_at_2p4GHz"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (dur[k] * 2.4), 4)
+                # busy cycles of the matrix pipes, summed by the counter over the chip's 1024 SIMDs (256 CUs x 4), against the
+                # dispatch's own duration at the nominal 2.4 GHz (the card holds ~2.1 under load; NOTEBOOK 4.2's "69 % busy")
+                e["mfma_busy_frac_at_2p4GHz"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (dur[k] * 2.4 * 1024), 4)
             for c, x in sorted(v.items()):
                 e[c + "_per_dispatch"] = x / n
                 if c != "SQ_WAVE_CYCLES" and not c.startswith("SQ_INSTS") and c != "SQ_VALU_MFMA_BUSY_CYCLES":
