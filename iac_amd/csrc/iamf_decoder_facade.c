@@ -247,6 +247,8 @@ struct IAMF_Decoder {
   float *tmp; /* [MAX_SUBSTREAMS * 2][frame_size] unpack scratch */
   iamf_hip_dmx_frame *h_dmx; /* pinned */
   void *h_pcm; /* pinned: the render kernels write it, decode copies the caller's share out */
+  volatile uint32_t *h_done; /* pinned word a one-lane kernel writes behind the frame's launches (facade_wait) */
+  uint32_t done_seq;
   size_t pcm_cap;
   hipStream_t stream;
   int flushed;
@@ -869,6 +871,8 @@ static void free_runtime(struct IAMF_Decoder *d) {
   if (d->h_demix) (void)hipHostFree(d->h_demix);
   d->h_demix = 0;
   if (d->h_pcm) (void)hipHostFree(d->h_pcm);
+  if (d->h_done) (void)hipHostFree((void *)d->h_done);
+  d->h_done = 0;
   d->d_mid = d->d_res = 0;
   d->h_dmx = 0;
   d->h_pcm = 0;
@@ -1225,6 +1229,9 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   if (hipHostMalloc((void **)&d->h_dmx, sizeof(iamf_hip_dmx_frame), 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
   d->pcm_cap = (size_t)4 * ((size_t)d->info.max_frame_size * d->pcm_stride + d->pcm_extra);
   if (hipHostMalloc(&d->h_pcm, d->pcm_cap, 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+  if (hipHostMalloc((void **)&d->h_done, 64, 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+  *d->h_done = 0;
+  d->done_seq = 0;
   d->gain_set[0] = d->gain_set[1] = 1.f; /* what iamf_hip_batch_create starts with */
   if (resample) {
     int cap = iamf_hip_resampler_out_capacity(d->rs, (int)d->frame_size) + 512;
@@ -1432,6 +1439,20 @@ static int tu_complete(const struct IAMF_Decoder *d) { /* IAMF_decoder.c:2854-28
   return 1;
 }
 
+/* Wait for what this call queued on the handle's stream.  A frame is ~10 us of device work: a one-lane kernel behind it
+ * writes a pinned word and the host spins on it (14.8 instead of 18.1 us per launch-and-wait on MI355X,
+ * tools/debug/sync_probe.hip); a spin that gets long — or IAMF_HIP_FACADE_SYNC=1 — ends in hipStreamSynchronize, which is
+ * also what reports a device error. */
+static int facade_wait(struct IAMF_Decoder *d) {
+  static int plain = -1;
+  if (plain < 0) plain = getenv("IAMF_HIP_FACADE_SYNC") ? 1 : 0;
+  if (!plain && d->h_done && iamf_hip_stream_signal(d->stream, d->h_done, ++d->done_seq) == IAMF_HIP_OK) {
+    for (int spin = 0; spin < 400000; ++spin)
+      if (*d->h_done == d->done_seq) return IAMF_OK;
+  }
+  return hipStreamSynchronize(d->stream) == hipSuccess ? IAMF_OK : IAMF_ERR_INTERNAL;
+}
+
 /* time_transform, IAMF_decoder.c:91-95 */
 static int64_t time_transform(int64_t t1, int s1, int s2) {
   double r;
@@ -1596,7 +1617,7 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     n = n2 ? iamf_hip_batch_render(d->batch3, d->d_res, 0, d->out_channels, n2, d->h_pcm, (int64_t)d->pcm_cap, d->stream) : 0;
   }
   if (n < 0) return IAMF_ERR_INTERNAL;
-  if (hipStreamSynchronize(d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
+  if (facade_wait(d)) return IAMF_ERR_INTERNAL;
   if (n > 0) memcpy(pcm, d->h_pcm, ((size_t)n * d->pcm_stride + d->pcm_extra) * bytes);
   params_time_elapse(d, (uint64_t)keep); /* IAMF_decoder.c:3471: the mixed frame's length */
   d->timestamp += fs;
@@ -1634,7 +1655,7 @@ static int flush_tail(struct IAMF_Decoder *d, void *pcm) { /* iamf_delay_buffer_
     n = (n2 + extra) ? iamf_hip_batch_render(d->batch3, d->d_res, 0, d->out_channels, n2 + extra, d->h_pcm, (int64_t)d->pcm_cap, d->stream) : 0;
   }
   if (n < 0) return IAMF_ERR_INTERNAL;
-  if (hipStreamSynchronize(d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
+  if (facade_wait(d)) return IAMF_ERR_INTERNAL;
   if (n > 0) memcpy(pcm, d->h_pcm, ((size_t)n * d->pcm_stride + d->pcm_extra) * bytes);
   meta_note_output(d, n);
   return n;

@@ -78,7 +78,19 @@ __global__ __launch_bounds__(256) void upload_kernel(const u32x4 *__restrict__ s
   if (i < n16) dst[i] = __builtin_nontemporal_load(src + i);
 }
 
+// one lane, one word of pinned host memory behind a system-scope fence: "everything queued on this stream before me is done"
+__global__ void signal_kernel(volatile uint32_t *flag, uint32_t seq) {
+  __threadfence_system();
+  *flag = seq;
+}
+
 }  // namespace
+
+extern "C" int iamf_hip_stream_signal(void *stream, volatile uint32_t *h_pinned_flag, uint32_t seq) {
+  if (!h_pinned_flag) return IAMF_HIP_ERR_BAD_ARG;
+  hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), h_pinned_flag, seq);
+  return hipGetLastError() == hipSuccess ? IAMF_HIP_OK : IAMF_HIP_ERR_DEVICE;
+}
 
 extern "C" int iamf_hip_upload_by_kernel(const void *h_pinned, void *d_dst, size_t bytes, void *stream) {
   if (!h_pinned || !d_dst || !bytes || (bytes & 15) || ((uintptr_t)h_pinned & 15) || ((uintptr_t)d_dst & 15)) return IAMF_HIP_ERR_BAD_ARG;

@@ -501,6 +501,12 @@ int iamf_hip_batch_render_lpcm_range(iamf_hip_batch *b, const iamf_hip_lpcm_inpu
  * MI355X; the kernel moves 8 MB as fast as the engine).  Both pointers 16-byte aligned, `bytes` a multiple of 16.
  * IAMF_HIP_OK, IAMF_HIP_ERR_BAD_ARG or IAMF_HIP_ERR_DEVICE. */
 int iamf_hip_upload_by_kernel(const void *h_pinned, void *d_dst, size_t bytes, void *stream);
+/* A one-lane kernel on `stream` that stores `seq` to a word of PINNED host memory behind a system-scope fence: a host
+ * that has just queued a few microseconds of work and wants its result spins on the word instead of calling
+ * hipStreamSynchronize (MI355X, tools/debug/sync_probe.hip: 14.8 instead of 18.1 us per launch-and-wait).  What was queued
+ * before it on the stream has completed and is visible to the host when the word reads `seq`.  The caller bounds its
+ * spin and falls back to hipStreamSynchronize (which also reports a device error).  IAMF_HIP_OK / _BAD_ARG / _DEVICE. */
+int iamf_hip_stream_signal(void *stream, volatile uint32_t *h_pinned_flag, uint32_t seq);
 
 /* ------------------------------------------------------------------------------------------
  * A group of decoder handles: callers of the reference API get the batch renderer's throughput.

@@ -136,6 +136,7 @@ int iamf_hip_batch_flush_range(iamf_hip_batch *b, void *pcm, int64_t cap, void *
 int iamf_hip_batch_flush(iamf_hip_batch *b, void *pcm, int64_t cap, void *st) {
   return iamf_hip_batch_flush_range(b, pcm, cap, st, 0, b->cfg.n_streams);
 }
+int iamf_hip_stream_signal(void *st, volatile uint32_t *flag, uint32_t seq) { (void)st; *flag = seq; return IAMF_HIP_OK; }
 int iamf_hip_upload_by_kernel(const void *h, void *d, size_t n, void *st) {
   (void)st;
   if (!h || !d || !n || (n & 15)) return IAMF_HIP_ERR_BAD_ARG;
