@@ -142,6 +142,11 @@ def lib():
         L.iamf_hip_resampler_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                                  C.c_void_p]
         L.iamf_hip_resampler_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.iamf_hip_resampler_process_range.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                                       C.c_void_p, C.c_int32, C.c_int32]
+        L.iamf_hip_resampler_flush_range.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32]
+        L.iamf_hip_resampler_same_state.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.iamf_hip_stream_signal.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.iamf_hip_batch_set_projection.argtypes = [C.c_void_p, FP, C.c_int]
         L.iamf_hip_lpcm_unpack.argtypes = [C.POINTER(LpcmLayout), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_int64, C.c_int32, C.c_void_p]
@@ -380,6 +385,16 @@ class Resampler:
         if r < 0:
             raise IamfHipError(r, "iamf_hip_resampler_flush")
         return r
+
+    def process_range(self, d_in, in_stride, ns, d_out, out_stride, s0, cnt, stream=None):
+        """streams [s0, s0 + cnt) only (they must be in one state); returns the library's value, errors included"""
+        return lib().iamf_hip_resampler_process_range(self.h, d_in, in_stride, ns, d_out, out_stride, stream, s0, cnt)
+
+    def flush_range(self, d_out, out_stride, s0, cnt, stream=None):
+        return lib().iamf_hip_resampler_flush_range(self.h, d_out, out_stride, stream, s0, cnt)
+
+    def same_state(self, a, b):
+        return bool(lib().iamf_hip_resampler_same_state(self.h, a, b))
 
     def close(self):
         if self.h:

@@ -313,6 +313,70 @@ def test_resampler_goldens_bit_exact(hip, golden):
         assert np.array_equal(np.concatenate(outs[1], axis=1).view(np.uint32), y1.view(np.uint32)), name
 
 
+@pytest.mark.parametrize("rates", [(44100, 48000), (16000, 48000), (48000, 44100)])
+def test_resampler_streams_out_of_step_by_ranges(hip, rates):
+    """round 4: one resampler, five streams that consume DIFFERENT sequences of call lengths through range calls (what a
+    group of decoder handles does): each stream's phase and history are its own, so every stream's output must be the
+    oracle's for ITS sequence; a range across streams in different states is refused, same_state says which are alike"""
+    A, G, torch = hip
+    ch, S = 2, 5
+    plans = [[300, 1024, 77, 1024], [1024, 512, 300, 64], [300, 1024, 77, 1024], [512, 512, 512, 889], [1024, 512, 300, 64]]   # (a stream's state is a function of the samples it has consumed: the three plans differ in every running total)
+    xs = [synth.hot(7700 + s, ch, sum(plans[s]), sigma=0.3, burst_amp=1.1, burst_len=50, burst_phase=40, burst_period=600) for s in range(S)]
+    r = A.Resampler(S, ch, rates[0], rates[1])
+    st = torch.cuda.current_stream().cuda_stream
+    cap = r.out_capacity(1024)
+    outs, pos = [[] for _ in range(S)], [0] * S
+    for step in range(4):
+        # streams with equal call length this step AND equal history of lengths form the ranges: {0, 2}, {1, 4}, {3}
+        inter = torch.zeros((S, 1024, ch), dtype=torch.float32, device="cuda")
+        for s in range(S):
+            ns = plans[s][step]
+            inter[s, :ns] = torch.from_numpy(np.ascontiguousarray(xs[s][:, pos[s]:pos[s] + ns].T)).cuda()
+        o = torch.zeros((S, cap, ch), dtype=torch.float32, device="cuda")
+        if step > 0 and rates[1] % rates[0]:   # (1 : 3 leaves every stream in the same phase after any whole call)
+            assert r.same_state(0, 2) and r.same_state(1, 4) and not r.same_state(0, 1)
+            assert r.process_range(inter.data_ptr(), 1024 * ch, 300, o.data_ptr(), cap * ch, 0, 2, st) == -5   # streams 0 and 1 differ
+        got = {}
+        for s0, cnt in ((0, 1), (2, 1), (1, 1), (4, 1), (3, 1)) if step == 0 else ((0, 1), (1, 1), (2, 1), (3, 1), (4, 1)):
+            got[s0] = r.process_range(inter.data_ptr(), 1024 * ch, plans[s0][step], o.data_ptr(), cap * ch, s0, cnt, st)
+            assert got[s0] >= 0, got[s0]
+        torch.cuda.synchronize()
+        h = o.cpu().numpy()
+        for s in range(S):
+            outs[s].append(h[s, :got[s]].T.copy())
+            pos[s] += plans[s][step]
+    o = torch.zeros((S, max(r.flush_capacity(), 1), ch), dtype=torch.float32, device="cuda")
+    n02 = r.flush_range(o.data_ptr(), o.shape[1] * ch, 0, 1, st)
+    tails = {0: n02}
+    for s in range(1, S):
+        tails[s] = r.flush_range(o.data_ptr(), o.shape[1] * ch, s, 1, st)
+    torch.cuda.synchronize()
+    h = o.cpu().numpy()
+    r.close()
+    for s in range(S):
+        outs[s].append(h[s, :tails[s]].T.copy())
+        want, _ = O.resample_run(xs[s], rates[0], rates[1], plans[s])
+        assert np.array_equal(np.concatenate(outs[s], axis=1).view(np.uint32), want.view(np.uint32)), s
+
+
+def test_stream_signal_writes_the_pinned_word_behind_the_queued_work(hip):
+    """iamf_hip_stream_signal (what the single-handle facade waits on instead of hipStreamSynchronize)"""
+    A, G, torch = hip
+    flag = torch.zeros(16, dtype=torch.int32).pin_memory()
+    big = torch.zeros(1 << 24, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for seq in (1, 2, 77):
+        big.add_(1.0)    # queued in front of the signal
+        assert A.lib().iamf_hip_stream_signal(st, flag.data_ptr(), seq) == 0
+        for _ in range(2000000):
+            if int(flag[0]) == seq:
+                break
+        assert int(flag[0]) == seq
+    torch.cuda.synchronize()
+    assert float(big[0]) == 3.0
+    assert A.lib().iamf_hip_stream_signal(st, None, 1) == -1
+
+
 def test_resampled_pipeline_vs_oracle(hip):
     """44.1 kHz stereo element -> Sound System A at 48 kHz: render (f32) -> resample -> limiter +
     pack as three launches, against the oracle's stages in the decoder's order
