@@ -127,7 +127,7 @@ def measured_mfma(workload, kernel_tags):
         for name, v in d.items():
             if any(t in name for t in tags) and "mfma_busy_frac_at_2p4GHz" in v:
                 return {"busy_frac": v["mfma_busy_frac_at_2p4GHz"], "kernel": name, "source": os.path.basename(f),
-                        "note": "SQ_VALU_MFMA_BUSY_CYCLES / (dispatch duration x 2.4 GHz), a separate rocprofv3 --pmc pass of this workload"}
+                        "note": "SQ_VALU_MFMA_BUSY_CYCLES / (dispatch duration x 2.4 GHz x 1024 SIMDs), a separate rocprofv3 --pmc pass of this workload"}
     return None
 
 
