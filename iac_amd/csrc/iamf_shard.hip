@@ -129,7 +129,13 @@ struct Dev {
   iamf_hip_batch *batch = nullptr;
   hipStream_t render = nullptr, gather = nullptr;
   hipEvent_t rendered = nullptr, gathered = nullptr;
-  hipEvent_t g_begin = nullptr, g_end = nullptr;   // (timing) around the device's share of the last gather
+  // (timing) around the device's share of a gather: a ring of pairs, so that closing the books of one gather never makes
+  // the host wait for it while the next is being issued (that wait would throttle the run-ahead of step i + 1's render)
+  static constexpr int kPairs = 4;
+  hipEvent_t g_begin[kPairs] = {}, g_end[kPairs] = {};
+  bool pending[kPairs] = {};   // pair k brackets a gather whose time is not yet in total_gather_ms
+  int g_cur = 0;               // the pair of the last gather
+  double last_gather_ms = 0.0;
   ncclComm_t comm = nullptr;
   Worker w;
   int result = 0;
@@ -140,7 +146,6 @@ struct Dev {
   // accounting (iamf_hip_shard_times)
   int64_t last_sent = 0, total_sent = 0, last_received = 0;
   double total_gather_ms = 0.0;
-  bool timed = false;   // g_begin / g_end of a gather not yet added to total_gather_ms
 };
 
 // room for `bytes` in a staging buffer of device d (current): reallocation waits for the gather stream, whose queued
@@ -157,12 +162,30 @@ int stage_room(Dev *d, void **buf, size_t *have, size_t bytes) {
 }
 
 // close the books of the last gather of device d (its events have completed, or are waited for): its time -> the total
-void settle_times(Dev *d) {
-  if (!d->timed) return;
-  float ms = 0.f;
-  if (hipEventSynchronize(d->g_end) == hipSuccess && hipEventElapsedTime(&ms, d->g_begin, d->g_end) == hipSuccess)
-    d->total_gather_ms += (double)ms;
-  d->timed = false;
+// wait == false: only the gathers that have completed (hipEventQuery), no blocking; true: all of them
+void settle_times(Dev *d, bool wait) {
+  for (int k = 0; k < Dev::kPairs; ++k) {
+    if (!d->pending[k]) continue;
+    if (!wait && hipEventQuery(d->g_end[k]) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventSynchronize(d->g_end[k]) == hipSuccess && hipEventElapsedTime(&ms, d->g_begin[k], d->g_end[k]) == hipSuccess) {
+      d->total_gather_ms += (double)ms;
+      if (k == d->g_cur) d->last_gather_ms = (double)ms;
+    }
+    d->pending[k] = false;
+  }
+}
+// the pair the next gather uses (if the ring has come round to a gather still in flight, that one is waited for)
+int next_pair(Dev *d) {
+  const int k = (d->g_cur + 1) % Dev::kPairs;
+  if (d->pending[k]) {
+    float ms = 0.f;
+    if (hipEventSynchronize(d->g_end[k]) == hipSuccess && hipEventElapsedTime(&ms, d->g_begin[k], d->g_end[k]) == hipSuccess)
+      d->total_gather_ms += (double)ms;
+    d->pending[k] = false;
+  }
+  d->g_cur = k;
+  return k;
 }
 
 }  // namespace
@@ -208,8 +231,10 @@ void iamf_hip_shard_destroy(iamf_hip_shard *s) {
       if (d->batch) iamf_hip_batch_destroy(d->batch);
       if (d->rendered) (void)hipEventDestroy(d->rendered);
       if (d->gathered) (void)hipEventDestroy(d->gathered);
-      if (d->g_begin) (void)hipEventDestroy(d->g_begin);
-      if (d->g_end) (void)hipEventDestroy(d->g_end);
+      for (int k = 0; k < Dev::kPairs; ++k) {
+        if (d->g_begin[k]) (void)hipEventDestroy(d->g_begin[k]);
+        if (d->g_end[k]) (void)hipEventDestroy(d->g_end[k]);
+      }
       if (d->pack) (void)hipFree(d->pack);
       if (d->unpack) (void)hipFree(d->unpack);
       if (d->render) (void)hipStreamDestroy(d->render);
@@ -258,11 +283,13 @@ int iamf_hip_shard_create(const iamf_hip_batch_config *cfg, const int *devices, 
     if (hipStreamCreateWithFlags(&d->render, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&d->gather, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&d->rendered, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&d->gathered, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreate(&d->g_begin) != hipSuccess || hipEventCreate(&d->g_end) != hipSuccess) {
+        hipEventCreateWithFlags(&d->gathered, hipEventDisableTiming) != hipSuccess) {
       rc = IAMF_HIP_ERR_DEVICE;
       break;
     }
+    for (int k = 0; k < Dev::kPairs && rc == IAMF_HIP_OK; ++k)
+      if (hipEventCreate(&d->g_begin[k]) != hipSuccess || hipEventCreate(&d->g_end[k]) != hipSuccess) rc = IAMF_HIP_ERR_DEVICE;
+    if (rc != IAMF_HIP_OK) break;
     d->w.device = d->device;
     d->w.start();
   }
@@ -387,8 +414,9 @@ int iamf_hip_shard_gather_rows(iamf_hip_shard *s, int root_index, void *d_dst, i
       err = 1;
       break;
     }
-    settle_times(d);
-    if (hipStreamWaitEvent(d->gather, d->rendered, 0) != hipSuccess || hipEventRecord(d->g_begin, d->gather) != hipSuccess) err = 1;
+    settle_times(d, false);
+    const int pair = next_pair(d);
+    if (hipStreamWaitEvent(d->gather, d->rendered, 0) != hipSuccess || hipEventRecord(d->g_begin[pair], d->gather) != hipSuccess) err = 1;
     wire[(size_t)i] = d_pcm[i];
     if (!err && pack_src && d->count > 1) {
       if (stage_room(d, &d->pack, &d->pack_bytes, row * (size_t)d->count) ||
@@ -424,14 +452,14 @@ int iamf_hip_shard_gather_rows(iamf_hip_shard *s, int root_index, void *d_dst, i
   }
   for (int i = 0; i < n; ++i) {   // always: a render that waits on `gathered` must find the latest state of the stream
     Dev *d = s->devs[i];
-    if (hipSetDevice(d->device) != hipSuccess || hipEventRecord(d->g_end, d->gather) != hipSuccess ||
+    if (hipSetDevice(d->device) != hipSuccess || hipEventRecord(d->g_end[d->g_cur], d->gather) != hipSuccess ||
         hipEventRecord(d->gathered, d->gather) != hipSuccess)
       err = 1;
     if (!err) {
       d->last_sent = (int64_t)d->count * bytes_per_stream;
       d->total_sent += d->last_sent;
       d->last_received = d == root ? (int64_t)s->n_streams * bytes_per_stream : 0;
-      d->timed = true;
+      d->pending[d->g_cur] = true;
     }
   }
   if (cur >= 0) (void)hipSetDevice(cur);
@@ -455,17 +483,14 @@ int iamf_hip_shard_times(iamf_hip_shard *s, int index, int64_t *last_sent_bytes,
   int cur = -1;
   (void)hipGetDevice(&cur);
   if (hipSetDevice(d->device) != hipSuccess) return IAMF_HIP_ERR_DEVICE;
-  float ms = 0.f;
   int rc = IAMF_HIP_OK;
-  if (d->g_end && (d->timed || d->total_sent > 0)) {
-    if (hipEventSynchronize(d->g_end) != hipSuccess || hipEventElapsedTime(&ms, d->g_begin, d->g_end) != hipSuccess) rc = IAMF_HIP_ERR_DEVICE;
-  }
-  settle_times(d);
+  settle_times(d, true);
+  const double ms = d->last_gather_ms;
   if (cur >= 0) (void)hipSetDevice(cur);
   if (last_sent_bytes) *last_sent_bytes = d->last_sent;
   if (total_sent_bytes) *total_sent_bytes = d->total_sent;
   if (last_received_bytes) *last_received_bytes = d->last_received;
-  if (last_gather_ms) *last_gather_ms = (double)ms;
+  if (last_gather_ms) *last_gather_ms = ms;
   if (total_gather_ms) *total_gather_ms = d->total_gather_ms;
   return rc;
 }

@@ -200,6 +200,11 @@ hipError_t hipEventSynchronize(hipEvent_t e) {
   e->cv.wait(lk, [e, target] { return e->completed >= target; });
   return hipSuccess;
 }
+hipError_t hipEventQuery(hipEvent_t e) {
+  if (!e) return hipErrorInvalidValue;
+  std::lock_guard<std::mutex> lk(e->mu);
+  return e->completed >= e->recorded ? hipSuccess : hipErrorNotReady;
+}
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
   if (!ms || !a || !b) return hipErrorInvalidValue;
   std::unique_lock<std::mutex> la(a->mu, std::defer_lock), lb(b->mu, std::defer_lock);

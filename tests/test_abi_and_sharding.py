@@ -246,6 +246,7 @@ def _run_shard(rehearsal, args, env_extra=None):
     (7, 2, 1, 3, None),             # N = 2
     (67, 8, 5, 4, None),            # N = 8
     (8, 8, 7, 2, "7,6,5,4,3,2,1,0"),   # one stream per device
+    (11, 3, 1, 9, None),            # more gathers in flight than the shard keeps timing event pairs for
 ])
 def test_shard_n_devices_gather_rows_beside_the_next_render(shard_rehearsal, streams, devices, root, steps, ordinals):
     out = _run_shard(shard_rehearsal, [streams, devices, root, steps, "rows"] + ([ordinals] if ordinals else []))
