@@ -57,3 +57,74 @@ def test_group_entry_points_validate_their_arguments_without_a_gpu():
     assert L.iamf_hip_decoder_group_create(harr, 0, 0, C.byref(g)) == -1
     assert L.iamf_hip_decoder_group_create(harr, 1, 0, C.byref(g)) == -5     # not configured: IAMF_ERR_INVALID_STATE
     assert L.IAMF_decoder_close(d) == 0
+
+
+# ---- IAMF_decoder_get_last_metadata is host logic: pinned on the CPU too ----
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = os.path.join(ROOT, "tests", "facade_stub")
+
+
+@pytest.fixture(scope="module")
+def stub_lib():
+    """the facade's plain-C host side linked against the device stand-ins (tests/facade_stub/device_stub.c: renders
+    nothing, reports the sample counts a render would) as a shared library"""
+    os.makedirs(os.path.join(STUB, "build"), exist_ok=True)
+    so = os.path.join(STUB, "build", "libfacade_stub.so")
+    srcs = [os.path.join(ROOT, "iac_amd", "csrc", "iamf_decoder_facade.c"), os.path.join(STUB, "device_stub.c")]
+    deps = srcs + [os.path.join(ROOT, "iac_amd", "csrc", "iamf_decoder_group.inc"), os.path.join(ROOT, "include", "iamf_hip.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in deps):
+        subprocess.check_call(["gcc", "-g", "-O1", "-std=gnu11", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+                               "-I/opt/rocm/include"] + srcs + ["-lm", "-lpthread", "-o", so])
+    return C.CDLL(so)
+
+
+def _meta_cases_without_resampler():
+    import e2e_cases
+    return sorted(n for n in e2e_cases.META_CASES if not e2e_cases.CASES[n].get("out_rate"))
+
+
+@pytest.mark.parametrize("name", _meta_cases_without_resampler())
+def test_get_last_metadata_rows_equal_the_reference_without_a_gpu(stub_lib, golden, name):
+    """The metadata call reports what the HOST side knows — clocks, the presentation's records, the demixing mode of the
+    frame — so the rows recorded from the real reference (tests/golden/meta.npz) must come out of the facade with the
+    device replaced by stand-ins too (the stand-ins emit the sample counts a render emits; streams that resample are
+    left to the GPU run, tests/test_gpu_facade.py: the stand-in resampler's counts are approximate)."""
+    import e2e_cases
+    from decoder_driver import decode_stream
+    case, mc = e2e_cases.CASES[name], e2e_cases.META_CASES[name]
+    stream, _ = e2e_cases.build(name)
+    md = dict(rows=[], owns_anchors=True, **{k: v for k, v in mc.items() if k != "pts"})
+    decode_stream(stub_lib, stream, case["layout"], bit_depth=case.get("bit_depth", 16), loudness=case.get("loudness", 0.0),
+                  limiter=case.get("limiter", True), threshold=case.get("threshold", -1.0), metadata=md, pts=mc["pts"])
+    want = golden.npz("meta")[name]
+    got = np.array(md["rows"], dtype=np.int64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert np.array_equal(g, w), (name, "row %d" % i, [int(v) for v in g if v != -9999], [int(v) for v in w if v != -9999])
+
+
+def _cases_for_the_stub():
+    import e2e_cases
+    return sorted(n for n, c in e2e_cases.CASES.items() if not c.get("out_rate"))
+
+
+@pytest.mark.parametrize("name", _cases_for_the_stub())
+def test_every_e2e_stream_configures_and_returns_the_reference_counts_without_a_gpu(stub_lib, golden, name):
+    """host protocol of every end-to-end stream (descriptor parsing, presentation and layer selection, the exchange of a
+    two-element presentation's entries, temporal-unit assembly, trims, the limiter's withheld 240, flush, reconfiguration at
+    a new IA sequence): IAMF_decoder_configure accepts it and every IAMF_decoder_decode call returns the count the
+    reference returned (tests/golden/e2e.npz `_rets`) — with the device replaced by stand-ins, so on any machine"""
+    import e2e_cases
+    from decoder_driver import decode_stream
+    case = e2e_cases.CASES[name]
+    stream, _ = e2e_cases.build(name)
+    pcm, rets = decode_stream(stub_lib, stream, case["layout"], bit_depth=case.get("bit_depth", 16), loudness=case.get("loudness", 0.0),
+                              limiter=case.get("limiter", True), threshold=case.get("threshold", -1.0))
+    assert list(rets) == list(golden.npz("e2e")[name + "_rets"]), name
+    assert pcm.shape == golden.npz("e2e")[name].shape
