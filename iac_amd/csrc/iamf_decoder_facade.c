@@ -182,6 +182,24 @@ typedef struct {
   anchor_loudness_t anchors[8][MAX_ANCHORS];
 } Presentation;
 
+/* The per-stream stage one element can need in front of its renderer: the demixer of a scalable / output-gained channel
+ * element (IAMF_decoder.c:2324-2386) or the parametric down-mixer (:2448-2478), with what the parameter blocks left for it */
+typedef struct {
+  int use_dmx, dmx_mode;
+  iamf_hip_dmx_state dmx;
+  int use_demix, demix_layer, demix_nsub, demix_nch;
+  iamf_hip_demix_state dmst;
+  uint32_t rec_flags;
+  int rec_n;
+  int32_t rec_ch[12];
+  float rec_gain[12];
+  uint32_t layer_rec_flags[MAX_LAYERS]; /* latest recon-gain block, per layer (ctx->conf_s[i].recon_gain) */
+  float layer_rec_gain[MAX_LAYERS][12];
+  iamf_hip_demix_frame *h_demix; /* pinned */
+  iamf_hip_dmx_frame *h_dmx;     /* pinned */
+  iamf_hip_demix_config dc_sig;  /* the demixer configuration, if use_demix */
+} Pre;
+
 struct IAMF_Decoder {
   /* user settings (IAMF_decoder.c:3726-3744, 3960-4130) */
   int out_type; /* IAMF_LayoutType */
@@ -204,24 +222,20 @@ struct IAMF_Decoder {
   int configured;
   Presentation *sel;
   Element *sel_el[2];
-  Param *el_gain_p[2], *out_gain_p, *demix_p;
+  Param *el_gain_p[2], *out_gain_p;
   IAMF_StreamInfo info;
   int out_channels;
   float mix_loudness;
   iamf_hip_batch *batch, *batch3; /* batch3: limiter stage behind the resampler */
   iamf_hip_resampler *rs;
-  iamf_hip_dmx_state dmx;
-  int use_dmx, dmx_mode;
-  /* demixer of a scalable (or gain-carrying) channel element 0 (IAMF_decoder.c:2324-2386) */
-  int use_demix, demix_layer, demix_nsub, demix_nch;
-  iamf_hip_demix_state dmst;
-  uint32_t rec_flags;
-  int rec_n;
-  int32_t rec_ch[12];
-  float rec_gain[12];
-  uint32_t layer_rec_flags[MAX_LAYERS]; /* latest recon-gain block, per layer (ctx->conf_s[i].recon_gain) */
-  float layer_rec_gain[MAX_LAYERS][12];
-  iamf_hip_demix_frame *h_demix; /* pinned */
+  Pre pre[2]; /* [0]: the stage in front of element 0 of `batch`; [1]: of element 1, in front of `aux` */
+  /* Both elements need a stage: element 1 is rendered (stage, matrix, its mix gain) by a batch of its own into f32 and
+   * handed to `batch` as a second element with the identity matrix and gain 1 (setup_pipeline) */
+  iamf_hip_batch *aux;
+  int dmx_last;      /* the element (batch order) whose down-mixer was opened last: dmx_shared_coefficients */
+  float dmx_static_s; /* the TL / TR factor the reference's shared table holds */
+  float *d_aux_il, *d_aux_pl; /* device: aux's frame as it writes it [sample][channel], and planar for `batch` */
+  float aux_gain_set;
   /* packets of the temporal unit being assembled */
   uint8_t *pkt[2][MAX_SUBSTREAMS];
   uint32_t pkt_len[2][MAX_SUBSTREAMS];
@@ -237,7 +251,7 @@ struct IAMF_Decoder {
   /* buffers */
   /* pinned host memory that the kernels read and write directly (a frame is 64 KB in, 4 KB out: over PCIe inside the
    * one render launch, instead of three copies around it — each ~9 us of call and ~12 us of engine hand-over) */
-  float *h_in[2], *h_ramp[3], *d_mid, *d_res;
+  float *h_in[2], *h_ramp[4], *d_mid, *d_res; /* ramps: element 0, element 1 for `batch`, output, element 1 for `aux` */
   /* element 0's packets as they are, pinned, for the fused LPCM form of the render kernel (iamf_hip_batch_render_lpcm):
    * one mono-coded ambisonics element in 16-bit little-endian LPCM into one or two channels with the limiter on */
   uint8_t *h_raw;
@@ -245,7 +259,6 @@ struct IAMF_Decoder {
   iamf_hip_lpcm_layout lp_layout;
   float gain_set[2]; /* element / output constant gains the batch holds (iamf_hip_batch_set_gains synchronises: only on change) */
   float *tmp; /* [MAX_SUBSTREAMS * 2][frame_size] unpack scratch */
-  iamf_hip_dmx_frame *h_dmx; /* pinned */
   void *h_pcm; /* pinned: the render kernels write it, decode copies the caller's share out */
   volatile uint32_t *h_done; /* pinned word a one-lane kernel writes behind the frame's launches (facade_wait) */
   uint32_t done_seq;
@@ -259,7 +272,6 @@ struct IAMF_Decoder {
   struct iamf_hip_decoder_group *group; /* the handle renders through a group's batch (iamf_decoder_group.inc) */
   iamf_hip_batch_config cfg_sig;        /* what setup_pipeline created the batch from (mat pointer zeroed) ... */
   const float *cfg_mat;                 /* ... and its matrix */
-  iamf_hip_demix_config dc_sig;         /* the demixer configuration, if use_demix */
   /* IAMF_decoder_get_last_metadata (IAMF_decoder.c:3619-3706,4150-4168) */
   uint64_t meta_duration;   /* ctx->duration: samples returned since IAMF_decoder_set_pts */
   int el_dmx_mode[2];       /* cctx->dmx_mode of the presentation's elements (batch order), -1 = none yet */
@@ -673,17 +685,18 @@ static int parse_parameter_block(struct IAMF_Decoder *d, const Obu *o) {
   p->use_default = 0;
   /* iamf_stream_decoder_update_parameter, IAMF_decoder.c:2141-2148: a recon-gain block updates the
    * per-layer gains from the segment covering the middle of the current frame */
-  if (p->type == IAMF_PARAMETER_TYPE_RECON_GAIN && d->sel_el[0] && d->sel_el[0]->has_recon &&
-      d->sel_el[0]->recon_pid == p->id) {
+  for (int e = 0; e < 2 && p->type == IAMF_PARAMETER_TYPE_RECON_GAIN; ++e) {
+    const Element *se = d->sel && e < d->sel->nel ? d->sel_el[e] : 0;
     const uint64_t pts = d->timestamp + d->frame_size / 2;
+    if (!se || !se->has_recon || se->recon_pid != p->id) continue;
     if (pts > p->timestamp && pts <= p->timestamp + p->duration) {
       uint64_t start = pts - p->timestamp;
       for (int i = 0; i < p->qn; ++i) {
         if (start < p->q[i].interval) { /* iamf_stream_scale_decoder_update_recon_gain, :2238-2274 */
-          for (int k = 0; k < d->sel_el[0]->nlayers; ++k) {
-            if (!d->sel_el[0]->layer[k].recon_flag) continue;
-            d->layer_rec_flags[k] = p->rq[i].flags[k];
-            memcpy(d->layer_rec_gain[k], p->rq[i].gain[k], sizeof(d->layer_rec_gain[k]));
+          for (int k = 0; k < se->nlayers; ++k) {
+            if (!se->layer[k].recon_flag) continue;
+            d->pre[e].layer_rec_flags[k] = p->rq[i].flags[k];
+            memcpy(d->pre[e].layer_rec_gain[k], p->rq[i].gain[k], sizeof(d->pre[e].layer_rec_gain[k]));
           }
           break;
         }
@@ -708,7 +721,7 @@ static int parse_parameter_block(struct IAMF_Decoder *d, const Obu *o) {
       }
     }
     d->el_dmx_mode[e] = mode;
-    if (e == 0) d->dmx_mode = mode; /* the element the batch's demixer / down-mixer serves */
+    d->pre[e].dmx_mode = mode; /* what the element's demixer / down-mixer takes at its next frame */
   }
   return IAMF_OK;
 }
@@ -859,7 +872,7 @@ static void free_runtime(struct IAMF_Decoder *d) {
       d->pkt_have[e][s] = 0;
     }
   }
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 4; ++i) {
     if (d->h_ramp[i]) (void)hipHostFree(d->h_ramp[i]);
     d->h_ramp[i] = 0;
   }
@@ -867,14 +880,21 @@ static void free_runtime(struct IAMF_Decoder *d) {
   d->tmp = 0;
   if (d->d_mid) (void)hipFree(d->d_mid);
   if (d->d_res) (void)hipFree(d->d_res);
-  if (d->h_dmx) (void)hipHostFree(d->h_dmx);
-  if (d->h_demix) (void)hipHostFree(d->h_demix);
-  d->h_demix = 0;
+  for (int e = 0; e < 2; ++e) {
+    if (d->pre[e].h_dmx) (void)hipHostFree(d->pre[e].h_dmx);
+    if (d->pre[e].h_demix) (void)hipHostFree(d->pre[e].h_demix);
+    d->pre[e].h_dmx = 0;
+    d->pre[e].h_demix = 0;
+  }
+  if (d->aux) iamf_hip_batch_destroy(d->aux);
+  d->aux = 0;
+  if (d->d_aux_il) (void)hipFree(d->d_aux_il);
+  if (d->d_aux_pl) (void)hipFree(d->d_aux_pl);
+  d->d_aux_il = d->d_aux_pl = 0;
   if (d->h_pcm) (void)hipHostFree(d->h_pcm);
   if (d->h_done) (void)hipHostFree((void *)d->h_done);
   d->h_done = 0;
   d->d_mid = d->d_res = 0;
-  d->h_dmx = 0;
   d->h_pcm = 0;
   if (d->stream) (void)hipStreamDestroy(d->stream);
   d->stream = 0;
@@ -895,16 +915,12 @@ static void reset_descriptors(struct IAMF_Decoder *d) {
   d->frame_size = d->sample_size = d->rate = 0;
   d->sel = 0;
   d->sel_el[0] = d->sel_el[1] = 0;
-  d->el_gain_p[0] = d->el_gain_p[1] = d->out_gain_p = d->demix_p = 0;
-  d->use_dmx = d->use_demix = 0;
-  d->dmx_mode = -1;
+  d->el_gain_p[0] = d->el_gain_p[1] = d->out_gain_p = 0;
+  memset(d->pre, 0, sizeof(d->pre)); /* (free_runtime has released what it pointed to) */
+  d->pre[0].dmx_mode = d->pre[1].dmx_mode = -1;
   d->el_dmx_mode[0] = d->el_dmx_mode[1] = -1;
   d->meta_dmixp = 0;
   d->swapped = 0;
-  d->rec_flags = 0;
-  d->rec_n = 0;
-  memset(d->layer_rec_flags, 0, sizeof(d->layer_rec_flags));
-  memset(d->layer_rec_gain, 0, sizeof(d->layer_rec_gain));
   d->tu_trim_start = d->tu_trim_end = 0;
   d->timestamp = 0;
   d->last_frame = 0;
@@ -958,11 +974,137 @@ static Element *find_element(struct IAMF_Decoder *d, uint64_t id) {
   return 0;
 }
 
+/* What element ei needs in front of its renderer, and the matrix its batch is created with: the parametric down-mixer when
+ * the element carries demixing info and the target is a smaller IAMF layout (iamf_stream_renderer_enable_downmix,
+ * IAMF_decoder.c:2448-2478), the demixer when it is scalable or carries output gains (:2351-2386) */
+static int pre_decide(struct IAMF_Decoder *d, int ei, iamf_hip_matrix *mx) {
+  Element *e = d->sel_el[ei];
+  Pre *q = &d->pre[ei];
+  const int out_layout = d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION ? k_ss_layout[d->out_ss] : -1;
+  q->use_dmx = q->use_demix = 0;
+  if (e->type == AUDIO_ELEMENT_CHANNEL_BASED) {
+    int lay = select_layer(d, e), gains = 0;
+    for (int k = 0; k <= lay; ++k) gains |= e->layer[k].out_gain_flag;
+    if (e->nlayers > 1 || gains) {
+      q->use_demix = 1;
+      q->demix_layer = lay;
+    }
+  }
+  if (e->type == AUDIO_ELEMENT_CHANNEL_BASED && e->has_demix && out_layout >= 0 && iamf_hip_dmx_valid(e->layout, out_layout)) {
+    q->use_dmx = 1;
+    mx->kind = IAMF_HIP_KIND_DMX;
+    mx->in_id = e->layout;
+    mx->out_id = out_layout;
+    iamf_hip_dmx_state_init(&q->dmx);
+    q->dmx_mode = -1;
+    iamf_hip_dmx_set_mode_weight(&q->dmx, e->demix_default_mode, e->demix_default_w);
+    return 0;
+  }
+  return element_matrix(d, e, mx);
+}
+
+/* ... and its configuration on the batch that renders the element (projection de-mapping, IAMF_core_decoder.c:116-130;
+ * iamf_stream_scale_demixer_configure, IAMF_decoder.c:2351-2386) plus the pinned per-frame records */
+static int pre_attach(struct IAMF_Decoder *d, int ei, iamf_hip_batch *batch) {
+  const Element *e = d->sel_el[ei];
+  Pre *q = &d->pre[ei];
+  memset(&q->dc_sig, 0, sizeof(q->dc_sig));
+  if (e->amb_projection && iamf_hip_batch_set_projection(batch, e->proj, element_in_channels(e))) return IAMF_ERR_INTERNAL;
+  if (q->use_demix) {
+    iamf_hip_demix_config dc;
+    int last = -1;
+    memset(&dc, 0, sizeof(dc));
+    dc.layout = e->layout;
+    q->demix_nsub = 0;
+    for (int l = 0; l <= q->demix_layer; ++l) {
+      const Layer *L = &e->layer[l];
+      int n = layer_new_channels(last, L->layout, dc.chs_in + dc.n_in);
+      if (n != L->nsub + L->ncoupled || dc.n_in + n > 12) return IAMF_ERR_INVALID_PACKET;
+      dc.n_in += n;
+      q->demix_nsub += L->nsub;
+      last = L->layout;
+      if (L->out_gain_flag)
+        for (int c = 0; c < 6; ++c)
+          if (L->gain_flags & (1 << c)) {
+            int ch = output_gain_channel(L->layout, c);
+            if (ch != CH_INVALID) {
+              dc.gain_ch[dc.n_gain] = ch;
+              dc.gain[dc.n_gain++] = db2lin(q_to_float(L->gain_q, 8));
+            }
+          }
+    }
+    if (dc.n_in != k_layout_channels[e->layout]) return IAMF_ERR_INVALID_PACKET;
+    q->demix_nch = dc.n_in;
+    /* iamf_stream_scale_decoder_set_default_recon_gain, :2202-2236 */
+    q->rec_flags = q->demix_layer > 0 ? recon_default_flags(e->layer[0].layout, e->layout) : 0;
+    q->rec_n = recon_channel_order(e->layout, q->rec_flags, q->rec_ch);
+    for (int i = 0; i < 12; ++i) q->rec_gain[i] = 1.f;
+    memset(q->layer_rec_flags, 0, sizeof(q->layer_rec_flags));
+    dc.frame_offset = 0; /* LPCM has no decoder delay: demixer_set_frame_offset(0), IAMF_decoder.c:2175-2183 */
+    if (iamf_hip_batch_set_demixer(batch, &dc)) return IAMF_ERR_INTERNAL;
+    q->dc_sig = dc;
+    iamf_hip_demix_state_init(&q->dmst);
+    if (e->has_demix) iamf_hip_demix_set_info(&q->dmst, e->demix_default_mode, e->demix_default_w);
+    q->dmx_mode = -1;
+    if (hipHostMalloc((void **)&q->h_demix, sizeof(iamf_hip_demix_frame), 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+  }
+  if (hipHostMalloc((void **)&q->h_dmx, sizeof(iamf_hip_dmx_frame), 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+  return IAMF_OK;
+}
+
+/* What a down-mixer of this handle multiplies with.  The reference keeps the dependency tables of its down-mixer
+ * (chsl5, chl3, chhl, chtl ...: downmix_renderer.c:65-75) in STATIC arrays that every DMRenderer shares: DMRenderer_open
+ * points their `sp` fields at the opened instance's own mix_factors (:165-172) and DMRenderer_set_mode_weight stores
+ * gamma * w in the TL / TR entries' `s` (:199-211).  With one down-mixer that is its own state.  With two in one
+ * presentation, BOTH read alpha / beta / gamma / delta of the one opened LAST — the later element in presentation order —
+ * as they are at that moment (the earlier element renders before the later one's update of the frame: it sees the mode of
+ * the frame before), and gamma * w as whoever stored it last (each element's own update precedes its own render).
+ * Reproduced per handle, and pinned by `l714dmx_plus_l714dmx_C` / `scalable_plus_l714dmx_312`; the reference shares the
+ * tables across HANDLES of a process as well — not reproduced: that depends on how a caller interleaves its decoders. */
+static void dmx_shared_coefficients(const struct IAMF_Decoder *d, float out[5]) {
+  const iamf_hip_dmx_state *last = &d->pre[d->dmx_last].dmx;
+  out[0] = last->alpha;
+  out[1] = last->beta;
+  out[2] = last->gamma;
+  out[3] = last->delta;
+  out[4] = d->dmx_static_s;
+}
+
+/* The stage's records of the frame at hand: iamf_stream_render's down-mixer update (IAMF_decoder.c:2574-2583) into *fr,
+ * iamf_stream_scale_decoder_demix's (:2324-2349; demixer_set_recon_gain, demixer.c:620-634) into *dm */
+static void pre_frame(struct IAMF_Decoder *d, int ei, iamf_hip_dmx_frame *fr, iamf_hip_demix_frame *dm) {
+  const Element *e = d->sel_el[ei];
+  Pre *q = &d->pre[ei];
+  if (q->use_dmx) {
+    fr->offset = 0;
+    dmx_shared_coefficients(d, fr->prev);
+    if (q->dmx_mode > -1) {
+      iamf_hip_dmx_set_mode_weight(&q->dmx, q->dmx_mode, -1);
+      if (e->layout != IA_CHANNEL_LAYOUT_312) d->dmx_static_s = q->dmx.gamma_w;
+    }
+    dmx_shared_coefficients(d, fr->cur);
+  }
+  if (q->use_demix) {
+    if (e->layer[q->demix_layer].recon_flag) {
+      const uint32_t lf = q->layer_rec_flags[q->demix_layer];
+      const int cnt = popcount32(lf);
+      if (lf && (lf ^ q->rec_flags)) {
+        q->rec_n = recon_channel_order(e->layout, lf, q->rec_ch);
+        q->rec_flags = lf;
+      }
+      for (int i = 0; i < cnt && i < 12; ++i) q->rec_gain[i] = q->layer_rec_gain[q->demix_layer][i];
+    }
+    if (q->dmx_mode > -1) iamf_hip_demix_set_info(&q->dmst, q->dmx_mode, -1);
+    iamf_hip_demix_frame_fill(&q->dmst, q->rec_n, q->rec_ch, q->rec_gain, dm);
+  }
+}
+
 static int setup_pipeline(struct IAMF_Decoder *d) {
   iamf_hip_batch_config cfg;
   Presentation *p = 0;
-  int resample;
+  int resample, aux = 0; /* aux: element 1 needs a stage of its own */
   free_runtime(d);
+  d->pre[1].use_dmx = d->pre[1].use_demix = 0;
   if (!d->have_header || !d->have_codec || !d->nel || !d->npr) return IAMF_ERR_BUFFER_TOO_SMALL;
   if (d->out_type == IAMF_LAYOUT_TYPE_NOT_DEFINED) return IAMF_ERR_BAD_ARG;
   /* iamf_decoder_get_best_mix_presentation, IAMF_decoder.c:3083-3111 */
@@ -1019,8 +1161,9 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
    * depend on the order of the two frames (0 + a is a; a + b is b + a in IEEE arithmetic; two -0 terms give +0 either
    * way, which no PCM word can tell).  So a presentation whose SECOND element needs the pre-stage is rendered with its
    * two elements exchanged: every per-element item (mix-gain definition and default, parameter streams, packets) is
-   * indexed through the presentation entry that is exchanged here.  Both elements needing one: not built
-   * (IAMF_ERR_UNIMPLEMENTED below). */
+   * indexed through the presentation entry that is exchanged here.  Both elements needing one: element 1 gets a batch
+   * of its own (`aux`, below).  The LFE generator exists in `batch` only, so a scene-based element that feeds it is
+   * always element 0. */
   {
     const int out_layout = d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION ? k_ss_layout[d->out_ss] : -1;
     int needs[2] = {0, 0};
@@ -1034,7 +1177,9 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
         needs[i] = e->amb_projection || (d->lfe_hoa && d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION);
       }
     }
-    if (p->nel == 2 && needs[1] && !needs[0]) {
+    const int lfe_gen = d->lfe_hoa && d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION;
+    if (p->nel == 2 && needs[1] &&
+        (!needs[0] || (lfe_gen && d->sel_el[1]->type == AUDIO_ELEMENT_SCENE_BASED && d->sel_el[0]->type != AUDIO_ELEMENT_SCENE_BASED))) {
       const uint64_t id = p->el_id[0];
       const ParamDef pd = p->el_gain_def[0];
       const int16_t q = p->el_gain_q[0];
@@ -1051,8 +1196,9 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
       d->sel_el[1] = e;
       d->el_gain_p[1] = gp;
       d->swapped ^= 1; /* (a second configuration of the same descriptors finds them exchanged already) */
+      aux = needs[0];
     } else if (p->nel == 2 && needs[1]) {
-      return IAMF_ERR_UNIMPLEMENTED;
+      aux = 1;
     }
   }
   /* IAMF_decoder.c:2625-2633: scene-based element, LFE generator compiled in, layout with an LFE.  The
@@ -1064,41 +1210,8 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
     if (scene > 1 || (scene == 1 && d->sel_el[0]->type != AUDIO_ELEMENT_SCENE_BASED)) return IAMF_ERR_UNIMPLEMENTED;
     cfg.lfe_hoa = scene == 1;
   }
-  /* element 0: the parametric down-mixer when the element carries demixing info and the target
-   * is a smaller IAMF layout (iamf_stream_renderer_enable_downmix, IAMF_decoder.c:2448-2478) */
-  d->use_dmx = 0;
-  d->demix_p = 0;
-  d->use_demix = 0;
   d->el_dmx_mode[0] = d->el_dmx_mode[1] = -1; /* cctx->dmx_mode = INVALID_VALUE at stream creation, :1728 */
-  {
-    Element *e = d->sel_el[0];
-    if (e->type == AUDIO_ELEMENT_CHANNEL_BASED) {
-      int lay = select_layer(d, e), gains = 0;
-      for (int k = 0; k <= lay; ++k) gains |= e->layer[k].out_gain_flag;
-      if (e->nlayers > 1 || gains) {
-        d->use_demix = 1;
-        d->demix_layer = lay;
-      }
-    }
-  }
-  {
-    Element *e0 = d->sel_el[0];
-    int out_layout = d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION ? k_ss_layout[d->out_ss] : -1;
-    if (e0->type == AUDIO_ELEMENT_CHANNEL_BASED && e0->has_demix && out_layout >= 0 &&
-        iamf_hip_dmx_valid(e0->layout, out_layout)) {
-      d->use_dmx = 1;
-      cfg.matrix.kind = IAMF_HIP_KIND_DMX;
-      cfg.matrix.in_id = e0->layout;
-      cfg.matrix.out_id = out_layout;
-      iamf_hip_dmx_state_init(&d->dmx);
-      d->dmx_mode = -1;
-      iamf_hip_dmx_set_mode_weight(&d->dmx, e0->demix_default_mode, e0->demix_default_w);
-      for (int i = 0; i < d->nparam; ++i)
-        if (d->param[i].id == e0->demix_pid) d->demix_p = &d->param[i];
-    } else if (element_matrix(d, e0, &cfg.matrix)) {
-      return IAMF_ERR_INTERNAL;
-    }
-  }
+  if (pre_decide(d, 0, &cfg.matrix)) return IAMF_ERR_INTERNAL;
   if (resample) {
     cfg.out_format = IAMF_HIP_FMT_F32;
     cfg.limiter_enable = 0;
@@ -1114,56 +1227,55 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   d->cfg_sig = cfg; /* a group of handles is formed from handles whose batches were created alike */
   d->cfg_mat = cfg.matrix.mat;
   d->cfg_sig.matrix.mat = 0;
-  memset(&d->dc_sig, 0, sizeof(d->dc_sig));
-  if (d->sel_el[0]->amb_projection &&
-      iamf_hip_batch_set_projection(d->batch, d->sel_el[0]->proj, element_in_channels(d->sel_el[0])))
-    return IAMF_ERR_INTERNAL;
-  if (d->use_demix) { /* iamf_stream_scale_demixer_configure, IAMF_decoder.c:2351-2386 */
-    const Element *e0 = d->sel_el[0];
-    iamf_hip_demix_config dc;
-    int last = -1;
-    memset(&dc, 0, sizeof(dc));
-    dc.layout = e0->layout;
-    d->demix_nsub = 0;
-    for (int l = 0; l <= d->demix_layer; ++l) {
-      const Layer *L = &e0->layer[l];
-      int n = layer_new_channels(last, L->layout, dc.chs_in + dc.n_in);
-      if (n != L->nsub + L->ncoupled || dc.n_in + n > 12) return IAMF_ERR_INVALID_PACKET;
-      dc.n_in += n;
-      d->demix_nsub += L->nsub;
-      last = L->layout;
-      if (L->out_gain_flag)
-        for (int c = 0; c < 6; ++c)
-          if (L->gain_flags & (1 << c)) {
-            int ch = output_gain_channel(L->layout, c);
-            if (ch != CH_INVALID) {
-              dc.gain_ch[dc.n_gain] = ch;
-              dc.gain[dc.n_gain++] = db2lin(q_to_float(L->gain_q, 8));
-            }
-          }
-    }
-    if (dc.n_in != k_layout_channels[e0->layout]) return IAMF_ERR_INVALID_PACKET;
-    d->demix_nch = dc.n_in;
-    /* iamf_stream_scale_decoder_set_default_recon_gain, :2202-2236 */
-    d->rec_flags = d->demix_layer > 0 ? recon_default_flags(e0->layer[0].layout, e0->layout) : 0;
-    d->rec_n = recon_channel_order(e0->layout, d->rec_flags, d->rec_ch);
-    for (int i = 0; i < 12; ++i) d->rec_gain[i] = 1.f;
-    memset(d->layer_rec_flags, 0, sizeof(d->layer_rec_flags));
-    dc.frame_offset = 0; /* LPCM has no decoder delay: demixer_set_frame_offset(0), IAMF_decoder.c:2175-2183 */
-    if (iamf_hip_batch_set_demixer(d->batch, &dc)) return IAMF_ERR_INTERNAL;
-    d->dc_sig = dc;
-    iamf_hip_demix_state_init(&d->dmst);
-    if (e0->has_demix) iamf_hip_demix_set_info(&d->dmst, e0->demix_default_mode, e0->demix_default_w);
-    d->dmx_mode = -1;
-    for (int i = 0; i < d->nparam; ++i)
-      if (e0->has_demix && d->param[i].id == e0->demix_pid) d->demix_p = &d->param[i];
-    if (hipHostMalloc((void **)&d->h_demix, sizeof(iamf_hip_demix_frame), 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
+  {
+    int rc = pre_attach(d, 0, d->batch);
+    if (rc) return rc;
   }
-  if (p->nel == 2) {
+  if (p->nel == 2 && !aux) {
     iamf_hip_matrix m2;
     float one = 1.f;
     if (element_matrix(d, d->sel_el[1], &m2) || iamf_hip_batch_set_second_element(d->batch, &m2, &one))
       return IAMF_ERR_INTERNAL;
+  }
+  if (aux) {
+    /* Element 1 needs a stage of its own: a second batch renders it — stage, matrix, its mix gain; no limiter, no
+     * loudness — into f32 sample-frames, and `batch` takes those as its second element through the identity matrix with
+     * gain 1:  0 + 1 * y[c] + 0 * y[..]  is y[c] for every finite y, so what reaches the mixer is what the reference's
+     * renderer and iamf_frame_gain left for this element (IAMF_decoder.c:2536-2651, 639-664), bit for bit. */
+    iamf_hip_batch_config ca;
+    iamf_hip_matrix m2;
+    float eye[24 * 24], one = 1.f;
+    int rc;
+    memset(&ca, 0, sizeof(ca));
+    ca.n_streams = 1;
+    ca.frame_size = (int32_t)d->frame_size;
+    ca.sample_rate = (int32_t)d->rate;
+    ca.out_channels = d->out_channels;
+    ca.out_format = IAMF_HIP_FMT_F32;
+    ca.projection = IAMF_HIP_PROJ_EXACT;
+    if (pre_decide(d, 1, &ca.matrix) || iamf_hip_batch_create(&ca, &d->aux)) return IAMF_ERR_INTERNAL;
+    rc = pre_attach(d, 1, d->aux);
+    if (rc) return rc;
+    d->aux_gain_set = 1.f;
+    for (int i = 0; i < d->out_channels; ++i)
+      for (int j = 0; j < d->out_channels; ++j) eye[i * d->out_channels + j] = i == j ? 1.f : 0.f;
+    memset(&m2, 0, sizeof(m2));
+    m2.kind = IAMF_HIP_KIND_M2M;
+    m2.m = m2.n = m2.channels = d->out_channels;
+    m2.lfe1 = m2.lfe2 = -1;
+    m2.mat = eye;
+    if (iamf_hip_batch_set_second_element(d->batch, &m2, &one)) return IAMF_ERR_INTERNAL;
+    if (hipMalloc((void **)&d->d_aux_il, sizeof(float) * d->frame_size * d->out_channels) != hipSuccess ||
+        hipMalloc((void **)&d->d_aux_pl, sizeof(float) * d->frame_size * d->out_channels) != hipSuccess)
+      return IAMF_ERR_ALLOC_FAIL;
+  }
+  d->dmx_last = 0;
+  d->dmx_static_s = 0.f;
+  for (int k = 0; k < p->nel; ++k) { /* DMRenderer_open + DMRenderer_set_mode_weight(default), in presentation order */
+    const int e = d->swapped ? p->nel - 1 - k : k;
+    if (!d->pre[e].use_dmx || (e == 1 && !aux)) continue;
+    d->dmx_last = e;
+    if (d->sel_el[e]->layout != IA_CHANNEL_LAYOUT_312) d->dmx_static_s = d->pre[e].dmx.gamma_w;
   }
   if (resample) {
     float eye[24 * 24];
@@ -1202,7 +1314,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
     if (hipHostMalloc((void **)&d->h_in[e], bytes, 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
     memset(d->h_in[e], 0, bytes);
   }
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 4; ++i)
     if (hipHostMalloc((void **)&d->h_ramp[i], sizeof(float) * d->frame_size, 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
   {
     /* the headline's kind of stream: its packets go to the render kernel as they are (the reference's LPCM decode,
@@ -1210,7 +1322,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
      * fused kernel takes it and unpacks on the device otherwise; here: whether asking is worth it */
     const Element *e0 = d->sel_el[0];
     iamf_hip_lpcm_layout *L = &d->lp_layout;
-    d->lp_ok = p->nel == 1 && e0->type == AUDIO_ELEMENT_SCENE_BASED && !e0->amb_projection && !d->use_dmx && !d->use_demix &&
+    d->lp_ok = p->nel == 1 && e0->type == AUDIO_ELEMENT_SCENE_BASED && !e0->amb_projection && !d->pre[0].use_dmx && !d->pre[0].use_demix &&
                !resample && d->sample_size == 16 && d->little_endian && d->limiter_on && d->out_channels <= 2 &&
                d->pcm_stride == d->out_channels && (d->frame_size & 63) == 0 && e0->nsub > 0 && e0->nsub <= MAX_SUBSTREAMS &&
                (e0->channels == 1 || e0->channels == 4 || e0->channels == 9 || e0->channels == 16) && !getenv("IAMF_HIP_FACADE_UNPACK");
@@ -1226,7 +1338,6 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
     }
     if (d->lp_ok && hipHostMalloc((void **)&d->h_raw, (size_t)e0->nsub * d->frame_size * 2 + 256, 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
   }
-  if (hipHostMalloc((void **)&d->h_dmx, sizeof(iamf_hip_dmx_frame), 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
   d->pcm_cap = (size_t)4 * ((size_t)d->info.max_frame_size * d->pcm_stride + d->pcm_extra);
   if (hipHostMalloc(&d->h_pcm, d->pcm_cap, 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
   if (hipHostMalloc((void **)&d->h_done, 64, 0) != hipSuccess) return IAMF_ERR_ALLOC_FAIL;
@@ -1285,24 +1396,13 @@ int IAMF_decoder_configure(IAMF_DecoderHandle d, const uint8_t *data, uint32_t s
      * while the decoders, the parameter database and the stream time go on: everything that belongs to them is kept
      * across the rebuild of the pipeline. */
     const uint64_t ts = d->timestamp;
-    const int dmx_mode = d->dmx_mode, use_demix = d->use_demix;
     const int was_swapped = d->swapped, el_mode0 = d->el_dmx_mode[0], el_mode1 = d->el_dmx_mode[1];
     const int had_limiter = d->limiter_on && d->configured;
-    const iamf_hip_demix_state dmst = d->dmst;
-    const uint32_t rec_flags = d->rec_flags;
-    const int rec_n = d->rec_n;
-    int32_t rec_ch[12];
-    float rec_gain[12];
-    uint32_t lrf[MAX_LAYERS];
-    float lrg[MAX_LAYERS][12];
-    memcpy(rec_ch, d->rec_ch, sizeof(rec_ch));
-    memcpy(rec_gain, d->rec_gain, sizeof(rec_gain));
-    memcpy(lrf, d->layer_rec_flags, sizeof(lrf));
-    memcpy(lrg, d->layer_rec_gain, sizeof(lrg));
+    Pre was[2]; /* (values only: the pinned records they point to go with the old pipeline) */
+    memcpy(was, d->pre, sizeof(was));
     rc = setup_pipeline(d);
     if (rc == IAMF_OK) {
       d->timestamp = ts;
-      d->dmx_mode = dmx_mode;
       /* the stream contexts (and their demixing modes) live on; if this layout exchanges the elements the other way
        * round, the modes follow their elements */
       d->el_dmx_mode[0] = was_swapped == d->swapped ? el_mode0 : el_mode1;
@@ -1311,14 +1411,19 @@ int IAMF_decoder_configure(IAMF_DecoderHandle d, const uint8_t *data, uint32_t s
         d->meta_duration += 240;
         d->last_frame += 240;
       }
-      memcpy(d->layer_rec_flags, lrf, sizeof(lrf));
-      memcpy(d->layer_rec_gain, lrg, sizeof(lrg));
-      if (use_demix && d->use_demix) { /* the demixer is part of the stream decoder, which is not re-opened */
-        d->dmst = dmst;
-        d->rec_flags = rec_flags;
-        d->rec_n = rec_n;
-        memcpy(d->rec_ch, rec_ch, sizeof(rec_ch));
-        memcpy(d->rec_gain, rec_gain, sizeof(rec_gain));
+      for (int e = 0; e < 2; ++e) {
+        const Pre *o = &was[was_swapped == d->swapped ? e : 1 - e];
+        Pre *q = &d->pre[e];
+        q->dmx_mode = o->dmx_mode;
+        memcpy(q->layer_rec_flags, o->layer_rec_flags, sizeof(q->layer_rec_flags));
+        memcpy(q->layer_rec_gain, o->layer_rec_gain, sizeof(q->layer_rec_gain));
+        if (o->use_demix && q->use_demix) { /* the demixer is part of the stream decoder, which is not re-opened */
+          q->dmst = o->dmst;
+          q->rec_flags = o->rec_flags;
+          q->rec_n = o->rec_n;
+          memcpy(q->rec_ch, o->rec_ch, sizeof(q->rec_ch));
+          memcpy(q->rec_gain, o->rec_gain, sizeof(q->rec_gain));
+        }
       }
     }
     return rc;
@@ -1384,8 +1489,8 @@ static int unpack_element(struct IAMF_Decoder *d, int ei) {
   float *tmp = d->tmp;
   /* audio-layer order: coupled pairs first, then singles */
   int c = 0;
-  const int demix = ei == 0 && d->use_demix;
-  const int nsub = demix ? d->demix_nsub : e->nsub;
+  const int demix = d->pre[ei].use_demix;
+  const int nsub = demix ? d->pre[ei].demix_nsub : e->nsub;
   int lay = 0, lay_s0 = 0; /* layer of sub-stream s and its first sub-stream */
   for (int s = 0; s < nsub; ++s) {
     int w;
@@ -1547,7 +1652,7 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     }
   a.d_in = lp ? 0 : d->h_in[0];
   a.in_stream_stride = a.in_frame_stride = (int64_t)element_in_channels(d->sel_el[0]) * fs;
-  if (d->sel->nel > 1) {
+  if (d->sel->nel > 1 && !d->aux) {
     a.d_in2 = d->h_in[1];
     a.in2_stream_stride = a.in2_frame_stride = (int64_t)d->sel_el[1]->channels * fs;
   }
@@ -1564,29 +1669,47 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     if (d->sel->nel > 1) a.d_element2_ramp = d->h_ramp[1]; /* element 1: constant or ramp, both exact */
   }
   a.ramp_stream_stride = fs;
-  if (d->use_dmx) { /* IAMF_decoder.c:2574-2583 */
-    iamf_hip_dmx_frame *fr = d->h_dmx;
-    fr->offset = 0;
-    iamf_hip_dmx_coefficients(&d->dmx, fr->prev);
-    if (d->dmx_mode > -1) iamf_hip_dmx_set_mode_weight(&d->dmx, d->dmx_mode, -1);
-    iamf_hip_dmx_coefficients(&d->dmx, fr->cur);
-    a.d_dmx_frames = fr;
+  for (int k = 0; k < d->sel->nel; ++k) { /* in the order the reference renders its streams (dmx_shared_coefficients) */
+    const int e = d->swapped ? d->sel->nel - 1 - k : k;
+    if (e == 0 || d->aux) pre_frame(d, e, d->pre[e].h_dmx, d->pre[e].h_demix);
   }
-  if (d->use_demix) { /* iamf_stream_scale_decoder_demix, IAMF_decoder.c:2324-2349 */
-    const Element *e0 = d->sel_el[0];
-    if (e0->layer[d->demix_layer].recon_flag) { /* demixer_set_recon_gain, demixer.c:620-634 */
-      const uint32_t lf = d->layer_rec_flags[d->demix_layer];
-      const int cnt = popcount32(lf);
-      if (lf && (lf ^ d->rec_flags)) {
-        d->rec_n = recon_channel_order(e0->layout, lf, d->rec_ch);
-        d->rec_flags = lf;
-      }
-      for (int i = 0; i < cnt && i < 12; ++i) d->rec_gain[i] = d->layer_rec_gain[d->demix_layer][i];
-    }
-    if (d->dmx_mode > -1) iamf_hip_demix_set_info(&d->dmst, d->dmx_mode, -1);
-    iamf_hip_demix_frame_fill(&d->dmst, d->rec_n, d->rec_ch, d->rec_gain, d->h_demix);
-    a.d_demix_frames = d->h_demix;
+  if (d->pre[0].use_dmx) a.d_dmx_frames = d->pre[0].h_dmx;
+  if (d->pre[0].use_demix) {
+    a.d_demix_frames = d->pre[0].h_demix;
     a.demix_sample0 = s0;
+  }
+  if (d->aux) { /* element 1 through its own batch -> f32 sample-frames -> planar, where `batch` reads its second element */
+    iamf_hip_render_args b;
+    const float eg = ramp[1] ? 1.f : cgain[1], one = 1.f;
+    int n1;
+    memset(&b, 0, sizeof(b));
+    b.d_in = d->h_in[1];
+    b.in_stream_stride = b.in_frame_stride = (int64_t)element_in_channels(d->sel_el[1]) * fs;
+    if (eg != d->aux_gain_set) {
+      if (iamf_hip_batch_set_gains(d->aux, &eg, &one, 0)) return IAMF_ERR_INTERNAL;
+      d->aux_gain_set = eg;
+    }
+    if (ramp[1]) {
+      memcpy(d->h_ramp[3], d->h_ramp[1], sizeof(float) * keep);
+      b.d_element_ramp = d->h_ramp[3];
+    }
+    b.ramp_stream_stride = fs;
+    for (int k = 0; k < keep; ++k) d->h_ramp[1][k] = 1.f; /* `batch` takes the frame as it is */
+    if (d->pre[1].use_dmx) b.d_dmx_frames = d->pre[1].h_dmx;
+    if (d->pre[1].use_demix) {
+      b.d_demix_frames = d->pre[1].h_demix;
+      b.demix_sample0 = s0;
+    }
+    b.n_frames = 1;
+    b.n_samples = keep < fs ? keep : 0;
+    b.stream = d->stream;
+    b.d_pcm = d->d_aux_il;
+    b.pcm_stream_stride_bytes = (int64_t)sizeof(float) * fs * d->out_channels;
+    n1 = iamf_hip_batch_render_ex(d->aux, &b);
+    if (n1 != keep) return IAMF_ERR_INTERNAL;
+    if (iamf_hip_deinterleave_f32(d->d_aux_il, 0, d->out_channels, 1, keep, d->d_aux_pl, 0, fs, d->stream)) return IAMF_ERR_INTERNAL;
+    a.d_in2 = d->d_aux_pl;
+    a.in2_stream_stride = a.in2_frame_stride = (int64_t)d->out_channels * fs;
   }
   a.n_frames = 1;
   a.n_samples = keep < fs ? keep : 0;

@@ -156,3 +156,33 @@ extern "C" int iamf_hip_lpcm_unpack(const iamf_hip_lpcm_layout *lay, const void 
   return iamf_hip_lpcm_unpack_frames(lay, d_raw, raw_stream_stride, raw_stream_stride, 1, d_first_count, first_count_stride, d_out,
                                      out_stream_stride, out_stream_stride, n_streams, stream, 0, 0);
 }
+
+// Sample-frames [stream][sample][channels] (what a batch with out_format F32 writes) -> planar [stream][channel][...]
+// (what a batch reads as element PCM).  A workgroup takes 256 sample-frames of one stream through LDS: contiguous reads,
+// contiguous writes per channel; the LDS row stride is odd, so the transposed reads spread over the banks.
+__global__ __launch_bounds__(256) void deinterleave_kernel(const float *src, int64_t src_stream_stride, int channels, int n,
+                                                           float *dst, int64_t dst_stream_stride, int64_t dst_channel_stride) {
+  __shared__ float tile[256 * 25];
+  const int s = blockIdx.y, j0 = 256 * (int)blockIdx.x, t = threadIdx.x;
+  const int rows = n - j0 < 256 ? n - j0 : 256, ld = channels | 1;
+  const float *in = src + (int64_t)s * src_stream_stride + (int64_t)j0 * channels;
+  for (int k = t; k < rows * channels; k += 256) tile[(k / channels) * ld + k % channels] = in[k];
+  __syncthreads();
+  float *out = dst + (int64_t)s * dst_stream_stride + j0;
+  if (t < rows)
+    for (int c = 0; c < channels; ++c) out[(int64_t)c * dst_channel_stride + t] = tile[t * ld + c];
+}
+
+extern "C" int iamf_hip_deinterleave_f32(const float *d_src, int64_t src_stream_stride, int32_t channels, int32_t n_streams,
+                                         int32_t n_samples, float *d_dst, int64_t dst_stream_stride, int64_t dst_channel_stride,
+                                         void *stream) {
+  if (!d_src || !d_dst || channels <= 0 || channels > 24 || n_streams <= 0 || n_streams > 65535 || n_samples < 0 ||
+      dst_channel_stride < n_samples || (n_streams > 1 && (src_stream_stride < (int64_t)n_samples * channels ||
+                                                           dst_stream_stride < (int64_t)channels * dst_channel_stride)))
+    return IAMF_HIP_ERR_BAD_ARG;
+  if (!n_samples) return IAMF_HIP_OK;
+  hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)((n_samples + 255) / 256), (unsigned)n_streams), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), d_src, src_stream_stride, channels, n_samples, d_dst, dst_stream_stride,
+                     dst_channel_stride);
+  return hipGetLastError() == hipSuccess ? IAMF_HIP_OK : IAMF_HIP_ERR_DEVICE;
+}

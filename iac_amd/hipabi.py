@@ -147,6 +147,8 @@ def lib():
         L.iamf_hip_resampler_flush_range.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32]
         L.iamf_hip_resampler_same_state.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.iamf_hip_stream_signal.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.iamf_hip_deinterleave_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                                C.c_int64, C.c_void_p]
         L.iamf_hip_batch_set_projection.argtypes = [C.c_void_p, FP, C.c_int]
         L.iamf_hip_lpcm_unpack.argtypes = [C.POINTER(LpcmLayout), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_int64, C.c_int32, C.c_void_p]

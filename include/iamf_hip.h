@@ -507,6 +507,13 @@ int iamf_hip_upload_by_kernel(const void *h_pinned, void *d_dst, size_t bytes, v
  * before it on the stream has completed and is visible to the host when the word reads `seq`.  The caller bounds its
  * spin and falls back to hipStreamSynchronize (which also reports a device error).  IAMF_HIP_OK / _BAD_ARG / _DEVICE. */
 int iamf_hip_stream_signal(void *stream, volatile uint32_t *h_pinned_flag, uint32_t seq);
+/* f32 sample-frames [stream][sample][channels] — what a batch with out_format IAMF_HIP_FMT_F32 writes — to planar
+ * [stream][channel][dst_channel_stride], the form a batch reads element PCM in: how one batch's rendered frame becomes
+ * another batch's (second) element, e.g. a presentation both of whose elements need a per-stream stage (the reference
+ * mixes rendered frames, iamf_mixer_mix, IAMF_decoder.c:2702-2733).  Strides in floats; channels <= 24.
+ * IAMF_HIP_OK / _BAD_ARG / _DEVICE. */
+int iamf_hip_deinterleave_f32(const float *d_src, int64_t src_stream_stride, int32_t channels, int32_t n_streams,
+                              int32_t n_samples, float *d_dst, int64_t dst_stream_stride, int64_t dst_channel_stride, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * A group of decoder handles: callers of the reference API get the batch renderer's throughput.

@@ -156,6 +156,30 @@ CASES = {
                                      pair=("stereo", "toa_projection"), element_gain_q78=-256, element2_gain_q78=-400),
     "l51_plus_projection_binaural": dict(layout=("binaural",), bit_depth=32, frames=6, fs=1024, seed=208,
                                          pair=("l51", "toa_projection"), element2_gain_q78=-300),
+    # ---- BOTH elements need such a stage (the second one is rendered by a batch of its own into f32, the first one's batch
+    # mixes it in as a plain second element: iamf_decoder_facade.c setup_pipeline)
+    "scalable_plus_scalable_J": dict(layout=_ss_layout("J"), bit_depth=16, frames=8, fs=1024, seed=221,
+                                     pair=("scalable", "scalable"), element_gain_q78=-400, element2_gain_q78=-650,
+                                     scalable_modes2=[2, 0, 1, 6, 5, 4, 4, 1], recon_salt2=77),
+    "scalable_plus_scalable_A": dict(layout=_ss_layout("A"), bit_depth=24, frames=8, fs=1024, seed=222,
+                                     pair=("scalable", "scalable"), element_gain_q78=-300, element2_gain_q78=-500,
+                                     scalable_modes2=[0, 2, 4, 6, 1, 5, 2, 0], recon_salt2=78),
+    "scalable_plus_projection_B": dict(layout=_ss_layout("B"), bit_depth=16, frames=8, fs=1024, seed=223,
+                                       pair=("scalable", "toa_projection"), element_gain_q78=-256, element2_gain_q78=-512),
+    "projection_plus_scalable_C": dict(layout=_ss_layout("C"), bit_depth=16, frames=8, fs=1024, seed=224,
+                                       pair=("toa_projection", "scalable"), element_gain_q78=-512, element2_gain_q78=-128),
+    "projection_plus_projection_binaural": dict(layout=("binaural",), bit_depth=16, frames=6, fs=1024, seed=225,
+                                                pair=("toa_projection", "toa_projection"), element_gain_q78=-700,
+                                                element2_gain_q78=-900),
+    "l714dmx_plus_l714dmx_C": dict(layout=_ss_layout("C"), bit_depth=16, frames=8, fs=1024, seed=226,
+                                   pair=("l714dmx", "l714dmx"), element_gain_q78=-600, element2_gain_q78=-450,
+                                   dmx_modes=[1, 1, 2, 4, 5, 6, 0, 0], dmx_modes2=[4, 5, 0, 0, 1, 2, 6, 6]),
+    "l714dmx_plus_scalable_C": dict(layout=_ss_layout("C"), bit_depth=16, frames=8, fs=1024, seed=227,
+                                    pair=("l714dmx", "scalable"), element_gain_q78=-500, element2_gain_q78=-350,
+                                    dmx_modes=[6, 5, 4, 2, 1, 0, 0, 1], scalable_modes2=[1, 2, 2, 0, 6, 5, 4, 1]),
+    "scalable_plus_l714dmx_312": dict(layout=("ss", 11), bit_depth=16, frames=8, fs=1024, seed=228,
+                                      pair=("scalable", "l714dmx"), element_gain_q78=-450, element2_gain_q78=-550,
+                                      dmx_modes=[0, 1, 2, 4, 5, 6, 2, 1]),
     # a presentation that says more about itself (two layouts, true peak, anchored loudness): what
     # IAMF_decoder_get_last_metadata hands out (IAMF_decoder.c:3619-3706)
     "stereo_loudness_info": dict(layout=_ss_layout("A"), bit_depth=16, frames=4, fs=1024, seed=209, loudness_infos=True),
@@ -166,8 +190,8 @@ SCALABLE_GAINS = {0: (0b110000, -768), 1: (0b001111, 384)}   # layer -> (flags, 
 SCALABLE_MODES = [1, 1, 2, 4, 5, 6, 0, 2]
 
 
-def scalable_recon_bytes(frame, n):
-    rng = np.random.default_rng(5600 + frame)
+def scalable_recon_bytes(frame, n, salt=0):
+    rng = np.random.default_rng(5600 + frame + 1000 * salt)
     return [int(v) for v in rng.integers(100, 256, size=n)]
 
 
@@ -192,6 +216,10 @@ def _toa_element(eid, x, first_sid, sample_size):
 # ---- one element of a two-element presentation: descriptor, per-frame (parameter blocks, sub-streams), what the renderer sees ----
 def _pair_element(kind, eid, sid0, pid0, seed, n, fs, ss, rate, c):
     """returns (descriptor obus, frame -> (parameter block obus, [(sub-stream id, bytes)]), info element, sub-streams used)"""
+    second = eid == 2   # the second element's own schedules, where the case names them
+    dmx_modes = c.get("dmx_modes2" if second else "dmx_modes", c.get("dmx_modes"))
+    sc_modes = c.get("scalable_modes2", SCALABLE_MODES) if second else SCALABLE_MODES
+    salt = c.get("recon_salt2", 0) if second else 0
     if kind in ("stereo", "l51"):
         lay = 1 if kind == "stereo" else 2
         x = np.clip(synth.hot(seed, W.LAYOUT_CHANNELS[lay], n, sigma=0.18, burst_amp=0.5, burst_phase=350, burst_period=3100),
@@ -208,7 +236,7 @@ def _pair_element(kind, eid, sid0, pid0, seed, n, fs, ss, rate, c):
             x_al[a_] = xq[p_]
         desc = W.audio_element_channel(eid, 0, 7, list(range(sid0, sid0 + 7)),
                                        demixing=dict(pid=pid0, rate=rate, frame=fs, mode=1, w=3))
-        return (desc, lambda f: (W.demixing_block(pid0, c["dmx_modes"][f]),
+        return (desc, lambda f: (W.demixing_block(pid0, dmx_modes[f]),
                                  W.channel_element_substreams(7, x_al[:, f * fs:(f + 1) * fs], sid0, ss)),
                 dict(kind="channel", layout=7, x=xq), 7)
     if kind == "scalable":
@@ -228,8 +256,8 @@ def _pair_element(kind, eid, sid0, pid0, seed, n, fs, ss, rate, c):
                                         recon=dict(pid=pid0 + 1, rate=rate, frame=fs))
 
         def frame(f):
-            blocks = W.demixing_block(pid0, SCALABLE_MODES[f])
-            blocks += W.recon_gain_block(pid0 + 1, [(l["recon_flags"], scalable_recon_bytes(f, bin(l["recon_flags"]).count("1")))
+            blocks = W.demixing_block(pid0, sc_modes[f])
+            blocks += W.recon_gain_block(pid0 + 1, [(l["recon_flags"], scalable_recon_bytes(f, bin(l["recon_flags"]).count("1"), salt))
                                                     for l in wl if l["recon"]])
             subs, ch, sid = [], 0, sid0
             for l in wl:
@@ -239,7 +267,8 @@ def _pair_element(kind, eid, sid0, pid0, seed, n, fs, ss, rate, c):
                     ch += w
                     sid += 1
             return blocks, subs
-        return desc, frame, dict(kind="scalable", layers=layers, order=order, x=xd, wl=wl, gains=SCALABLE_GAINS), nsub
+        return desc, frame, dict(kind="scalable", layers=layers, order=order, x=xd, wl=wl, gains=SCALABLE_GAINS, modes=sc_modes,
+                                 salt=salt), nsub
     if kind == "toa_projection":
         subs_n, coupled = 10, 6
         rng = np.random.default_rng(seed)
@@ -525,4 +554,7 @@ META_CASES = {
     "l714dmx_plus_stereo_C": dict(pts=(0, 90000)),
     "l51_plus_projection_binaural": dict(pts=(0, 90000)),
     "stereo_fs128": dict(pts=(0, 90000)),
+    "l714dmx_plus_l714dmx_C": dict(pts=(0, 90000)),
+    "l714dmx_plus_scalable_C": dict(pts=(0, 48000)),
+    "scalable_plus_l714dmx_312": dict(pts=(17, 90000)),
 }

@@ -65,8 +65,8 @@ def demix_scalable(el, c):
     for f in range(c["frames"]):
         rg = None
         if rec and el["wl"][li]["recon"]:   # qf_to_float(byte, 8): double division, then float (fixedp11_5.c:53)
-            rg = [float(np.float32(np.float64(np.float32(v)) / 255.0)) for v in e2e_cases.scalable_recon_bytes(f, len(rec))]
-        sched.append((e2e_cases.SCALABLE_MODES[f], rg))
+            rg = [float(np.float32(np.float64(np.float32(v)) / 255.0)) for v in e2e_cases.scalable_recon_bytes(f, len(rec), el.get("salt", 0))]
+        sched.append((el.get("modes", e2e_cases.SCALABLE_MODES)[f], rg))
     case = dict(layout=layout, order=order, gains=gains, default=(1, 3), recon=rec, flags=flags, offset=0,
                 fs=c["fs"], schedule=sched)
     x = el["x"][:len(order)].reshape(len(order), c["frames"], c["fs"]).transpose(1, 0, 2)

@@ -30,7 +30,7 @@ hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)calloc(1, 8); ret
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { (void)s; return hipSuccess; }
 
-struct iamf_hip_batch { iamf_hip_batch_config cfg; int *pad_left; /* per stream: limiter delay still to withhold */ };
+struct iamf_hip_batch { iamf_hip_batch_config cfg; int *pad_left; /* per stream: limiter delay still to withhold */ int m2; };
 struct iamf_hip_resampler { int ch, in, out; };
 
 static const int k_ch[] = {2, 6, 8, 10, 11, 12, 14, 24, 8, 12};
@@ -84,7 +84,10 @@ int iamf_hip_batch_set_gains(iamf_hip_batch *b, const float *a, const float *c, 
   (void)b; (void)a; (void)c; (void)d; return 0;
 }
 int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *m, const float *g) {
-  (void)b; (void)m; (void)g; return 0;
+  (void)g;
+  if (!m || m->m <= 0 || m->m > 24) return IAMF_HIP_ERR_BAD_ARG;
+  b->m2 = m->m;
+  return 0;
 }
 int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *p, int l) { (void)b; (void)p; (void)l; return 0; }
 int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *c) { (void)b; (void)c; return 0; }
@@ -115,6 +118,9 @@ int iamf_hip_batch_render_range(iamf_hip_batch *b, const iamf_hip_render_args *a
     for (int64_t i = 0; i < (int64_t)b->cfg.matrix.m * b->cfg.frame_size && b->cfg.matrix.kind != IAMF_HIP_KIND_DMX; ++i) acc += in[i];
     (void)acc;
     if (a->d_element_ramp) acc += ((const volatile float *)a->d_element_ramp)[(int64_t)s * a->ramp_stream_stride + n - 1];
+    if (a->d_in2) /* the second element: m2 planar rows of the frame */
+      for (int c = 0; c < b->m2; ++c)
+        for (int i = 0; i < n; ++i) acc += ((const volatile float *)a->d_in2)[(int64_t)s * a->in2_stream_stride + (int64_t)c * b->cfg.frame_size + i];
     r = emit(b, s, a->d_pcm, a->pcm_stream_stride_bytes, n);
     if (r < 0) return r;
   }
@@ -135,6 +141,15 @@ int iamf_hip_batch_flush_range(iamf_hip_batch *b, void *pcm, int64_t cap, void *
 }
 int iamf_hip_batch_flush(iamf_hip_batch *b, void *pcm, int64_t cap, void *st) {
   return iamf_hip_batch_flush_range(b, pcm, cap, st, 0, b->cfg.n_streams);
+}
+int iamf_hip_deinterleave_f32(const float *src, int64_t sss, int32_t ch, int32_t ns, int32_t n, float *dst, int64_t dss, int64_t dcs,
+                              void *st) {
+  (void)st;
+  if (!src || !dst || ch <= 0 || ch > 24 || ns <= 0 || n < 0 || dcs < n) return IAMF_HIP_ERR_BAD_ARG;
+  for (int s = 0; s < ns; ++s)
+    for (int c = 0; c < ch; ++c)
+      for (int i = 0; i < n; ++i) dst[s * dss + c * dcs + i] = src[s * sss + (int64_t)i * ch + c];
+  return IAMF_HIP_OK;
 }
 int iamf_hip_stream_signal(void *st, volatile uint32_t *flag, uint32_t seq) { (void)st; *flag = seq; return IAMF_HIP_OK; }
 int iamf_hip_upload_by_kernel(const void *h, void *d, size_t n, void *st) {
