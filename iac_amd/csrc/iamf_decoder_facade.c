@@ -236,6 +236,8 @@ struct IAMF_Decoder {
   float dmx_static_s; /* the TL / TR factor the reference's shared table holds */
   float *d_aux_il, *d_aux_pl; /* device: aux's frame as it writes it [sample][channel], and planar for `batch` */
   float aux_gain_set;
+  iamf_hip_batch_config aux_sig; /* what `aux` was created from (mat pointer zeroed), and its matrix: as cfg_sig / cfg_mat */
+  const float *aux_mat;
   /* packets of the temporal unit being assembled */
   uint8_t *pkt[2][MAX_SUBSTREAMS];
   uint32_t pkt_len[2][MAX_SUBSTREAMS];
@@ -1254,6 +1256,9 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
     ca.out_format = IAMF_HIP_FMT_F32;
     ca.projection = IAMF_HIP_PROJ_EXACT;
     if (pre_decide(d, 1, &ca.matrix) || iamf_hip_batch_create(&ca, &d->aux)) return IAMF_ERR_INTERNAL;
+    d->aux_sig = ca;
+    d->aux_mat = ca.matrix.mat;
+    d->aux_sig.matrix.mat = 0;
     rc = pre_attach(d, 1, d->aux);
     if (rc) return rc;
     d->aux_gain_set = 1.f;

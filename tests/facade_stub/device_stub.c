@@ -24,6 +24,7 @@ hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t st) {
   (void)k; (void)st; memcpy(d, s, n); return hipSuccess;
 }
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind k) { (void)k; memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st) { (void)st; memset(d, v, n); return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)calloc(1, 8); return hipSuccess; }

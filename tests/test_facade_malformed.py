@@ -130,7 +130,8 @@ def test_scene_and_scalable_descriptors_fuzz(driver, tmp_path):
     import e2e_cases as E
     rng = np.random.default_rng(5)
     for n in ["toa_projection_B_s16", "scalable_J_s16", "scalable_312_dmx_s16", "l714_J_ramps", "l714_C_dmx",
-              "two_elements_A_s32", "stereo_441_to_48k"]:
+              "two_elements_A_s32", "stereo_441_to_48k", "scalable_plus_scalable_J", "scalable_plus_l714dmx_312",
+              "projection_plus_scalable_C"]:
         case = E.CASES[n]
         stream, _ = E.build(n)
         lay = "b" if case["layout"][0] == "binaural" else str(case["layout"][1])
@@ -249,3 +250,21 @@ def test_group_of_resampling_handles_matches_the_single_handle_totals(driver, gr
     assert "group_create 0" in out
     totals = [int(l.split()[2]) for l in out if l.startswith("total h")]
     assert totals == [want] * n, (totals, want)
+
+
+@pytest.mark.parametrize("name,n,threads", [("scalable_plus_scalable_J", 5, 2), ("l714dmx_plus_l714dmx_C", 9, 3),
+                                            ("projection_plus_projection_binaural", 3, 1)])
+def test_group_of_handles_with_a_batch_per_element(driver, group_driver, tmp_path, name, n, threads):
+    """round 4: presentations BOTH of whose elements need a per-stream stage (demixer / down-mixer / projection): element 1
+    goes through a batch of its own, its frame is transposed on the device and mixed in as a second element — single
+    handles and groups.  Here: the host side (two sets of stage records, the second batch's rows, the planar hand-over
+    buffer) under ASan / UBSan against the stub, handles out of step; PCM on the GPU (tests/test_gpu_group.py)."""
+    import e2e_cases as E
+    case = E.CASES[name]
+    stream, _ = E.build(name)
+    lay = "b" if case["layout"][0] == "binaural" else str(case["layout"][1])
+    want = int(run(driver, tmp_path, stream, layout=lay, bits=case["bit_depth"])[-1].split()[1])
+    assert want == case["frames"] * case["fs"]
+    out = run_group(group_driver, tmp_path, stream, n, threads, layout=lay, bits=case["bit_depth"])
+    assert "group_create 0" in out
+    assert [int(l.split()[2]) for l in out if l.startswith("total h")] == [want] * n

@@ -377,6 +377,30 @@ def test_stream_signal_writes_the_pinned_word_behind_the_queued_work(hip):
     assert A.lib().iamf_hip_stream_signal(st, None, 1) == -1
 
 
+@pytest.mark.parametrize("ch,n,S", [(2, 1024, 1), (6, 777, 3), (12, 1, 2), (24, 1024, 5), (8, 257, 4)])
+def test_deinterleave_f32_is_a_transposition(hip, ch, n, S):
+    """iamf_hip_deinterleave_f32: a batch's f32 sample-frames -> the planar form a batch reads (how the frame of an element
+    rendered by a batch of its own reaches the mixing batch as a second element); strides, short rows, untouched padding"""
+    A, G, torch = hip
+    rng = np.random.default_rng(ch * 1000 + n)
+    src_stride, ch_stride = n * ch + 24, n + 8
+    dst_stride = ch * ch_stride + 16
+    x = rng.standard_normal((S, src_stride)).astype(np.float32)
+    src = torch.from_numpy(x).cuda()
+    dst = torch.full((S, dst_stride), -7.0, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert A.lib().iamf_hip_deinterleave_f32(src.data_ptr(), src_stride, ch, S, n, dst.data_ptr(), dst_stride, ch_stride, st) == 0
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy()
+    for s in range(S):
+        want = np.full(dst_stride, -7.0, np.float32)
+        for c in range(ch):
+            want[c * ch_stride:c * ch_stride + n] = x[s, :n * ch].reshape(n, ch)[:, c]
+        assert np.array_equal(got[s], want), s
+    assert A.lib().iamf_hip_deinterleave_f32(src.data_ptr(), src_stride, 25, S, n, dst.data_ptr(), dst_stride, ch_stride, st) == -1
+    assert A.lib().iamf_hip_deinterleave_f32(src.data_ptr(), src_stride, ch, S, n, dst.data_ptr(), dst_stride, n - 1, st) == -1
+
+
 def test_resampled_pipeline_vs_oracle(hip):
     """44.1 kHz stereo element -> Sound System A at 48 kHz: render (f32) -> resample -> limiter +
     pack as three launches, against the oracle's stages in the decoder's order

@@ -77,4 +77,9 @@ SWITCH_CASES = {
     "switch_toa_H_to_binaural": dict(stream="toa_H_s16", layouts=[("ss", 7), ("binaural",)], after=[2]),
     "switch_scalable_C_to_A": dict(stream="scalable_C_s16", layouts=[("ss", 2), ("ss", 0)], after=[3]),
     "switch_dmx_C_to_J": dict(stream="l714_C_dmx", layouts=[("ss", 2), ("ss", 9)], after=[2]),
+    # both elements behind a stage of their own (a second batch for element 1): the demixers' and the down-mixers' states
+    # across the switch, per element; a layout after which only one / none of the two stages remains
+    "switch_2scalable_J_to_A_to_C": dict(stream="scalable_plus_scalable_J", layouts=[("ss", 9), ("ss", 0), ("ss", 2)], after=[3, 5]),
+    "switch_2dmx_C_to_312_to_J": dict(stream="l714dmx_plus_l714dmx_C", layouts=[("ss", 2), ("ss", 11), ("ss", 9)], after=[2, 5]),
+    "switch_scalable_dmx_312_to_B": dict(stream="scalable_plus_l714dmx_312", layouts=[("ss", 11), ("ss", 1)], after=[4]),
 }
