@@ -856,6 +856,8 @@ IAMF_DecoderHandle IAMF_decoder_open(void) { /* IAMF_decoder.c:3726-3744 */
 }
 
 static void free_runtime(struct IAMF_Decoder *d) {
+  if (d->aux) iamf_hip_batch_destroy(d->aux); /* (before `batch`, whose LFE filter state it may share) */
+  d->aux = 0;
   if (d->batch) iamf_hip_batch_destroy(d->batch);
   if (d->batch3) iamf_hip_batch_destroy(d->batch3);
   if (d->rs) iamf_hip_resampler_destroy(d->rs);
@@ -888,8 +890,6 @@ static void free_runtime(struct IAMF_Decoder *d) {
     d->pre[e].h_dmx = 0;
     d->pre[e].h_demix = 0;
   }
-  if (d->aux) iamf_hip_batch_destroy(d->aux);
-  d->aux = 0;
   if (d->d_aux_il) (void)hipFree(d->d_aux_il);
   if (d->d_aux_pl) (void)hipFree(d->d_aux_pl);
   d->d_aux_il = d->d_aux_pl = 0;
@@ -1180,8 +1180,13 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
       }
     }
     const int lfe_gen = d->lfe_hoa && d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION;
+    const int scene0 = d->sel_el[0]->type == AUDIO_ELEMENT_SCENE_BASED;
+    const int scene1 = p->nel == 2 && d->sel_el[1]->type == AUDIO_ELEMENT_SCENE_BASED;
+    /* Two scene-based elements and the LFE generator: the reference has ONE filter per output layout (IAMF_decoder.c:
+     * 2629-2632), both W channels run through it in turn, in presentation order.  `aux` renders before `batch` and the two
+     * share the filter state (iamf_hip_batch_share_lfe_state): the EARLIER element of the presentation must be element 1. */
     if (p->nel == 2 && needs[1] &&
-        (!needs[0] || (lfe_gen && d->sel_el[1]->type == AUDIO_ELEMENT_SCENE_BASED && d->sel_el[0]->type != AUDIO_ELEMENT_SCENE_BASED))) {
+        (!needs[0] || (lfe_gen && scene1 && !scene0) || (lfe_gen && scene1 && scene0 && !d->swapped))) {
       const uint64_t id = p->el_id[0];
       const ParamDef pd = p->el_gain_def[0];
       const int16_t q = p->el_gain_q[0];
@@ -1203,15 +1208,9 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
       aux = 1;
     }
   }
-  /* IAMF_decoder.c:2625-2633: scene-based element, LFE generator compiled in, layout with an LFE.  The
-   * reference keeps ONE filter per output layout, so two scene-based elements would run their W
-   * channels through the same histories in turn; only the single-filter case is taken here */
-  if (d->lfe_hoa && d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION) {
-    int scene = 0;
-    for (int i = 0; i < p->nel; ++i) scene += d->sel_el[i]->type == AUDIO_ELEMENT_SCENE_BASED;
-    if (scene > 1 || (scene == 1 && d->sel_el[0]->type != AUDIO_ELEMENT_SCENE_BASED)) return IAMF_ERR_UNIMPLEMENTED;
-    cfg.lfe_hoa = scene == 1;
-  }
+  /* IAMF_decoder.c:2625-2633: scene-based element, LFE generator compiled in, layout with an LFE */
+  if (d->lfe_hoa && d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION)
+    cfg.lfe_hoa = d->sel_el[0]->type == AUDIO_ELEMENT_SCENE_BASED;
   d->el_dmx_mode[0] = d->el_dmx_mode[1] = -1; /* cctx->dmx_mode = INVALID_VALUE at stream creation, :1728 */
   if (pre_decide(d, 0, &cfg.matrix)) return IAMF_ERR_INTERNAL;
   if (resample) {
@@ -1255,7 +1254,10 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
     ca.out_channels = d->out_channels;
     ca.out_format = IAMF_HIP_FMT_F32;
     ca.projection = IAMF_HIP_PROJ_EXACT;
+    ca.lfe_hoa = cfg.lfe_hoa && d->sel_el[1]->type == AUDIO_ELEMENT_SCENE_BASED; /* (then element 0 is scene-based too) */
     if (pre_decide(d, 1, &ca.matrix) || iamf_hip_batch_create(&ca, &d->aux)) return IAMF_ERR_INTERNAL;
+    /* both batches have a generator only if both matrices have an LFE slot — the same output layout: both or neither */
+    if (ca.lfe_hoa && iamf_hip_batch_share_lfe_state(d->aux, d->batch) == IAMF_HIP_ERR_INVALID_STATE) return IAMF_ERR_INTERNAL;
     d->aux_sig = ca;
     d->aux_mat = ca.matrix.mat;
     d->aux_sig.matrix.mat = 0;

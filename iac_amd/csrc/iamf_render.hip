@@ -240,6 +240,7 @@ struct iamf_hip_batch {
   float lfe_a1 = 0.f, lfe_a2 = 0.f, lfe_a3 = 0.f, lfe_b1 = 0.f, lfe_b2 = 0.f;
   double lfe_div = 0.0;
   float *d_lfe_state = nullptr, *d_lfe_next = nullptr, *d_lfe_u = nullptr;
+  bool lfe_shared = false;   // d_lfe_state / d_lfe_next belong to another batch (iamf_hip_batch_share_lfe_state)
   size_t lfe_u_floats = 0;
   // fixed PCM channel stride (cfg.pcm_stride_channels): the kernels pack into d_nat, restride_kernel re-lays
   uint8_t *d_nat = nullptr;
@@ -283,7 +284,7 @@ int reset_state(iamf_hip_batch *b) {
     for (float *q : b->d_fir_pre)
       if (q) HIPCHK(hipMemset(q, 0, b->fir_pre_bytes));
   }
-  if (b->lfe) {  // lfefilter_init zeroes both histories (h2m_rdr.c:1210-1211)
+  if (b->lfe && !b->lfe_shared) {  // lfefilter_init zeroes both histories (h2m_rdr.c:1210-1211)
     HIPCHK(hipMemset(b->d_lfe_state, 0, sizeof(float) * 4 * (size_t)ns));
     HIPCHK(hipMemset(b->d_lfe_next, 0, sizeof(float) * 2 * (size_t)ns));
   }
@@ -1107,8 +1108,10 @@ void iamf_hip_batch_destroy(iamf_hip_batch *b) {
   (void)hipFree(b->d_lp_in);
   (void)hipFree(b->d_fir_id);
   (void)hipFree(b->d_fir_id_feed);
-  (void)hipFree(b->d_lfe_state);
-  (void)hipFree(b->d_lfe_next);
+  if (!b->lfe_shared) {
+    (void)hipFree(b->d_lfe_state);
+    (void)hipFree(b->d_lfe_next);
+  }
   (void)hipFree(b->d_lfe_u);
   (void)hipFree(b->d_nat);
   (void)hipFree(b->d_dump);
@@ -1332,6 +1335,24 @@ int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *
   HIPCHK(hipMemcpy(b->d_src_feed2, feed, sizeof(feed), hipMemcpyHostToDevice));
   b->m2 = mx->m;
   b->has2 = true;
+  return IAMF_HIP_OK;
+}
+
+// The reference keeps the LFE generator's filter in the OUTPUT LAYOUT (IAMF_decoder.c:2629-2632: plfe =
+// &stream->final_layout->sp.lfe_f), not in the stream: two scene-based elements of one presentation push their W channels
+// through the same two histories in turn.  Two batches that render such a pair share the state: `b` adopts `owner`'s; the
+// caller issues the calls of a frame in presentation order on one HIP stream.
+int iamf_hip_batch_share_lfe_state(iamf_hip_batch *b, iamf_hip_batch *owner) {
+  if (!b || !owner || b == owner) return IAMF_HIP_ERR_BAD_ARG;
+  if (!on_batch_device(b) || !on_batch_device(owner)) return IAMF_HIP_ERR_INVALID_STATE;
+  if (!b->lfe || !owner->lfe || owner->lfe_shared || b->lfe_shared || b->any_rendered || owner->any_rendered ||
+      b->cfg.n_streams != owner->cfg.n_streams || b->cfg.sample_rate != owner->cfg.sample_rate)
+    return IAMF_HIP_ERR_BAD_ARG;
+  (void)hipFree(b->d_lfe_state);
+  (void)hipFree(b->d_lfe_next);
+  b->d_lfe_state = owner->d_lfe_state;
+  b->d_lfe_next = owner->d_lfe_next;
+  b->lfe_shared = true;
   return IAMF_HIP_OK;
 }
 

@@ -204,6 +204,12 @@ void iamf_hip_dmx_coefficients(const iamf_hip_dmx_state *st, float out[5]);
 int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *mx,
                                       const float *element2_gain);
 
+/* HOA LFE generator with TWO scene-based elements: the reference keeps the filter in the output layout
+ * (IAMF_decoder.c:2629-2632, h2m_rdr.c:1151-1239), so both elements' W channels run through the same two histories in
+ * turn, frame by frame, in presentation order.  Two batches created with lfe_hoa (same n_streams and sample rate, nothing
+ * rendered yet) that render such a pair: `b` adopts `owner`'s filter state; the caller issues each frame's calls in
+ * presentation order on ONE HIP stream, and destroys `b` before `owner`.  IAMF_HIP_OK / _BAD_ARG / _INVALID_STATE. */
+int iamf_hip_batch_share_lfe_state(iamf_hip_batch *b, iamf_hip_batch *owner);
 /* Ambisonics projection de-mapping in front of element 0's renderer (projection-mode scene-based
  * elements): x[r] = sum over the l_in decoded channels l, ascending, of in[l] * matrix[l*m + r]
  * (iamf_core_decoder_convert_projection, src/iamf_dec/IAMF_core_decoder.c:116-130).  `matrix` is a

@@ -90,6 +90,9 @@ int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *
   b->m2 = m->m;
   return 0;
 }
+int iamf_hip_batch_share_lfe_state(iamf_hip_batch *b, iamf_hip_batch *o) {
+  return b && o && b != o && b->cfg.lfe_hoa && o->cfg.lfe_hoa && b->cfg.n_streams == o->cfg.n_streams ? 0 : IAMF_HIP_ERR_BAD_ARG;
+}
 int iamf_hip_batch_set_projection(iamf_hip_batch *b, const float *p, int l) { (void)b; (void)p; (void)l; return 0; }
 int iamf_hip_batch_set_demixer(iamf_hip_batch *b, const iamf_hip_demix_config *c) { (void)b; (void)c; return 0; }
 static int emit(iamf_hip_batch *b, int s, void *pcm, int64_t cap, int n) {

@@ -65,11 +65,81 @@ E2E = {
     "toa_G_s16": dict(order=3, ss="G", bit_depth=16, frames=4, fs=1024, seed=211),
     "foa_E_s24": dict(order=1, ss="E", bit_depth=24, frames=4, fs=1024, seed=212),
     "toa_D_s16": dict(order=3, ss="D", bit_depth=16, frames=5, fs=1024, seed=213),
+    # round 4: presentations of TWO elements.  A scene-based element beside a channel-based one (plain or scalable), in
+    # either position; and two scene-based elements: the reference keeps ONE filter per output layout
+    # (IAMF_decoder.c:2629-2632: plfe = &stream->final_layout->sp.lfe_f), so the two W channels run through the same
+    # two histories in turn, frame by frame, in presentation order
+    "toa_plus_stereo_B_s16": dict(order=3, ss="B", bit_depth=16, frames=5, fs=1024, seed=214, second=("stereo",), gains=(-300, -500)),
+    "stereo_plus_toa_J_s16": dict(order=3, ss="J", bit_depth=16, frames=5, fs=1024, seed=215, second=("stereo",), scene_second=True,
+                                  gains=(-200, -600)),
+    "toa_plus_scalable_C_s16": dict(order=3, ss="C", bit_depth=16, frames=8, fs=1024, seed=216, second=("scalable",), gains=(-400, -350)),
+    "scalable_plus_foa_D_s24": dict(order=1, ss="D", bit_depth=24, frames=8, fs=1024, seed=217, second=("scalable",), scene_second=True,
+                                    gains=(-500, -250)),
+    "toa_plus_foa_B_s16": dict(order=3, ss="B", bit_depth=16, frames=6, fs=1024, seed=218, second=("scene", 1), gains=(-450, -300)),
+    "foa_plus_toa_J_s16": dict(order=1, ss="J", bit_depth=16, frames=6, fs=1024, seed=219, second=("scene", 3), gains=(-350, -550)),
+    "toa_projection_plus_soa_F_s16": dict(order=3, ss="F", bit_depth=16, frames=5, fs=1024, seed=220, projection=True,
+                                          second=("scene", 2), gains=(-600, -400)),
 }
+
+
+def build_pair(name):
+    """two-element presentations: element 1 = the case's scene-based element (mono or projection mode), element 2 =
+    c["second"]; c["scene_second"] puts them into the presentation (and the stream) the other way round"""
+    import e2e_cases as E
+    c = E2E[name]
+    fs, F, rate = c["fs"], c["frames"], 48000
+    n = fs * F
+    m = (c["order"] + 1) ** 2
+    pd = lambda pid: W.param_definition(pid, rate, mode=1)
+    s = W.sequence_header(1) + W.codec_config_lpcm(0, fs, 16, rate)
+
+    def scene(eid, sid0, order, seed, projection):
+        mm = (order + 1) ** 2
+        xq = W.quantize(programme(seed, mm, n, rate), 16)
+        if projection:
+            subs_n, coupled = 10, 6
+            rng = np.random.default_rng(seed)
+            pq = rng.integers(-9000, 9000, size=(subs_n + coupled, mm)).astype(np.int16)
+            pq[np.arange(mm), np.arange(mm)] = 29000
+            desc = W.audio_element_ambisonics_projection(eid, 0, mm, list(range(sid0, sid0 + subs_n)), coupled, pq)
+
+            def frame(f):
+                subs, ch = [], 0
+                for i in range(subs_n):
+                    w = 2 if i < coupled else 1
+                    subs.append((sid0 + i, W.lpcm_bytes(xq[ch:ch + w, f * fs:(f + 1) * fs], 16)))
+                    ch += w
+                return b"", subs
+            return desc, frame, subs_n
+        desc = W.audio_element_ambisonics_mono(eid, 0, mm, list(range(sid0, sid0 + mm)))
+        return desc, (lambda f: (b"", [(sid0 + i, W.lpcm_bytes(xq[i:i + 1, f * fs:(f + 1) * fs], 16)) for i in range(mm)])), mm
+
+    specs = [("scene", c["order"], c.get("projection", False)), c["second"]]
+    if c.get("scene_second"):
+        specs.reverse()
+    descs, frames, sid = [], [], 0
+    for k, sp in enumerate(specs):
+        if sp[0] == "scene":
+            d, fr, ns = scene(k + 1, sid, sp[1], c["seed"] + 10 * k, sp[2] if len(sp) > 2 else False)
+        else:
+            d, fr, _, ns = E._pair_element(sp[0], k + 1, sid, 200 + 10 * k, c["seed"] + 10 * k, n, fs, 16, rate, c)
+        descs.append(d)
+        frames.append(fr)
+        sid += ns
+    s += descs[0] + descs[1]
+    s += W.mix_presentation(1, [dict(eid=1, pdef=pd(100), default_q78=c["gains"][0]), dict(eid=2, pdef=pd(102), default_q78=c["gains"][1])],
+                            dict(pdef=pd(101), default_q78=0), [("ss", SS_ENUM[c["ss"]])])
+    for f in range(F):
+        ba, sa = frames[0](f)
+        bb, sb = frames[1](f)
+        s += W.temporal_delimiter() + ba + bb + W.audio_frames(sa + sb)
+    return s, None
 
 
 def build(name):
     c = E2E[name]
+    if c.get("second"):
+        return build_pair(name)
     fs, F, rate = c["fs"], c["frames"], c.get("rate", 48000)
     m = (c["order"] + 1) ** 2
     x = programme(c["seed"], m, fs * F, rate, c.get("silence_from"))

@@ -184,6 +184,8 @@ def test_lfe_e2e_through_the_oracle_stream(golden):
     import lfe_cases as LC
     g = golden.npz("lfe")
     for name, c in LC.E2E.items():
+        if c.get("second"):   # two elements (one shared filter, a stage per element): the facade against this golden (-m gpu)
+            continue
         _, xq = LC.build(name)
         oid = LC.SS[c["ss"]]
         mx = O.get_h2m(c["order"], oid)
