@@ -180,6 +180,23 @@ CASES = {
     "scalable_plus_l714dmx_312": dict(layout=("ss", 11), bit_depth=16, frames=8, fs=1024, seed=228,
                                       pair=("scalable", "l714dmx"), element_gain_q78=-450, element2_gain_q78=-550,
                                       dmx_modes=[0, 1, 2, 4, 5, 6, 2, 1]),
+    # ... with animated mix gains on both elements and the output (element 1's ramp is applied by the second batch), with
+    # trimmed first / last frames (both demixers start inside a frame), and behind the resampler
+    "scalable_plus_scalable_J_ramps": dict(layout=_ss_layout("J"), bit_depth=16, frames=8, fs=1024, seed=231,
+                                           pair=("scalable", "scalable"), pair_ramps=True, scalable_modes2=[2, 0, 1, 6, 5, 4, 4, 1],
+                                           recon_salt2=79),
+    "stereo_plus_scalable_C_ramps": dict(layout=_ss_layout("C"), bit_depth=16, frames=8, fs=1024, seed=232,
+                                         pair=("stereo", "scalable"), pair_ramps=True),
+    "l714dmx_plus_l714dmx_C_trim": dict(layout=_ss_layout("C"), bit_depth=16, frames=8, fs=1024, seed=233,
+                                        pair=("l714dmx", "l714dmx"), element_gain_q78=-300, element2_gain_q78=-420,
+                                        dmx_modes=[1, 2, 4, 5, 6, 0, 0, 1], dmx_modes2=[6, 5, 4, 0, 1, 2, 2, 0],
+                                        trims={0: (100, 0), 7: (0, 300)}),
+    "scalable_plus_projection_B_trim": dict(layout=_ss_layout("B"), bit_depth=24, frames=8, fs=1024, seed=234,
+                                            pair=("scalable", "toa_projection"), element_gain_q78=-256, element2_gain_q78=-512,
+                                            trims={0: (260, 0), 3: (0, 0), 7: (0, 41)}),
+    "scalable_plus_scalable_A_441_to_48k": dict(layout=_ss_layout("A"), bit_depth=16, frames=8, fs=1024, seed=235, rate=44100,
+                                                out_rate=48000, pair=("scalable", "scalable"), element_gain_q78=-350,
+                                                element2_gain_q78=-450, recon_salt2=80),
     # a presentation that says more about itself (two layouts, true peak, anchored loudness): what
     # IAMF_decoder_get_last_metadata hands out (IAMF_decoder.c:3619-3706)
     "stereo_loudness_info": dict(layout=_ss_layout("A"), bit_depth=16, frames=4, fs=1024, seed=209, loudness_infos=True),
@@ -322,10 +339,21 @@ def build(name):
                                          dict(eid=2, pdef=_pdef_static(102, rate), default_q78=c.get("element2_gain_q78", 0))],
                                      dict(pdef=_pdef_static(101, rate), default_q78=og), layouts_field)
         info["elements"] += [ia, ib]
+        m1 = dict(duration=fs, constant_interval=fs)
         for f in range(F):
             ba, sa = fa(f)
             bb, sb = fb(f)
-            stream += W.temporal_delimiter() + ba + bb + W.audio_frames(sa + sb)
+            stream += W.temporal_delimiter()
+            if c.get("pair_ramps"):   # mix-gain blocks of both elements and (from the second frame on) of the output
+                a0, b0 = -64 * f, -700 + 90 * f
+                stream += W.mix_gain_block(100, [dict(anim=W.ANIM_LINEAR, start=a0, end=a0 - 64)], mode1=m1)
+                stream += W.mix_gain_block(102, [dict(anim=W.ANIM_BEZIER, start=b0, end=b0 + 90, control=b0 + 200, rel_time=40 + 20 * f)
+                                                 if f % 3 != 2 else dict(anim=W.ANIM_STEP, start=b0)], mode1=m1)
+                if f >= 1:
+                    stream += W.mix_gain_block(101, [dict(anim=W.ANIM_LINEAR, start=100 - 40 * f, end=60 - 40 * f),
+                                                     dict(anim=W.ANIM_STEP, start=60 - 40 * f)],
+                                               mode1=dict(duration=fs, constant_interval=0, intervals=[fs // 4, fs - fs // 4]))
+            stream += ba + bb + W.audio_frames(sa + sb, trim=c.get("trims", {}).get(f))
         return stream, info
     if name == "stereo_loudness_info":
         x = synth.uniform(c["seed"], 2, n, 0.7)

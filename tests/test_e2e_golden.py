@@ -8,7 +8,7 @@ import e2e_model
 
 
 SIMPLE = [n for n, c in sorted(e2e_cases.CASES.items())
-          if not (c.get("ramps") or c.get("concat") or c.get("dmx_modes") or c.get("out_rate") or c.get("trims") or "_dmx_" in n)]
+          if not (c.get("ramps") or c.get("pair_ramps") or c.get("concat") or c.get("dmx_modes") or c.get("out_rate") or c.get("trims") or "_dmx_" in n)]
 
 
 @pytest.mark.parametrize("name", SIMPLE)
