@@ -197,6 +197,7 @@ struct iamf_hip_batch {
   std::vector<int64_t> spos;        // samples consumed, per stream (streams advance together unless the range calls are used)
   std::vector<uint8_t> sflushed;    // per stream: the limiter's tail has been emitted
   bool any_rendered = false;        // the setters that must precede the first render check this
+  bool lp_scale_ok = false;         // every non-zero weight w has w * 2^-15 exact and w * 2^-15 * sample normal (fused LPCM form)
   float *d_matrix = nullptr, *d_gains = nullptr, *d_ctab = nullptr, *d_ring_y = nullptr,
         *d_ring_pm = nullptr;
   LimState *d_lim = nullptr;
@@ -584,7 +585,7 @@ constexpr int kNotFused = INT32_MIN;
 int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int s0, int cnt, const LpcmIn *lp = nullptr) {
   if (!on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
   if (lp && (b->fir || b->lfe || b->d_pre || b->demix || b->dmx || b->has2 || a.d_element_ramp || a.d_element2_ramp ||
-             a.d_output_ramp || getenv("IAMF_HIP_LPCM_UNFUSED")))
+             a.d_output_ramp || !b->lp_scale_ok || getenv("IAMF_HIP_LPCM_UNFUSED")))
     return kNotFused;
   if (s0 < 0 || cnt <= 0 || s0 + cnt > b->cfg.n_streams) return IAMF_HIP_ERR_BAD_ARG;
   const int64_t pos = b->spos[(size_t)s0];
@@ -923,6 +924,13 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
     fm.assign(mx.mat, mx.mat + (size_t)2 * mx.m * cfg->fir_taps);
   } else {
     build_feed_map(mx, cfg->out_channels, fm, b->src_feed);
+    // The fused LPCM kernel folds the LPCM decoder's "/ 32768" into the weights: (w * 2^-15) * (float)s has the bits of
+    // w * (s * 2^-15) as long as neither the scaled weight nor a product leaves the normal range — scaling by a power of two
+    // commutes with rounding there.  True of every table of the reference (|w| in 1e-4 .. 2); a caller's own matrix with
+    // weights below 2^-100 takes the unfused path.
+    b->lp_scale_ok = true;
+    for (float w : fm)
+      if (w != 0.f && !(fabsf(w) >= 0x1p-100f && fabsf(w) <= 0x1p100f)) b->lp_scale_ok = false;
     if (cfg->lfe_hoa && mx.kind == IAMF_HIP_KIND_H2M && (mx.lfe1 >= 0 || mx.lfe2 >= 0)) {
       // HOA LFE generator on (the reference built -DDISABLE_LFE_HOA=0): lfefilter_init(plfe, 120, rate),
       // h2m_rdr.c:1192-1212, in the reference's own expression types

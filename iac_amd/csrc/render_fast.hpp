@@ -270,7 +270,10 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
     if (!FIR && !DOWN && t < OC * M) {
       const int c = t / M, m = t - c * M;
       const int f = p.src_feed[c];
-      mat[t] = f >= 0 ? p.matrix[f * M + m] : 0.f;
+      // LP: the LPCM decoder's "sample / 32768.f" (pcm/IAMF_pcm_decoder.c:64-83) is folded into the weight — (w * 2^-15) *
+      // (float)s has the bits of w * (s * 2^-15): a power of two commutes with rounding in the normal range, which the host
+      // has checked for this matrix (iamf_hip_batch::lp_scale_ok).  Two packed multiplies per channel and chunk less.
+      mat[t] = (f >= 0 ? p.matrix[f * M + m] : 0.f) * (LP ? 1.0f / 32768.0f : 1.0f);
     }
     if (IN2 && p.in2 && t < OC * kFIn2) {
       const int c = t / kFIn2, m = t - c * kFIn2;
@@ -491,10 +494,9 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
             asm volatile("" : "+v"(xr[m].x), "+v"(xr[m].y), "+v"(prj[0]), "+v"(prj[1]), "+v"(prj[2]), "+v"(prj[3]));
           else
             asm volatile("" : "+v"(xr[m].x), "+v"(xr[m].y), "+v"(prj[0]), "+v"(prj[1]));
-          const unsigned a = xr[m].x, b = xr[m].y;
-          const f2 sc = {1.0f / 32768.0f, 1.0f / 32768.0f};
-          xa = f2{(float)(int)(short)(a & 0xffffu), (float)((int)a >> 16)} * sc;
-          xb = f2{(float)(int)(short)(b & 0xffffu), (float)((int)b >> 16)} * sc;
+          const unsigned a = xr[m].x, b = xr[m].y;   // (the scale 2^-15 sits in the weights: see where `mat` is filled)
+          xa = f2{(float)(int)(short)(a & 0xffffu), (float)((int)a >> 16)};
+          xb = f2{(float)(int)(short)(b & 0xffffu), (float)((int)b >> 16)};
         } else {
           // (the same ordering for the f32 element: channel m is taken up when channel m - 1 has been added up, so that the
           //  weights of one group of four channels are all that is live beside the samples)

@@ -144,6 +144,31 @@ def test_mono_coded_ambisonics_s16_equals_the_f32_path(order, out, unfused, monk
         assert np.array_equal(got[s], want[s]), "stream %d" % s
 
 
+def test_weights_outside_the_range_of_the_folded_scale_take_the_unfused_form():
+    """The fused kernel keeps the LPCM decoder's "/ 32768" in its weights ((w * 2^-15) * (float)s has the bits of
+    w * (s * 2^-15) while everything stays normal); a caller's matrix with a weight below 2^-100 must not take that form.
+    Same PCM as the f32 path either way — here with weights that would underflow if scaled first."""
+    import ctypes as C
+    rng = np.random.default_rng(321)
+    ch, fs, S, F = 16, 1024, 3, 3
+    base = A.get_h2m_matrix(3, A.SS["BINAURAL"])
+    w = np.ctypeslib.as_array(base.mat, shape=(base.m * base.n,)).copy()
+    w[5] = np.float32(1.5e-38)          # normal, but w * 2^-15 is subnormal
+    w[21] = np.float32(-3e-41)          # subnormal already
+    w[7] = np.float32(2.0 ** -120)
+    keep = w   # the batch copies the matrix at create; keep the array alive until then
+    mx = A.Matrix()
+    C.memmove(C.byref(mx), C.byref(base), C.sizeof(A.Matrix))
+    mx.mat = keep.ctypes.data_as(A.FP)
+    ints = _ints(rng, S, F, ch, fs, 2)
+    perm = list(range(ch))
+    raw, L, row = _rows(ints, 2, True, [1] * ch, perm, head=16, pad=0, frame_size=fs)
+    got = _render_lpcm(mx, 2, raw, L, row, fs, [F])
+    want = _reference_bytes(mx, 2, ints, 2, perm, fs, [F])
+    for s in range(S):
+        assert np.array_equal(got[s], want[s]), "stream %d" % s
+
+
 @pytest.mark.parametrize("bps,le", [(2, False), (3, True), (3, False), (4, True), (4, False)])
 def test_other_sample_formats_take_the_general_form(bps, le):
     rng = np.random.default_rng(200 + bps * 2 + le)
