@@ -180,6 +180,7 @@ typedef struct {
   int layout_type[8], layout_ss[8];
   IAMF_LoudnessInfo loud[8];              /* anchor_loudness stays NULL here: the values live in anchors[] */
   anchor_loudness_t anchors[8][MAX_ANCHORS];
+  int swapped; /* the two element entries above were exchanged for the batch (setup_pipeline): batch order != stream order */
 } Presentation;
 
 /* The per-stream stage one element can need in front of its renderer: the demixer of a scalable / output-gained channel
@@ -278,7 +279,6 @@ struct IAMF_Decoder {
   uint64_t meta_duration;   /* ctx->duration: samples returned since IAMF_decoder_set_pts */
   int el_dmx_mode[2];       /* cctx->dmx_mode of the presentation's elements (batch order), -1 = none yet */
   uint32_t meta_dmixp;      /* ctx->metadata.param->dmixp_mode */
-  int swapped;              /* the presentation's two elements were exchanged for the batch (setup_pipeline) */
   int started;      /* a configure call with data has been made: status left INIT */
   int need_reconf;  /* a new IA sequence header was met while decoding: status RECONFIGURE */
 };
@@ -922,7 +922,6 @@ static void reset_descriptors(struct IAMF_Decoder *d) {
   d->pre[0].dmx_mode = d->pre[1].dmx_mode = -1;
   d->el_dmx_mode[0] = d->el_dmx_mode[1] = -1;
   d->meta_dmixp = 0;
-  d->swapped = 0;
   d->tu_trim_start = d->tu_trim_end = 0;
   d->timestamp = 0;
   d->last_frame = 0;
@@ -1186,7 +1185,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
      * 2629-2632), both W channels run through it in turn, in presentation order.  `aux` renders before `batch` and the two
      * share the filter state (iamf_hip_batch_share_lfe_state): the EARLIER element of the presentation must be element 1. */
     if (p->nel == 2 && needs[1] &&
-        (!needs[0] || (lfe_gen && scene1 && !scene0) || (lfe_gen && scene1 && scene0 && !d->swapped))) {
+        (!needs[0] || (lfe_gen && scene1 && !scene0) || (lfe_gen && scene1 && scene0 && !p->swapped))) {
       const uint64_t id = p->el_id[0];
       const ParamDef pd = p->el_gain_def[0];
       const int16_t q = p->el_gain_q[0];
@@ -1202,7 +1201,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
       p->el_gain_q[1] = q;
       d->sel_el[1] = e;
       d->el_gain_p[1] = gp;
-      d->swapped ^= 1; /* (a second configuration of the same descriptors finds them exchanged already) */
+      p->swapped ^= 1; /* (a second configuration of the same descriptors finds them exchanged already) */
       aux = needs[0];
     } else if (p->nel == 2 && needs[1]) {
       aux = 1;
@@ -1279,7 +1278,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   d->dmx_last = 0;
   d->dmx_static_s = 0.f;
   for (int k = 0; k < p->nel; ++k) { /* DMRenderer_open + DMRenderer_set_mode_weight(default), in presentation order */
-    const int e = d->swapped ? p->nel - 1 - k : k;
+    const int e = p->swapped ? p->nel - 1 - k : k;
     if (!d->pre[e].use_dmx || (e == 1 && !aux)) continue;
     d->dmx_last = e;
     if (d->sel_el[e]->layout != IA_CHANNEL_LAYOUT_312) d->dmx_static_s = d->pre[e].dmx.gamma_w;
@@ -1403,33 +1402,37 @@ int IAMF_decoder_configure(IAMF_DecoderHandle d, const uint8_t *data, uint32_t s
      * while the decoders, the parameter database and the stream time go on: everything that belongs to them is kept
      * across the rebuild of the pipeline. */
     const uint64_t ts = d->timestamp;
-    const int was_swapped = d->swapped, el_mode0 = d->el_dmx_mode[0], el_mode1 = d->el_dmx_mode[1];
+    const int el_mode[2] = {d->el_dmx_mode[0], d->el_dmx_mode[1]};
+    const Element *was_el[2] = {d->sel_el[0], d->sel ? (d->sel->nel > 1 ? d->sel_el[1] : 0) : 0};
     const int had_limiter = d->limiter_on && d->configured;
     Pre was[2]; /* (values only: the pinned records they point to go with the old pipeline) */
     memcpy(was, d->pre, sizeof(was));
     rc = setup_pipeline(d);
     if (rc == IAMF_OK) {
       d->timestamp = ts;
-      /* the stream contexts (and their demixing modes) live on; if this layout exchanges the elements the other way
-       * round, the modes follow their elements */
-      d->el_dmx_mode[0] = was_swapped == d->swapped ? el_mode0 : el_mode1;
-      d->el_dmx_mode[1] = was_swapped == d->swapped ? el_mode1 : el_mode0;
       if (had_limiter) { /* IAMF_decoder.c:3837-3842: the limiter's delayed samples are counted as delivered */
         d->meta_duration += 240;
         d->last_frame += 240;
       }
-      for (int e = 0; e < 2; ++e) {
-        const Pre *o = &was[was_swapped == d->swapped ? e : 1 - e];
+      /* the stream contexts (demixing modes, recon gains, the demixers' histories) live on: every element of the new
+       * pipeline takes up what the SAME element left, whichever position it had (a layout may exchange the two the other
+       * way round, another mix presentation may bring other elements) */
+      for (int e = 0; e < d->sel->nel; ++e) {
+        int o = -1;
         Pre *q = &d->pre[e];
-        q->dmx_mode = o->dmx_mode;
-        memcpy(q->layer_rec_flags, o->layer_rec_flags, sizeof(q->layer_rec_flags));
-        memcpy(q->layer_rec_gain, o->layer_rec_gain, sizeof(q->layer_rec_gain));
-        if (o->use_demix && q->use_demix) { /* the demixer is part of the stream decoder, which is not re-opened */
-          q->dmst = o->dmst;
-          q->rec_flags = o->rec_flags;
-          q->rec_n = o->rec_n;
-          memcpy(q->rec_ch, o->rec_ch, sizeof(q->rec_ch));
-          memcpy(q->rec_gain, o->rec_gain, sizeof(q->rec_gain));
+        for (int k = 0; k < 2; ++k)
+          if (was_el[k] && was_el[k] == d->sel_el[e]) o = k;
+        if (o < 0) continue;
+        d->el_dmx_mode[e] = el_mode[o];
+        q->dmx_mode = was[o].dmx_mode;
+        memcpy(q->layer_rec_flags, was[o].layer_rec_flags, sizeof(q->layer_rec_flags));
+        memcpy(q->layer_rec_gain, was[o].layer_rec_gain, sizeof(q->layer_rec_gain));
+        if (was[o].use_demix && q->use_demix) { /* the demixer is part of the stream decoder, which is not re-opened */
+          q->dmst = was[o].dmst;
+          q->rec_flags = was[o].rec_flags;
+          q->rec_n = was[o].rec_n;
+          memcpy(q->rec_ch, was[o].rec_ch, sizeof(q->rec_ch));
+          memcpy(q->rec_gain, was[o].rec_gain, sizeof(q->rec_gain));
         }
       }
     }
@@ -1580,7 +1583,7 @@ static void meta_note_frame(struct IAMF_Decoder *d, int s0, uint64_t trim_end) {
   const int fs = (int)d->frame_size;
   if (s0 > 0 && s0 != fs && trim_end != (uint64_t)fs) d->pts += time_transform(s0, (int)d->rate, (int)d->pts_base);
   for (int k = 0; k < d->sel->nel; ++k) {
-    const int e = d->swapped ? d->sel->nel - 1 - k : k;
+    const int e = d->sel->swapped ? d->sel->nel - 1 - k : k;
     if (d->sel_el[e]->type == AUDIO_ELEMENT_CHANNEL_BASED && d->el_dmx_mode[e] >= 0) d->meta_dmixp = (uint32_t)d->el_dmx_mode[e];
   }
 }
@@ -1677,7 +1680,7 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
   }
   a.ramp_stream_stride = fs;
   for (int k = 0; k < d->sel->nel; ++k) { /* in the order the reference renders its streams (dmx_shared_coefficients) */
-    const int e = d->swapped ? d->sel->nel - 1 - k : k;
+    const int e = d->sel->swapped ? d->sel->nel - 1 - k : k;
     if (e == 0 || d->aux) pre_frame(d, e, d->pre[e].h_dmx, d->pre[e].h_demix);
   }
   if (d->pre[0].use_dmx) a.d_dmx_frames = d->pre[0].h_dmx;

@@ -159,7 +159,7 @@ def test_weights_outside_the_range_of_the_folded_scale_take_the_unfused_form():
     keep = w   # the batch copies the matrix at create; keep the array alive until then
     mx = A.Matrix()
     C.memmove(C.byref(mx), C.byref(base), C.sizeof(A.Matrix))
-    mx.mat = keep.ctypes.data_as(A.FP)
+    mx.mat = keep.ctypes.data_as(C.POINTER(C.c_float))
     ints = _ints(rng, S, F, ch, fs, 2)
     perm = list(range(ch))
     raw, L, row = _rows(ints, 2, True, [1] * ch, perm, head=16, pad=0, frame_size=fs)
