@@ -1785,6 +1785,12 @@ static int flush_tail(struct IAMF_Decoder *d, void *pcm) { /* iamf_delay_buffer_
     if (hipMemsetAsync(d->d_res, 0, sizeof(float) * (cap + extra) * d->out_channels, d->stream) != hipSuccess) return IAMF_ERR_INTERNAL;
     n2 = iamf_hip_resampler_flush(d->rs, d->d_res, (int64_t)(cap + extra) * d->out_channels, d->stream);
     if (n2 < 0) return IAMF_ERR_INTERNAL;
+    /* the reference drains the resampler straight into the limiter (:3271-3287): iamf_loudness_process belongs to the
+     * frame loop (:3480-3484), the tail is NOT normalised.  (The limiter's delayed samples were scaled when they entered.) */
+    if (d->norm_loudness != 0.f) {
+      const float one = 1.f;
+      if (iamf_hip_batch_set_gains(d->batch3, 0, 0, &one)) return IAMF_ERR_INTERNAL;
+    }
     n = (n2 + extra) ? iamf_hip_batch_render(d->batch3, d->d_res, 0, d->out_channels, n2 + extra, d->h_pcm, (int64_t)d->pcm_cap, d->stream) : 0;
   }
   if (n < 0) return IAMF_ERR_INTERNAL;

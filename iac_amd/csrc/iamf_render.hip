@@ -548,6 +548,10 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
     break;
     CASE_M(1) CASE_M(2) CASE_M(4) CASE_M(6) CASE_M(8) CASE_M(9) CASE_M(10) CASE_M(12) CASE_M(14) CASE_M(16) CASE_M(24)
 #undef CASE_M
+    // 11 inputs: no element of the reference has them, but the stage behind the resampler takes the OUTPUT layout's
+    // channels through the identity, and Sound System E has 11 (found by tests/test_gpu_fuzz_facade.py: resampling into
+    // layout E was refused).  The general kernel only.
+    case 11: launch_m<11>(p, grid, lds_bytes, st); break;
     default: return IAMF_HIP_ERR_UNIMPLEMENTED;
   }
   HIPCHK(hipGetLastError());

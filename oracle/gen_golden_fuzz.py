@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""tests/golden/fuzz.json: per seeded random stream of tests/e2e_fuzz.py the per-call return values and a SHA-256 of the PCM
+the REAL reference (oracle/_ref/libiamf_ref.so, IAMF_decoder_*) produced.  TEST INFRASTRUCTURE; runs only in the authoring
+container.  Every stream is decoded in a process of its own: a combination the reference crashes on is recorded as such
+("crash") and left out of the comparison instead of ending the run.
+
+    python oracle/gen_golden_fuzz.py            # all seeds
+    python oracle/gen_golden_fuzz.py --one 17   # (internal) one stream -> a JSON line on stdout"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import e2e_fuzz as F  # noqa: E402
+from decoder_driver import decode_stream  # noqa: E402
+
+
+def one(seed):
+    ref = C.CDLL(os.path.join(HERE, "_ref", "libiamf_ref.so"))
+    stream, c = F.build(seed)
+    try:
+        pcm, rets = decode_stream(ref, stream, c["layout"], **F.decode_kwargs(c))
+    except AssertionError as e:   # configure / decode refused the stream: what it said is the golden
+        return dict(error=str(e))
+    return dict(sha256=F.digest(pcm), shape=list(pcm.shape), rets=[int(r) for r in rets])
+
+
+def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--one":
+        print(json.dumps(one(int(sys.argv[2]))))
+        return
+    out = {}
+    for seed in range(F.N_SEEDS):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(seed)], capture_output=True, text=True)
+        if r.returncode != 0:
+            out[str(seed)] = dict(crash=r.returncode)
+        else:
+            out[str(seed)] = json.loads(r.stdout.strip().splitlines()[-1])
+        c = F.case(seed)
+        print("  fuzz %3d %-34s %-14s fs %4d -> %s" % (seed, "+".join(c["pair"]), c["layout"], c["fs"],
+                                                      out[str(seed)].get("shape") or out[str(seed)]))
+    with open(os.path.join(ROOT, "tests", "golden", "fuzz.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("fuzz goldens written:", sum("sha256" in v for v in out.values()), "decoded,",
+          sum("error" in v for v in out.values()), "refused,", sum("crash" in v for v in out.values()), "crashed")
+
+
+if __name__ == "__main__":
+    main()

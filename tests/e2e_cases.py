@@ -202,6 +202,7 @@ CASES = {
     "stereo_loudness_info": dict(layout=_ss_layout("A"), bit_depth=16, frames=4, fs=1024, seed=209, loudness_infos=True),
 }
 
+PLAIN_LAYOUT_KINDS = dict(mono=0, stereo=1, l51=2, l512=3, l514=4, l71=5, l712=6, l714=7, l312=8)
 SCALABLE_LAYERS = [1, 3, 7]
 SCALABLE_GAINS = {0: (0b110000, -768), 1: (0b001111, 384)}   # layer -> (flags, q7.8 dB)
 SCALABLE_MODES = [1, 1, 2, 4, 5, 6, 0, 2]
@@ -235,10 +236,18 @@ def _pair_element(kind, eid, sid0, pid0, seed, n, fs, ss, rate, c):
     """returns (descriptor obus, frame -> (parameter block obus, [(sub-stream id, bytes)]), info element, sub-streams used)"""
     second = eid == 2   # the second element's own schedules, where the case names them
     dmx_modes = c.get("dmx_modes2" if second else "dmx_modes", c.get("dmx_modes"))
-    sc_modes = c.get("scalable_modes2", SCALABLE_MODES) if second else SCALABLE_MODES
+    sc_modes = c.get("scalable_modes2", SCALABLE_MODES) if second else c.get("scalable_modes1", SCALABLE_MODES)
     salt = c.get("recon_salt2", 0) if second else 0
-    if kind in ("stereo", "l51"):
-        lay = 1 if kind == "stereo" else 2
+    if kind in ("zoa", "foa", "soa", "toa"):   # mono-coded ambisonics, one sub-stream per channel
+        order = ("zoa", "foa", "soa", "toa").index(kind)
+        m = (order + 1) ** 2
+        x = np.clip(synth.hot(seed, m, n, sigma=0.16, burst_amp=0.5, burst_phase=450, burst_period=2900), -1, 1 - 2 ** -15).astype(np.float32)
+        xq = W.quantize(x, ss)
+        desc = W.audio_element_ambisonics_mono(eid, 0, m, list(range(sid0, sid0 + m)))
+        return (desc, lambda f: (b"", [(sid0 + i, W.lpcm_bytes(xq[i:i + 1, f * fs:(f + 1) * fs], ss)) for i in range(m)]),
+                dict(kind="scene", order=order, x=xq), m)
+    if kind in PLAIN_LAYOUT_KINDS:
+        lay = PLAIN_LAYOUT_KINDS[kind]
         x = np.clip(synth.hot(seed, W.LAYOUT_CHANNELS[lay], n, sigma=0.18, burst_amp=0.5, burst_phase=350, burst_period=3100),
                     -1, 1 - 2 ** -15).astype(np.float32)
         desc, x_al, xq = _channel_element(eid, lay, x, sid0, ss)
@@ -331,14 +340,20 @@ def build(name):
         return subs_fn
 
     if c.get("pair"):
-        ka, kb = c["pair"]
+        ka = c["pair"][0]
+        kb = c["pair"][1] if len(c["pair"]) > 1 else None
         da, fa, ia, na = _pair_element(ka, 1, 0, 200, c["seed"], n, fs, ss, rate, c)
-        db, fb, ib, nb = _pair_element(kb, 2, na, 210, c["seed"] + 1, n, fs, ss, rate, c)
-        stream += da + db
-        stream += W.mix_presentation(1, [dict(eid=1, pdef=_pdef_static(100, rate), default_q78=eg),
-                                         dict(eid=2, pdef=_pdef_static(102, rate), default_q78=c.get("element2_gain_q78", 0))],
-                                     dict(pdef=_pdef_static(101, rate), default_q78=og), layouts_field)
-        info["elements"] += [ia, ib]
+        stream += da
+        els = [dict(eid=1, pdef=_pdef_static(100, rate), default_q78=eg)]
+        if kb:
+            db, fb, ib, nb = _pair_element(kb, 2, na, 210, c["seed"] + 1, n, fs, ss, rate, c)
+            stream += db
+            els.append(dict(eid=2, pdef=_pdef_static(102, rate), default_q78=c.get("element2_gain_q78", 0)))
+        else:
+            fb, ib = (lambda f: (b"", [])), None
+        stream += W.mix_presentation(1, els, dict(pdef=_pdef_static(101, rate), default_q78=og), layouts_field,
+                                     loudness_q78=c.get("mix_loudness_q78", 0))
+        info["elements"] += [ia, ib] if kb else [ia]
         m1 = dict(duration=fs, constant_interval=fs)
         for f in range(F):
             ba, sa = fa(f)
@@ -347,8 +362,9 @@ def build(name):
             if c.get("pair_ramps"):   # mix-gain blocks of both elements and (from the second frame on) of the output
                 a0, b0 = -64 * f, -700 + 90 * f
                 stream += W.mix_gain_block(100, [dict(anim=W.ANIM_LINEAR, start=a0, end=a0 - 64)], mode1=m1)
-                stream += W.mix_gain_block(102, [dict(anim=W.ANIM_BEZIER, start=b0, end=b0 + 90, control=b0 + 200, rel_time=40 + 20 * f)
-                                                 if f % 3 != 2 else dict(anim=W.ANIM_STEP, start=b0)], mode1=m1)
+                if kb:
+                    stream += W.mix_gain_block(102, [dict(anim=W.ANIM_BEZIER, start=b0, end=b0 + 90, control=b0 + 200, rel_time=(40 + 20 * f) % 256)
+                                                     if f % 3 != 2 else dict(anim=W.ANIM_STEP, start=b0)], mode1=m1)
                 if f >= 1:
                     stream += W.mix_gain_block(101, [dict(anim=W.ANIM_LINEAR, start=100 - 40 * f, end=60 - 40 * f),
                                                      dict(anim=W.ANIM_STEP, start=60 - 40 * f)],

@@ -1,0 +1,84 @@
+"""Seeded random IAMF streams for the decoder facade: one or two elements of random kinds, a random output layout, bit depth,
+sample format, frame size, gains, ramps, trims, rates.  TEST INFRASTRUCTURE.
+
+oracle/gen_golden_fuzz.py decodes every stream with the REAL reference (oracle/_ref/libiamf_ref.so) and stores, per seed, the
+per-call return values and a SHA-256 of the PCM in tests/golden/fuzz.json — a few dozen bytes per stream, so the set can be
+wide; tests/test_gpu_fuzz_facade.py decodes the same streams through libiamf_hip.so and compares both.  (The 80 + 20 + 25
+streams whose PCM is stored sample by sample are in e2e.npz / lfe.npz / tv.npz: a hash says THAT something differs, they
+say where.)"""
+import hashlib
+
+import numpy as np
+
+import e2e_cases as E
+
+KINDS = ["stereo", "l51", "l512", "l514", "l71", "l712", "l714", "l312", "mono", "l714dmx", "scalable", "toa_projection",
+         "zoa", "foa", "soa", "toa"]
+MODES = [0, 1, 2, 4, 5, 6]
+RATES = [(44100, 48000), (48000, 44100), (32000, 48000), (16000, 48000), (96000, 48000)]
+N_SEEDS = 240
+
+
+def case(seed):
+    """the e2e_cases-style description of stream `seed`"""
+    rng = np.random.default_rng(900000 + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
+    two = rng.random() < 0.6
+    pair = (pick(KINDS), pick(KINDS)) if two else (pick(KINDS),)
+    lay = int(rng.integers(0, 14))
+    layout = ("binaural",) if lay == 13 else ("ss", lay)
+    fs = pick([1024, 1024, 1024, 1024, 2048, 512, 960, 256, 240, 128])
+    if "scalable" in pair or "toa_projection" in pair:
+        fs = pick([1024, 1024, 2048, 512, 960])   # (the demixer's cross-fade windows are as long as a frame)
+    frames = int(rng.integers(4, 9)) if fs >= 512 else int(rng.integers(12, 30))
+    c = dict(layout=layout, bit_depth=pick([16, 16, 24, 32]), frames=frames, fs=fs, seed=910000 + 7 * seed,
+             sample_size=pick([16, 16, 24, 32]), pair=pair,
+             element_gain_q78=int(rng.integers(-1500, 300)), element2_gain_q78=int(rng.integers(-1500, 300)),
+             output_gain_q78=int(rng.integers(-600, 300)),
+             dmx_modes=[pick(MODES) for _ in range(32)], dmx_modes2=[pick(MODES) for _ in range(32)],
+             scalable_modes1=[pick(MODES) for _ in range(32)], scalable_modes2=[pick(MODES) for _ in range(32)],
+             recon_salt2=int(rng.integers(1, 50)))
+    if rng.random() < 0.25:
+        c["pair_ramps"] = True
+    trims = {}
+    if rng.random() < 0.3:
+        trims[0] = (int(rng.integers(1, fs)), 0)
+    if rng.random() < 0.3:
+        trims[frames - 1] = (0, int(rng.integers(1, fs)))
+    if trims:
+        c["trims"] = trims
+    if rng.random() < 0.2:
+        c["rate"], c["out_rate"] = pick(RATES)
+        # Sound System H from a scene-based element: render_H2M never writes slot 23 (h2m_rdr.c:1103-1150, the LFE2 slot is
+        # not reserved for H), so the reference hands out what its frame buffer held before — silence without a resampler
+        # (the buffers only ever rotate zeros into that slot), the previous frame's INTERLEAVED resampler output with one
+        # (iamf_resample uses the frame buffer as scratch, IAMF_decoder.c:3235-3244).  Stale memory, not a result: this
+        # library writes silence, and the combination is kept out of the comparison.
+        if layout == ("ss", 7) and any(k in ("zoa", "foa", "soa", "toa", "toa_projection") for k in pair):
+            del c["rate"], c["out_rate"]
+    if rng.random() < 0.2:
+        c["loudness"] = float(pick([-16.0, -24.0, -31.0]))
+        c["mix_loudness_q78"] = int(rng.integers(-30, -10)) * 256
+    if rng.random() < 0.15:
+        c["limiter"] = False
+    elif rng.random() < 0.3:
+        c["threshold"] = float(pick([-3.0, -6.0, -0.5]))
+    return c
+
+
+def build(seed):
+    name = "fuzz_%d" % seed
+    E.CASES[name] = case(seed)
+    try:
+        return E.build(name)[0], E.CASES[name]
+    finally:
+        del E.CASES[name]
+
+
+def decode_kwargs(c):
+    return dict(bit_depth=c["bit_depth"], out_rate=c.get("out_rate", 0), loudness=c.get("loudness", 0.0),
+                limiter=c.get("limiter", True), threshold=c.get("threshold", -1.0))
+
+
+def digest(pcm):
+    return hashlib.sha256(np.ascontiguousarray(pcm).tobytes()).hexdigest()

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""authoring container: gpurun_out/fuzz_dump.npz (tools/debug/fuzz_dump.py) against the reference's PCM of the same seeds"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import e2e_fuzz as F  # noqa: E402
+from decoder_driver import decode_stream  # noqa: E402
+
+ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libiamf_ref.so"))
+d = np.load(os.path.join(ROOT, "gpurun_out", "fuzz_dump.npz"))
+for k in sorted(d.files, key=lambda s: int(s.split("_")[1])):
+    if not k.startswith("pcm_"):
+        continue
+    seed = int(k[4:])
+    stream, c = F.build(seed)
+    want, rets = decode_stream(ref, stream, c["layout"], **F.decode_kwargs(c))
+    got = d[k]
+    desc = {x: c[x] for x in ("pair", "layout", "fs", "frames", "bit_depth", "sample_size") if x in c}
+    desc.update({x: c[x] for x in ("trims", "rate", "out_rate", "loudness", "limiter", "threshold", "pair_ramps") if x in c})
+    print("seed", seed, desc)
+    print("   rets ref", list(rets), "\n   rets got", list(d["rets_%d" % seed]))
+    if got.shape != want.shape:
+        print("   SHAPE", got.shape, want.shape)
+        n = min(len(got), len(want))
+        got, want = got[:n], want[:n]
+    if got.ndim == 3:   # 24-bit: bytes -> int
+        f = lambda a: (a[..., 0].astype(np.int64) | (a[..., 1].astype(np.int64) << 8) | (a[..., 2].astype(np.int8).astype(np.int64) << 16))
+        got, want = f(got), f(want)
+    diff = got.astype(np.int64) - want.astype(np.int64)
+    bad = np.argwhere(diff != 0)
+    print("   differing words", len(bad), "of", diff.size, "first", bad[:3].tolist(), "max |d|", int(np.abs(diff).max()) if diff.size else 0,
+          "per channel", [int((diff[:, ch] != 0).sum()) for ch in range(diff.shape[1])])

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""the facade's PCM of the given tests/e2e_fuzz.py seeds -> gpurun_out/fuzz_dump.npz (compared with the reference's in the
+authoring container: tools/debug/fuzz_diff.py)"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import e2e_fuzz as F  # noqa: E402
+import iac_amd  # noqa: E402
+from decoder_driver import decode_stream  # noqa: E402
+
+lib = C.CDLL(iac_amd.lib_path())
+out = {}
+for seed in [int(a) for a in sys.argv[1:]]:
+    stream, c = F.build(seed)
+    try:
+        pcm, rets = decode_stream(lib, stream, c["layout"], **F.decode_kwargs(c))
+        out["pcm_%d" % seed] = pcm
+        out["rets_%d" % seed] = np.array(rets, dtype=np.int64)
+    except AssertionError as e:
+        print(seed, "error", e)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", "fuzz_dump.npz"), **out)
+print("dumped", sorted(out))
