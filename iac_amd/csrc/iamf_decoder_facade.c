@@ -1654,13 +1654,21 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     if (r < 0) return r;
     lp = 0;
   }
+  /* An element that feeds the HOA LFE generator keeps its whole frame: the reference renders first and trims the result
+   * (IAMF_decoder.c:3424-3430), so the generator's filter runs over the trimmed samples too — the batch gets a pointer to
+   * the first kept sample and how many lie in front of and behind the call (iamf_hip_render_args::lfe_pre_samples). */
+  const int lfe0 = d->cfg_sig.lfe_hoa, lfe1 = d->aux && d->aux_sig.lfe_hoa;
   if (!lp)
     for (int e = 0; e < d->sel->nel; ++e) {
       const int ch = element_in_channels(d->sel_el[e]);
-      if (s0)
+      if (s0 && !(e == 0 ? lfe0 : lfe1))
         for (int c = 0; c < ch; ++c) memmove(d->h_in[e] + (size_t)c * fs, d->h_in[e] + (size_t)c * fs + s0, sizeof(float) * keep);
     }
-  a.d_in = lp ? 0 : d->h_in[0];
+  a.d_in = lp ? 0 : d->h_in[0] + (lfe0 ? s0 : 0);
+  if (lfe0) {
+    a.lfe_pre_samples = s0;
+    a.lfe_post_samples = (int)d->tu_trim_end;
+  }
   a.in_stream_stride = a.in_frame_stride = (int64_t)element_in_channels(d->sel_el[0]) * fs;
   if (d->sel->nel > 1 && !d->aux) {
     a.d_in2 = d->h_in[1];
@@ -1693,8 +1701,12 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
     const float eg = ramp[1] ? 1.f : cgain[1], one = 1.f;
     int n1;
     memset(&b, 0, sizeof(b));
-    b.d_in = d->h_in[1];
+    b.d_in = d->h_in[1] + (lfe1 ? s0 : 0);
     b.in_stream_stride = b.in_frame_stride = (int64_t)element_in_channels(d->sel_el[1]) * fs;
+    if (lfe1) {
+      b.lfe_pre_samples = s0;
+      b.lfe_post_samples = (int)d->tu_trim_end;
+    }
     if (eg != d->aux_gain_set) {
       if (iamf_hip_batch_set_gains(d->aux, &eg, &one, 0)) return IAMF_ERR_INTERNAL;
       d->aux_gain_set = eg;

@@ -522,7 +522,7 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
     return IAMF_HIP_OK;
   }
   // an LFE slot is filled by render_wide4_kernel<.., LFE> where that exists, else by the generic kernel
-  if (p.lfe && !p.demix_on && !p.dmx_on && !p.in2 && !p.elem_ramp && !p.elem2_ramp && !p.out_ramp && !p.pre_matrix &&
+  if (p.lfe && !p.lfe_k0 && !p.demix_on && !p.dmx_on && !p.in2 && !p.elem_ramp && !p.elem2_ramp && !p.out_ramp && !p.pre_matrix &&
       wide_path_ok(p, m) && wide4_path_ok(p, m) && iamf_hip_wide4_has_lfe(m, p.out_ch) &&
       iamf_hip_wide4_lfe_launch(&p, m, st)) {
     HIPCHK(hipGetLastError());
@@ -592,6 +592,10 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int
              a.d_output_ramp || !b->lp_scale_ok || getenv("IAMF_HIP_LPCM_UNFUSED")))
     return kNotFused;
   if (s0 < 0 || cnt <= 0 || s0 + cnt > b->cfg.n_streams) return IAMF_HIP_ERR_BAD_ARG;
+  if (a.lfe_pre_samples < 0 || a.lfe_post_samples < 0 ||
+      ((a.lfe_pre_samples || a.lfe_post_samples) &&
+       (a.n_frames != 1 || (int64_t)a.lfe_pre_samples + total + a.lfe_post_samples > b->cfg.frame_size)))
+    return IAMF_HIP_ERR_BAD_ARG;
   const int64_t pos = b->spos[(size_t)s0];
   for (int i = s0; i < s0 + cnt; ++i)
     if (b->spos[(size_t)i] != pos || b->sflushed[(size_t)i]) return IAMF_HIP_ERR_INVALID_STATE;
@@ -728,7 +732,10 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int
     // HOA LFE generator: feed-forward part in parallel, the recurrence one lane per stream, both on the
     // caller's stream ahead of the render kernel (render_lfe.hpp)
     hipStream_t st = static_cast<hipStream_t>(a.stream);
-    const int ns = b->cfg.n_streams, nb = (ns + 63) / 64, t4 = (total + 3) / 4;
+    // a trimmed frame: the filter also runs over what is cut off (iamf_hip_render_args::lfe_pre_samples; checked above)
+    const int lpre = a.lfe_pre_samples, lpost = a.lfe_post_samples;
+    const int ltotal = lpre + total + lpost;
+    const int ns = b->cfg.n_streams, nb = (ns + 63) / 64, t4 = (ltotal + 3) / 4;
     const size_t need_u = (size_t)nb * t4 * 64 * 4;
     if (need_u > b->lfe_u_floats) {  // grows with the largest call seen
       HIPCHK(hipStreamSynchronize(st));
@@ -740,7 +747,7 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int
     }
     LfeParams lp;
     memset(&lp, 0, sizeof(lp));
-    lp.in = a.d_in;
+    lp.in = a.d_in - lpre;
     lp.in_stream_stride = a.in_stream_stride;
     lp.in_frame_stride = a.in_frame_stride;
     lp.pre_matrix = b->d_pre;   // projection mode: W is channel 0 AFTER the de-mapping, in every mode
@@ -748,7 +755,7 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int
     lp.pre_m = b->m;
     lp.frame_size = b->cfg.frame_size;
     lp.n_streams = ns;
-    lp.total = total;
+    lp.total = ltotal;
     lp.t4 = t4;
     lp.a1 = b->lfe_a1; lp.a2 = b->lfe_a2; lp.a3 = b->lfe_a3; lp.b1 = b->lfe_b1; lp.b2 = b->lfe_b2;
     lp.state = b->d_lfe_state;
@@ -761,6 +768,7 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int
     HIPCHK(hipGetLastError());
     p.lfe = b->d_lfe_u;
     p.lfe_t4 = t4;
+    p.lfe_k0 = lpre;
     p.lfe_div = b->lfe_div;
     for (int c = 0; c < b->cfg.out_channels && c < 32; ++c)
       if (b->src_feed[c] == -2) p.lfe_mask |= 1 << c;

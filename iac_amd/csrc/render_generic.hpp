@@ -220,7 +220,8 @@ __global__ __launch_bounds__(kChunk) void render_kernel(const RenderParams p) {
         } else if (f == -2 && p.lfe && valid) {
           // LFE slot (h2m_rdr.c:1154-1184): the generator's output `* 0.5` or `/ sqrt(n_size)` — double
           // expressions narrowed by the store; slot lfe2 repeats slot lfe1
-          const float o = p.lfe[((((int64_t)(s >> 6) * p.lfe_t4 + (k >> 2)) * 64 + (s & 63)) << 2) + (k & 3)];
+          const int kl = k + p.lfe_k0;
+          const float o = p.lfe[((((int64_t)(s >> 6) * p.lfe_t4 + (kl >> 2)) * 64 + (s & 63)) << 2) + (kl & 3)];
           y = p.lfe_div == 0.0 ? (float)((double)o * 0.5) : (float)((double)o / p.lfe_div);
         }
       }

@@ -56,7 +56,8 @@ class RenderArgs(C.Structure):
                 ("d_output_ramp", C.c_void_p), ("ramp_stream_stride", C.c_int64),
                 ("d_dmx_frames", C.c_void_p), ("n_frames", C.c_int32), ("n_samples", C.c_int32),
                 ("d_pcm", C.c_void_p), ("pcm_stream_stride_bytes", C.c_int64), ("stream", C.c_void_p),
-                ("d_demix_frames", C.c_void_p), ("demix_sample0", C.c_int32)]
+                ("d_demix_frames", C.c_void_p), ("demix_sample0", C.c_int32), ("lfe_pre_samples", C.c_int32),
+                ("lfe_post_samples", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class LpcmLayout(C.Structure):   # iamf_hip_lpcm_layout

@@ -288,6 +288,12 @@ typedef struct {
   const iamf_hip_demix_frame *d_demix_frames; /* with a demixer: [n_streams][n_frames] on the device */
   int32_t demix_sample0;        /* with a demixer and n_frames == 1: position inside its frame of the call's
                                    first sample (a frame whose start was trimmed before the call) */
+  /* HOA LFE generator and a TRIMMED frame (n_frames == 1): the reference renders the whole frame and trims the result
+   * (iamf_stream_render then iamf_frame_trim, IAMF_decoder.c:3424-3430), so its low-pass filter also runs over the samples
+   * that are cut.  d_in points at the first KEPT sample of every channel row; the generator additionally takes the
+   * lfe_pre_samples in front of it and the lfe_post_samples behind the call's last sample from the same rows (W, or every
+   * decoded channel in projection mode).  lfe_pre_samples + samples + lfe_post_samples <= frame_size.  0 otherwise. */
+  int32_t lfe_pre_samples, lfe_post_samples, reserved0;
 } iamf_hip_render_args;
 
 /* Extended form of iamf_hip_batch_render; same return value. */

@@ -19,34 +19,39 @@ import e2e_fuzz as F  # noqa: E402
 from decoder_driver import decode_stream  # noqa: E402
 
 
-def one(seed):
-    ref = C.CDLL(os.path.join(HERE, "_ref", "libiamf_ref.so"))
-    stream, c = F.build(seed)
+REF = dict(default=("_ref", "libiamf_ref.so"), lfe=("_ref_lfe", "libiamf_ref_lfe.so"), tv=("_ref_tv", "libiamf_ref_tv.so"))
+
+
+def one(seed, variant):
+    ref = C.CDLL(os.path.join(HERE, *REF[variant]))
+    stream, c = F.build(seed, variant)
     try:
-        pcm, rets = decode_stream(ref, stream, c["layout"], **F.decode_kwargs(c))
+        pcm, rets = decode_stream(ref, stream, c["layout"], **F.decode_kwargs(c, variant))
     except AssertionError as e:   # configure / decode refused the stream: what it said is the golden
         return dict(error=str(e))
     return dict(sha256=F.digest(pcm), shape=list(pcm.shape), rets=[int(r) for r in rets])
 
 
 def main():
-    if len(sys.argv) == 3 and sys.argv[1] == "--one":
-        print(json.dumps(one(int(sys.argv[2]))))
+    if len(sys.argv) >= 3 and sys.argv[1] == "--one":
+        print(json.dumps(one(int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else "default")))
         return
-    out = {}
-    for seed in range(F.N_SEEDS):
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(seed)], capture_output=True, text=True)
-        if r.returncode != 0:
-            out[str(seed)] = dict(crash=r.returncode)
-        else:
-            out[str(seed)] = json.loads(r.stdout.strip().splitlines()[-1])
-        c = F.case(seed)
-        print("  fuzz %3d %-34s %-14s fs %4d -> %s" % (seed, "+".join(c["pair"]), c["layout"], c["fs"],
-                                                      out[str(seed)].get("shape") or out[str(seed)]))
-    with open(os.path.join(ROOT, "tests", "golden", "fuzz.json"), "w") as f:
-        json.dump(out, f, indent=0, sort_keys=True)
-    print("fuzz goldens written:", sum("sha256" in v for v in out.values()), "decoded,",
-          sum("error" in v for v in out.values()), "refused,", sum("crash" in v for v in out.values()), "crashed")
+    for variant, (_, n_seeds) in F.VARIANTS.items():
+        out = {}
+        for seed in range(n_seeds):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(seed), variant], capture_output=True, text=True)
+            if r.returncode != 0:
+                out[str(seed)] = dict(crash=r.returncode)
+            else:
+                out[str(seed)] = json.loads(r.stdout.strip().splitlines()[-1])
+            c = F.case(seed, variant)
+            print("  fuzz %-7s %3d %-34s %-14s fs %4d -> %s" % (variant, seed, "+".join(c["pair"]), c["layout"], c["fs"],
+                                                              out[str(seed)].get("shape") or out[str(seed)]))
+        name = "fuzz.json" if variant == "default" else "fuzz_%s.json" % variant
+        with open(os.path.join(ROOT, "tests", "golden", name), "w") as f:
+            json.dump(out, f, indent=0, sort_keys=True)
+        print("fuzz goldens (%s) written:" % variant, sum("sha256" in v for v in out.values()), "decoded,",
+              sum("error" in v for v in out.values()), "refused,", sum("crash" in v for v in out.values()), "crashed")
 
 
 if __name__ == "__main__":

@@ -17,14 +17,19 @@ KINDS = ["stereo", "l51", "l512", "l514", "l71", "l712", "l714", "l312", "mono",
 MODES = [0, 1, 2, 4, 5, 6]
 RATES = [(44100, 48000), (48000, 44100), (32000, 48000), (16000, 48000), (96000, 48000)]
 N_SEEDS = 240
+# the reference's two other builds: -DDISABLE_LFE_HOA=0 (oracle/_ref_lfe; the facade after iamf_hip_decoder_set_hoa_lfe) and
+# -DSAMSUNG_TV (oracle/_ref_tv; iamf_hip_decoder_set_variant: other layout -> layout tables, a 12-channel PCM stride)
+VARIANTS = dict(default=(0, N_SEEDS), lfe=(100000, 120), tv=(200000, 120))
+SCENE = ["zoa", "foa", "soa", "toa", "toa_projection"]
 
 
-def case(seed):
-    """the e2e_cases-style description of stream `seed`"""
-    rng = np.random.default_rng(900000 + seed)
+def case(seed, variant="default"):
+    """the e2e_cases-style description of stream `seed` of a variant's set"""
+    rng = np.random.default_rng(900000 + VARIANTS[variant][0] + seed)
     pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
+    kinds = KINDS + 3 * SCENE if variant == "lfe" else KINDS   # the LFE generator works on scene-based elements
     two = rng.random() < 0.6
-    pair = (pick(KINDS), pick(KINDS)) if two else (pick(KINDS),)
+    pair = (pick(kinds), pick(kinds)) if two else (pick(kinds),)
     lay = int(rng.integers(0, 14))
     layout = ("binaural",) if lay == 13 else ("ss", lay)
     fs = pick([1024, 1024, 1024, 1024, 2048, 512, 960, 256, 240, 128])
@@ -66,18 +71,21 @@ def case(seed):
     return c
 
 
-def build(seed):
-    name = "fuzz_%d" % seed
-    E.CASES[name] = case(seed)
+def build(seed, variant="default"):
+    name = "fuzz_%s_%d" % (variant, seed)
+    E.CASES[name] = case(seed, variant)
     try:
         return E.build(name)[0], E.CASES[name]
     finally:
         del E.CASES[name]
 
 
-def decode_kwargs(c):
-    return dict(bit_depth=c["bit_depth"], out_rate=c.get("out_rate", 0), loudness=c.get("loudness", 0.0),
-                limiter=c.get("limiter", True), threshold=c.get("threshold", -1.0))
+def decode_kwargs(c, variant="default"):
+    kw = dict(bit_depth=c["bit_depth"], out_rate=c.get("out_rate", 0), loudness=c.get("loudness", 0.0),
+              limiter=c.get("limiter", True), threshold=c.get("threshold", -1.0))
+    if variant == "tv":
+        kw["pcm_channels"] = 12   # IAMF_decoder.c:3492-3495
+    return kw
 
 
 def digest(pcm):

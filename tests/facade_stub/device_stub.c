@@ -117,7 +117,8 @@ int iamf_hip_batch_render_range(iamf_hip_batch *b, const iamf_hip_render_args *a
   int n = a->n_samples ? a->n_samples : a->n_frames * b->cfg.frame_size, r = 0;
   if (s0 < 0 || cnt <= 0 || s0 + cnt > b->cfg.n_streams) return IAMF_HIP_ERR_BAD_ARG;
   for (int s = s0; s < s0 + cnt; ++s) {
-    const volatile float *in = (const volatile float *)a->d_in + (int64_t)s * a->in_stream_stride; /* touch what a kernel would read */
+    /* touch what a kernel would read (an LFE element's rows start lfe_pre_samples in front of d_in) */
+    const volatile float *in = (const volatile float *)a->d_in - a->lfe_pre_samples + (int64_t)s * a->in_stream_stride;
     float acc = 0;
     for (int64_t i = 0; i < (int64_t)b->cfg.matrix.m * b->cfg.frame_size && b->cfg.matrix.kind != IAMF_HIP_KIND_DMX; ++i) acc += in[i];
     (void)acc;

@@ -65,6 +65,11 @@ E2E = {
     "toa_G_s16": dict(order=3, ss="G", bit_depth=16, frames=4, fs=1024, seed=211),
     "foa_E_s24": dict(order=1, ss="E", bit_depth=24, frames=4, fs=1024, seed=212),
     "toa_D_s16": dict(order=3, ss="D", bit_depth=16, frames=5, fs=1024, seed=213),
+    # trimmed frames: the reference renders a frame and trims the result (IAMF_decoder.c:3424-3430), so the generator's filter
+    # runs over the samples that are cut (found by tests/test_gpu_fuzz_facade.py; the batch takes them as
+    # iamf_hip_render_args::lfe_pre_samples / lfe_post_samples)
+    "toa_B_trim_s16": dict(order=3, ss="B", bit_depth=16, frames=6, fs=1024, seed=221, trims={0: (100, 0), 2: (7, 0), 5: (0, 300)}),
+    "foa_F_trim_s24": dict(order=1, ss="F", bit_depth=24, frames=5, fs=960, seed=222, trims={0: (959, 0), 4: (0, 1)}),
     # round 4: presentations of TWO elements.  A scene-based element beside a channel-based one (plain or scalable), in
     # either position; and two scene-based elements: the reference keeps ONE filter per output layout
     # (IAMF_decoder.c:2629-2632: plfe = &stream->final_layout->sp.lfe_f), so the two W channels run through the same
@@ -164,7 +169,7 @@ def build(name):
                 w = 2 if i < coupled else 1
                 subs.append((i, W.lpcm_bytes(xq[ch:ch + w, f * fs:(f + 1) * fs], 16)))
                 ch += w
-            s += W.audio_frames(subs)
+            s += W.audio_frames(subs, trim=c.get("trims", {}).get(f))
         else:
-            s += W.audio_frames([(i, W.lpcm_bytes(xq[i:i + 1, f * fs:(f + 1) * fs], 16)) for i in range(m)])
+            s += W.audio_frames([(i, W.lpcm_bytes(xq[i:i + 1, f * fs:(f + 1) * fs], 16)) for i in range(m)], trim=c.get("trims", {}).get(f))
     return s, xq

@@ -13,7 +13,9 @@ from decoder_driver import decode_stream
 
 pytestmark = pytest.mark.gpu
 
-GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz.json")))
+_G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLD = json.load(open(os.path.join(_G, "fuzz.json")))
+GOLD_V = dict(lfe=json.load(open(os.path.join(_G, "fuzz_lfe.json"))), tv=json.load(open(os.path.join(_G, "fuzz_tv.json"))))
 
 
 from test_gpu_group import group_decode_all, lib  # noqa: E402,F401  (the fixture that declares the group entry points)
@@ -38,6 +40,58 @@ def test_random_stream_through_a_group_of_handles(lib, seed):
     stream, c = F.build(seed)
     case = dict(c)
     rc, outs = group_decode_all(lib, case, stream, 5, 2, starve=lambda r, i: (r + i) % 4 == 0 and i % 2 == 0)
+    assert rc == 0, (seed, rc)
+    for i, (pcm, rets) in enumerate(outs):
+        assert [int(r) for r in rets] == want["rets"], (seed, i)
+        assert F.digest(pcm) == want["sha256"], (seed, i)
+
+
+class _Variant:
+    """the decoder library with every handle it opens switched to one of the reference's other builds"""
+
+    def __init__(self, lib, variant):
+        self._lib, self._variant = lib, variant
+
+    def __getattr__(self, name):
+        f = getattr(self._lib, name)
+        if name != "IAMF_decoder_open":
+            return f
+        lib, variant = self._lib, self._variant
+
+        def open_():
+            import ctypes as C
+            lib.IAMF_decoder_open.restype = C.c_void_p
+            lib.iamf_hip_decoder_set_hoa_lfe.argtypes = [C.c_void_p, C.c_int]
+            lib.iamf_hip_decoder_set_variant.argtypes = [C.c_void_p, C.c_int]
+            d = lib.IAMF_decoder_open()
+            assert (lib.iamf_hip_decoder_set_hoa_lfe(d, 1) if variant == "lfe" else lib.iamf_hip_decoder_set_variant(d, 1)) == 0
+            return d
+        return open_
+
+
+@pytest.mark.parametrize("variant,seed", [(v, s) for v in ("lfe", "tv") for s in range(F.VARIANTS[v][1])])
+def test_random_stream_matches_the_other_builds_of_the_reference(lib, variant, seed):
+    """the same generator against the reference built -DDISABLE_LFE_HOA=0 (scene-based elements three times as likely: one or
+    two of them through the LFE generator, beside channel-based ones, behind the resampler) and -DSAMSUNG_TV (its own layout
+    -> layout tables, 12-channel PCM stride)"""
+    want = GOLD_V[variant][str(seed)]
+    assert "sha256" in want, want
+    stream, c = F.build(seed, variant)
+    pcm, rets = decode_stream(_Variant(lib, variant), stream, c["layout"], **F.decode_kwargs(c, variant))
+    desc = {k: v for k, v in c.items() if not k.endswith(("modes", "modes1", "modes2"))}
+    assert [int(r) for r in rets] == want["rets"], (variant, seed, desc)
+    assert list(pcm.shape) == want["shape"], (variant, seed, desc)
+    assert F.digest(pcm) == want["sha256"], (variant, seed, desc)
+
+
+@pytest.mark.parametrize("seed", range(0, F.VARIANTS["lfe"][1], 3))
+def test_random_lfe_stream_through_a_group_of_handles(lib, seed):
+    """every third stream of the LFE set through five out-of-step handles: whole frames reach the generator of every stream
+    (trimmed ones too: the filter runs over what is cut), runs of equal trims share a launch"""
+    want = GOLD_V["lfe"][str(seed)]
+    stream, c = F.build(seed, "lfe")
+    case = dict(c, lfe_hoa=True)
+    rc, outs = group_decode_all(lib, case, stream, 5, 2, starve=lambda r, i: (r + 2 * i) % 3 == 0 and i % 2 == 1)
     assert rc == 0, (seed, rc)
     for i, (pcm, rets) in enumerate(outs):
         assert [int(r) for r in rets] == want["rets"], (seed, i)

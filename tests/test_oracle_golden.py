@@ -195,7 +195,17 @@ def test_lfe_e2e_through_the_oracle_stream(golden):
             continue
         if rate != 48000:   # resampled to the 48 kHz default: checked on the facade against this golden (-m gpu)
             continue
-        y = O.stream_run(mx, O.OUT_CH[oid], xq, c["fs"], bit_depth=c["bit_depth"], lfe_rate=rate)
+        if c.get("trims"):
+            # the reference renders every frame whole — the generator's filter runs over what is cut — and trims the result
+            # (IAMF_decoder.c:3424-3430); then limiter and pack over the kept samples
+            fs, F = c["fs"], c["frames"]
+            z = O.render_h2m_lfe(mx, xq, O.OUT_CH[oid], rate, [fs] * F)
+            keep = [(f * fs + c["trims"].get(f, (0, 0))[0], (f + 1) * fs - c["trims"].get(f, (0, 0))[1]) for f in range(F)]
+            z = np.ascontiguousarray(np.concatenate([z[:, a:b] for a, b in keep], axis=1))
+            z, _ = O.limiter_run(z, [b - a for a, b in keep])
+            y = O.pack(z, c["bit_depth"])
+        else:
+            y = O.stream_run(mx, O.OUT_CH[oid], xq, c["fs"], bit_depth=c["bit_depth"], lfe_rate=rate)
         assert y.shape == want.shape, (name, y.shape, want.shape)
         assert np.array_equal(y, want), name
 

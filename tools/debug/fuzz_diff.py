@@ -11,14 +11,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import e2e_fuzz as F  # noqa: E402
 from decoder_driver import decode_stream  # noqa: E402
 
-ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libiamf_ref.so"))
 d = np.load(os.path.join(ROOT, "gpurun_out", "fuzz_dump.npz"))
-for k in sorted(d.files, key=lambda s: int(s.split("_")[1])):
+variant = str(d["variant"]) if "variant" in d.files else "default"
+REF = dict(default=("_ref", "libiamf_ref.so"), lfe=("_ref_lfe", "libiamf_ref_lfe.so"), tv=("_ref_tv", "libiamf_ref_tv.so"))
+ref = C.CDLL(os.path.join(ROOT, "oracle", *REF[variant]))
+for k in sorted([x for x in d.files if x != "variant"], key=lambda s: int(s.split("_")[1])):
     if not k.startswith("pcm_"):
         continue
     seed = int(k[4:])
-    stream, c = F.build(seed)
-    want, rets = decode_stream(ref, stream, c["layout"], **F.decode_kwargs(c))
+    stream, c = F.build(seed, variant)
+    want, rets = decode_stream(ref, stream, c["layout"], **F.decode_kwargs(c, variant))
     got = d[k]
     desc = {x: c[x] for x in ("pair", "layout", "fs", "frames", "bit_depth", "sample_size") if x in c}
     desc.update({x: c[x] for x in ("trims", "rate", "out_rate", "loudness", "limiter", "threshold", "pair_ramps") if x in c})

@@ -15,11 +15,16 @@ import iac_amd  # noqa: E402
 from decoder_driver import decode_stream  # noqa: E402
 
 lib = C.CDLL(iac_amd.lib_path())
-out = {}
+variant = "default"
+if sys.argv[1] in F.VARIANTS:   # tools/debug/fuzz_dump.py lfe 3 17 ...
+    variant = sys.argv.pop(1)
+from test_gpu_fuzz_facade import _Variant  # noqa: E402
+dlib = lib if variant == "default" else _Variant(lib, variant)
+out = {"variant": np.array(variant)}
 for seed in [int(a) for a in sys.argv[1:]]:
-    stream, c = F.build(seed)
+    stream, c = F.build(seed, variant)
     try:
-        pcm, rets = decode_stream(lib, stream, c["layout"], **F.decode_kwargs(c))
+        pcm, rets = decode_stream(dlib, stream, c["layout"], **F.decode_kwargs(c, variant))
         out["pcm_%d" % seed] = pcm
         out["rets_%d" % seed] = np.array(rets, dtype=np.int64)
     except AssertionError as e:

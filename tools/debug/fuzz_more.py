@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""the facade on the seeds of tests/golden_tmp/fuzz_more.json (a hunting run of tests/e2e_fuzz.py seeds beyond the committed
+set: generated in the authoring container, not committed) -> the seeds that differ"""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import e2e_fuzz as F  # noqa: E402
+import iac_amd  # noqa: E402
+from decoder_driver import decode_stream  # noqa: E402
+
+lib = C.CDLL(iac_amd.lib_path())
+gold = json.load(open(os.path.join(ROOT, "tests", "golden_tmp", "fuzz_more.json")))
+bad = []
+for k in sorted(gold, key=int):
+    seed = int(k)
+    stream, c = F.build(seed)
+    try:
+        pcm, rets = decode_stream(lib, stream, c["layout"], **F.decode_kwargs(c))
+        ok = [int(r) for r in rets] == gold[k]["rets"] and F.digest(pcm) == gold[k]["sha256"]
+        why = "" if ok else ("rets" if [int(r) for r in rets] != gold[k]["rets"] else "pcm")
+    except AssertionError as e:
+        ok, why = False, str(e)
+    if not ok:
+        bad.append(seed)
+        print(seed, why, {x: c[x] for x in ("pair", "layout", "fs", "frames", "bit_depth", "sample_size", "trims", "rate", "out_rate", "loudness", "limiter", "threshold", "pair_ramps") if x in c}, flush=True)
+print("checked", len(gold), "bad", bad)
