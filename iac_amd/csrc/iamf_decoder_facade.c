@@ -1073,10 +1073,11 @@ static void dmx_shared_coefficients(const struct IAMF_Decoder *d, float out[5]) 
 
 /* The stage's records of the frame at hand: iamf_stream_render's down-mixer update (IAMF_decoder.c:2574-2583) into *fr,
  * iamf_stream_scale_decoder_demix's (:2324-2349; demixer_set_recon_gain, demixer.c:620-634) into *dm */
-static void pre_frame(struct IAMF_Decoder *d, int ei, iamf_hip_dmx_frame *fr, iamf_hip_demix_frame *dm) {
+static void pre_frame_parts(struct IAMF_Decoder *d, int ei, iamf_hip_dmx_frame *fr, iamf_hip_demix_frame *dm, int renderer,
+                            int decoder) {
   const Element *e = d->sel_el[ei];
   Pre *q = &d->pre[ei];
-  if (q->use_dmx) {
+  if (q->use_dmx && renderer) {
     fr->offset = 0;
     dmx_shared_coefficients(d, fr->prev);
     if (q->dmx_mode > -1) {
@@ -1085,7 +1086,7 @@ static void pre_frame(struct IAMF_Decoder *d, int ei, iamf_hip_dmx_frame *fr, ia
     }
     dmx_shared_coefficients(d, fr->cur);
   }
-  if (q->use_demix) {
+  if (q->use_demix && decoder) {
     if (e->layer[q->demix_layer].recon_flag) {
       const uint32_t lf = q->layer_rec_flags[q->demix_layer];
       const int cnt = popcount32(lf);
@@ -1098,6 +1099,24 @@ static void pre_frame(struct IAMF_Decoder *d, int ei, iamf_hip_dmx_frame *fr, ia
     if (q->dmx_mode > -1) iamf_hip_demix_set_info(&q->dmst, q->dmx_mode, -1);
     iamf_hip_demix_frame_fill(&q->dmst, q->rec_n, q->rec_ch, q->rec_gain, dm);
   }
+}
+
+static void pre_frame(struct IAMF_Decoder *d, int ei, iamf_hip_dmx_frame *fr, iamf_hip_demix_frame *dm) {
+  pre_frame_parts(d, ei, fr, dm, 1, 1);
+}
+
+/* A temporal unit that is trimmed away completely returns 0 samples, but not before the reference has decoded it — the
+ * demixer of a scalable element has run, its recon-gain smoothing and weight index have moved on (iamf_stream_decoder_decode,
+ * IAMF_decoder.c:3347) — and, unless the start or the end trim alone covers the whole frame (:3354-3357), rendered it: the
+ * parametric down-mixer has stepped its weight (:2574-2583) and the HOA LFE generator's filter has run over the frame
+ * (:2625-2636).  Returns 1 if the unit was rendered in the reference (the caller then advances the LFE generator). */
+static int dropped_unit_advance(struct IAMF_Decoder *d, int ns, iamf_hip_dmx_frame *fr[2], iamf_hip_demix_frame *dm[2]) {
+  const int rendered = !(d->tu_trim_start == (uint64_t)d->frame_size || d->tu_trim_end == (uint64_t)d->frame_size) && ns > 0;
+  for (int k = 0; k < d->sel->nel; ++k) {
+    const int e = d->sel->swapped ? d->sel->nel - 1 - k : k;
+    if (e == 0 || d->aux) pre_frame_parts(d, e, fr[e], dm[e], rendered, 1);
+  }
+  return rendered;
 }
 
 static int setup_pipeline(struct IAMF_Decoder *d) {
@@ -1627,6 +1646,19 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
   s0 = (int)d->tu_trim_start;
   keep = ns - s0 - (int)d->tu_trim_end;
   if (keep <= 0) {
+    iamf_hip_dmx_frame *fr[2] = {d->pre[0].h_dmx, d->pre[1].h_dmx};
+    iamf_hip_demix_frame *dm[2] = {d->pre[0].h_demix, d->pre[1].h_demix};
+    if (dropped_unit_advance(d, ns, fr, dm)) {
+      /* the LFE generator's filter over the frame the reference rendered before it cut it (element 1's batch first: it is
+       * the earlier element of the presentation when both feed the generator) */
+      if (d->aux && d->aux_sig.lfe_hoa &&
+          iamf_hip_batch_lfe_advance(d->aux, d->h_in[1], (int64_t)element_in_channels(d->sel_el[1]) * fs, ns, d->stream, 0, 1))
+        return IAMF_ERR_INTERNAL;
+      if (d->cfg_sig.lfe_hoa &&
+          iamf_hip_batch_lfe_advance(d->batch, d->h_in[0], (int64_t)element_in_channels(d->sel_el[0]) * fs, ns, d->stream, 0, 1))
+        return IAMF_ERR_INTERNAL;
+      if ((d->cfg_sig.lfe_hoa || (d->aux && d->aux_sig.lfe_hoa)) && facade_wait(d)) return IAMF_ERR_INTERNAL; /* h_in is reused */
+    }
     d->timestamp += fs;
     return 0;
   }

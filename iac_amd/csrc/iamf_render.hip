@@ -586,6 +586,46 @@ struct LpcmIn {
 };
 constexpr int kNotFused = INT32_MIN;
 
+// HOA LFE generator over `ltotal` samples of the element rows at d_in: feed-forward part in parallel, the recurrence one lane
+// per stream, both on the caller's stream (render_lfe.hpp); the output lies in b->d_lfe_u (t4 quads per stream), the filter
+// state of streams [s0, s0 + cnt) has moved on.
+int lfe_prepass(iamf_hip_batch *b, const float *d_in, int64_t in_stream_stride, int64_t in_frame_stride, int ltotal,
+                hipStream_t st, int s0, int cnt, int *t4_out) {
+  const int ns = b->cfg.n_streams, nb = (ns + 63) / 64, t4 = (ltotal + 3) / 4;
+  const size_t need_u = (size_t)nb * t4 * 64 * 4;
+  if (need_u > b->lfe_u_floats) {  // grows with the largest call seen
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(b->d_lfe_u);
+    b->d_lfe_u = nullptr;
+    b->lfe_u_floats = 0;
+    HIPCHK(hipMalloc(&b->d_lfe_u, sizeof(float) * need_u));
+    b->lfe_u_floats = need_u;
+  }
+  LfeParams lp;
+  memset(&lp, 0, sizeof(lp));
+  lp.in = d_in;
+  lp.in_stream_stride = in_stream_stride;
+  lp.in_frame_stride = in_frame_stride;
+  lp.pre_matrix = b->d_pre;   // projection mode: W is channel 0 AFTER the de-mapping, in every mode
+  lp.pre_l = b->pre_l;
+  lp.pre_m = b->m;
+  lp.frame_size = b->cfg.frame_size;
+  lp.n_streams = ns;
+  lp.total = ltotal;
+  lp.t4 = t4;
+  lp.a1 = b->lfe_a1; lp.a2 = b->lfe_a2; lp.a3 = b->lfe_a3; lp.b1 = b->lfe_b1; lp.b2 = b->lfe_b2;
+  lp.state = b->d_lfe_state;
+  lp.state_next = b->d_lfe_next;
+  lp.u_t = reinterpret_cast<float4 *>(b->d_lfe_u);
+  lp.s_first = s0;
+  lp.s_count = cnt;
+  hipLaunchKernelGGL(lfe_ff_kernel, dim3((unsigned)((t4 + kLfeTileQ - 1) / kLfeTileQ), (unsigned)nb), dim3(256), 0, st, lp);
+  hipLaunchKernelGGL(lfe_chain_kernel, dim3((unsigned)nb), dim3(64), 0, st, lp);
+  HIPCHK(hipGetLastError());
+  *t4_out = t4;
+  return IAMF_HIP_OK;
+}
+
 int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int s0, int cnt, const LpcmIn *lp = nullptr) {
   if (!on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
   if (lp && (b->fir || b->lfe || b->d_pre || b->demix || b->dmx || b->has2 || a.d_element_ramp || a.d_element2_ramp ||
@@ -729,43 +769,12 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int
     }
   }
   if (b->lfe && a.d_in && total > 0) {
-    // HOA LFE generator: feed-forward part in parallel, the recurrence one lane per stream, both on the
-    // caller's stream ahead of the render kernel (render_lfe.hpp)
-    hipStream_t st = static_cast<hipStream_t>(a.stream);
     // a trimmed frame: the filter also runs over what is cut off (iamf_hip_render_args::lfe_pre_samples; checked above)
     const int lpre = a.lfe_pre_samples, lpost = a.lfe_post_samples;
-    const int ltotal = lpre + total + lpost;
-    const int ns = b->cfg.n_streams, nb = (ns + 63) / 64, t4 = (ltotal + 3) / 4;
-    const size_t need_u = (size_t)nb * t4 * 64 * 4;
-    if (need_u > b->lfe_u_floats) {  // grows with the largest call seen
-      HIPCHK(hipStreamSynchronize(st));
-      (void)hipFree(b->d_lfe_u);
-      b->d_lfe_u = nullptr;
-      b->lfe_u_floats = 0;
-      HIPCHK(hipMalloc(&b->d_lfe_u, sizeof(float) * need_u));
-      b->lfe_u_floats = need_u;
-    }
-    LfeParams lp;
-    memset(&lp, 0, sizeof(lp));
-    lp.in = a.d_in - lpre;
-    lp.in_stream_stride = a.in_stream_stride;
-    lp.in_frame_stride = a.in_frame_stride;
-    lp.pre_matrix = b->d_pre;   // projection mode: W is channel 0 AFTER the de-mapping, in every mode
-    lp.pre_l = b->pre_l;
-    lp.pre_m = b->m;
-    lp.frame_size = b->cfg.frame_size;
-    lp.n_streams = ns;
-    lp.total = ltotal;
-    lp.t4 = t4;
-    lp.a1 = b->lfe_a1; lp.a2 = b->lfe_a2; lp.a3 = b->lfe_a3; lp.b1 = b->lfe_b1; lp.b2 = b->lfe_b2;
-    lp.state = b->d_lfe_state;
-    lp.state_next = b->d_lfe_next;
-    lp.u_t = reinterpret_cast<float4 *>(b->d_lfe_u);
-    lp.s_first = s0;
-    lp.s_count = cnt;
-    hipLaunchKernelGGL(lfe_ff_kernel, dim3((unsigned)((t4 + kLfeTileQ - 1) / kLfeTileQ), (unsigned)nb), dim3(256), 0, st, lp);
-    hipLaunchKernelGGL(lfe_chain_kernel, dim3((unsigned)nb), dim3(64), 0, st, lp);
-    HIPCHK(hipGetLastError());
+    int t4 = 0;
+    const int rc = lfe_prepass(b, a.d_in - lpre, a.in_stream_stride, a.in_frame_stride, lpre + total + lpost,
+                               static_cast<hipStream_t>(a.stream), s0, cnt, &t4);
+    if (rc) return rc;
     p.lfe = b->d_lfe_u;
     p.lfe_t4 = t4;
     p.lfe_k0 = lpre;
@@ -1356,6 +1365,19 @@ int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *
   b->m2 = mx->m;
   b->has2 = true;
   return IAMF_HIP_OK;
+}
+
+// A frame of an element that feeds the HOA LFE generator is rendered and then trimmed away COMPLETELY (start + end trim =
+// its length, neither of them the whole frame): the reference's filter has run over it (iamf_stream_render precedes
+// iamf_frame_trim, IAMF_decoder.c:3372-3406), nothing is emitted.  Streams [first, first + count) only.
+int iamf_hip_batch_lfe_advance(iamf_hip_batch *b, const float *d_in, int64_t in_stream_stride, int32_t n_samples, void *stream,
+                               int32_t first, int32_t count) {
+  if (!b || !d_in || n_samples <= 0 || n_samples > b->cfg.frame_size || first < 0 || count <= 0 || first + count > b->cfg.n_streams)
+    return IAMF_HIP_ERR_BAD_ARG;
+  if (!on_batch_device(b)) return IAMF_HIP_ERR_INVALID_STATE;
+  if (!b->lfe) return IAMF_HIP_OK;   // a layout without an LFE slot: no generator, nothing to advance
+  int t4 = 0;
+  return lfe_prepass(b, d_in, in_stream_stride, in_stream_stride, n_samples, static_cast<hipStream_t>(stream), first, count, &t4);
 }
 
 // The reference keeps the LFE generator's filter in the OUTPUT LAYOUT (IAMF_decoder.c:2629-2632: plfe =

@@ -152,6 +152,7 @@ def lib():
                                                 C.c_int64, C.c_void_p]
         L.iamf_hip_batch_set_projection.argtypes = [C.c_void_p, FP, C.c_int]
         L.iamf_hip_batch_share_lfe_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.iamf_hip_batch_lfe_advance.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
         L.iamf_hip_lpcm_unpack.argtypes = [C.POINTER(LpcmLayout), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_int64, C.c_int32, C.c_void_p]
         L.iamf_hip_batch_set_demixer.argtypes = [C.c_void_p, C.POINTER(DemixConfig)]

@@ -210,6 +210,12 @@ int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *
  * rendered yet) that render such a pair: `b` adopts `owner`'s filter state; the caller issues each frame's calls in
  * presentation order on ONE HIP stream, and destroys `b` before `owner`.  IAMF_HIP_OK / _BAD_ARG / _INVALID_STATE. */
 int iamf_hip_batch_share_lfe_state(iamf_hip_batch *b, iamf_hip_batch *owner);
+/* HOA LFE generator: a frame that is rendered and then trimmed away completely (start + end trim = its length, neither of
+ * them the whole frame: iamf_stream_render precedes iamf_frame_trim, IAMF_decoder.c:3372-3406).  The generator's filter
+ * runs over the frame's n_samples (d_in: the element's planar rows of the frame, as for a render call) for streams
+ * [first, first + count); nothing is emitted.  IAMF_HIP_OK (also for a batch without a generator) / _BAD_ARG / _DEVICE. */
+int iamf_hip_batch_lfe_advance(iamf_hip_batch *b, const float *d_in, int64_t in_stream_stride, int32_t n_samples, void *stream,
+                               int32_t first, int32_t count);
 /* Ambisonics projection de-mapping in front of element 0's renderer (projection-mode scene-based
  * elements): x[r] = sum over the l_in decoded channels l, ascending, of in[l] * matrix[l*m + r]
  * (iamf_core_decoder_convert_projection, src/iamf_dec/IAMF_core_decoder.c:116-130).  `matrix` is a

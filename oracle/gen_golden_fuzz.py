@@ -19,7 +19,8 @@ import e2e_fuzz as F  # noqa: E402
 from decoder_driver import decode_stream  # noqa: E402
 
 
-REF = dict(default=("_ref", "libiamf_ref.so"), lfe=("_ref_lfe", "libiamf_ref_lfe.so"), tv=("_ref_tv", "libiamf_ref_tv.so"))
+REF = dict(default=("_ref", "libiamf_ref.so"), lfe=("_ref_lfe", "libiamf_ref_lfe.so"), tv=("_ref_tv", "libiamf_ref_tv.so"),
+           wide=("_ref", "libiamf_ref.so"))
 
 
 def one(seed, variant):

@@ -253,21 +253,27 @@ def _pair_element(kind, eid, sid0, pid0, seed, n, fs, ss, rate, c):
         desc, x_al, xq = _channel_element(eid, lay, x, sid0, ss)
         return (desc, lambda f: (b"", W.channel_element_substreams(lay, x_al[:, f * fs:(f + 1) * fs], sid0, ss)),
                 dict(kind="channel", layout=lay, x=xq), W.LAYOUT_SUBSTREAMS[lay][0])
-    if kind == "l714dmx":
-        x = np.clip(synth.hot(seed, 12, n, sigma=0.18, burst_amp=0.5, burst_phase=500, burst_period=3000),
+    if kind == "l714dmx" or kind.startswith("dmx:"):   # a channel-based element with demixing info ("dmx:<layout id>")
+        lay = 7 if kind == "l714dmx" else int(kind[4:])
+        nch = W.LAYOUT_CHANNELS[lay]
+        x = np.clip(synth.hot(seed, nch, n, sigma=0.18, burst_amp=0.5, burst_phase=500, burst_period=3000),
                     -1, 1 - 2 ** -15).astype(np.float32)
         xq = W.quantize(x, ss)
         x_al = np.empty_like(xq)
-        for p_, a_ in enumerate(al_index_of_playback(7)):
+        for p_, a_ in enumerate(al_index_of_playback(lay)):
             x_al[a_] = xq[p_]
-        desc = W.audio_element_channel(eid, 0, 7, list(range(sid0, sid0 + 7)),
-                                       demixing=dict(pid=pid0, rate=rate, frame=fs, mode=1, w=3))
+        dmode, dw = c.get("dmx_default2" if second else "dmx_default1", (1, 3))
+        nsub = W.LAYOUT_SUBSTREAMS[lay][0]
+        desc = W.audio_element_channel(eid, 0, lay, list(range(sid0, sid0 + nsub)),
+                                       demixing=dict(pid=pid0, rate=rate, frame=fs, mode=dmode, w=dw))
         return (desc, lambda f: (W.demixing_block(pid0, dmx_modes[f]),
-                                 W.channel_element_substreams(7, x_al[:, f * fs:(f + 1) * fs], sid0, ss)),
-                dict(kind="channel", layout=7, x=xq), 7)
+                                 W.channel_element_substreams(lay, x_al[:, f * fs:(f + 1) * fs], sid0, ss)),
+                dict(kind="channel", layout=lay, x=xq), nsub)
     if kind == "scalable":
         import demix_cases as D
-        layers = SCALABLE_LAYERS
+        layers = c.get("scalable_layers2" if second else "scalable_layers1", SCALABLE_LAYERS)
+        lgains = c.get("scalable_gains2" if second else "scalable_gains1", SCALABLE_GAINS)
+        dmode, dw = c.get("dmx_default2" if second else "dmx_default1", (1, 3))
         order, per_layer = D.channels_order(layers)
         xd = W.quantize(synth.hot(seed, len(order), n, sigma=0.13, burst_amp=0.4, burst_phase=600,
                                   burst_period=2700).clip(-1, 1 - 2 ** -15).astype(np.float32), ss)
@@ -275,10 +281,10 @@ def _pair_element(kind, eid, sid0, pid0, seed, n, fs, ss, rate, c):
         for li, (lay, pl) in enumerate(zip(layers, per_layer)):
             rf = D.recon_flags(layers[0], lay) if li else 0
             wl.append(dict(layout=lay, nsub=pl["substreams"], ncoupled=pl["coupled"],
-                           out_gain=SCALABLE_GAINS.get(li), recon=bool(rf), recon_flags=rf))
+                           out_gain=lgains.get(li), recon=bool(rf), recon_flags=rf))
         nsub = sum(l["nsub"] for l in wl)
         desc = W.audio_element_scalable(eid, 0, wl, list(range(sid0, sid0 + nsub)),
-                                        demixing=dict(pid=pid0, rate=rate, frame=fs, mode=1, w=3),
+                                        demixing=dict(pid=pid0, rate=rate, frame=fs, mode=dmode, w=dw),
                                         recon=dict(pid=pid0 + 1, rate=rate, frame=fs))
 
         def frame(f):
@@ -293,7 +299,7 @@ def _pair_element(kind, eid, sid0, pid0, seed, n, fs, ss, rate, c):
                     ch += w
                     sid += 1
             return blocks, subs
-        return desc, frame, dict(kind="scalable", layers=layers, order=order, x=xd, wl=wl, gains=SCALABLE_GAINS, modes=sc_modes,
+        return desc, frame, dict(kind="scalable", layers=layers, order=order, x=xd, wl=wl, gains=lgains, modes=sc_modes,
                                  salt=salt), nsub
     if kind == "toa_projection":
         subs_n, coupled = 10, 6
@@ -340,6 +346,7 @@ def build(name):
         return subs_fn
 
     if c.get("pair"):
+        W.LE_DEFAULT = le   # (restored below: every sub-stream of this stream in the codec configuration's byte order)
         ka = c["pair"][0]
         kb = c["pair"][1] if len(c["pair"]) > 1 else None
         da, fa, ia, na = _pair_element(ka, 1, 0, 200, c["seed"], n, fs, ss, rate, c)
@@ -370,6 +377,7 @@ def build(name):
                                                      dict(anim=W.ANIM_STEP, start=60 - 40 * f)],
                                                mode1=dict(duration=fs, constant_interval=0, intervals=[fs // 4, fs - fs // 4]))
             stream += ba + bb + W.audio_frames(sa + sb, trim=c.get("trims", {}).get(f))
+        W.LE_DEFAULT = True
         return stream, info
     if name == "stereo_loudness_info":
         x = synth.uniform(c["seed"], 2, n, 0.7)

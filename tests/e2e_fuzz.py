@@ -19,7 +19,14 @@ RATES = [(44100, 48000), (48000, 44100), (32000, 48000), (16000, 48000), (96000,
 N_SEEDS = 240
 # the reference's two other builds: -DDISABLE_LFE_HOA=0 (oracle/_ref_lfe; the facade after iamf_hip_decoder_set_hoa_lfe) and
 # -DSAMSUNG_TV (oracle/_ref_tv; iamf_hip_decoder_set_variant: other layout -> layout tables, a 12-channel PCM stride)
-VARIANTS = dict(default=(0, N_SEEDS), lfe=(100000, 120), tv=(200000, 120))
+# "wide": the default build again with the dimensions the first generator held fixed — scalable layer stacks, any layout
+# with demixing info, the demixing defaults, big-endian samples, more stream / output rates (with and without conversion),
+# frames trimmed away completely, frame sizes that are not multiples of 4
+VARIANTS = dict(default=(0, N_SEEDS), lfe=(100000, 120), tv=(200000, 120), wide=(300000, 240))
+STACKS = [[1, 3, 7], [0, 1, 2, 5], [1, 8], [2, 4], [3, 4], [8, 3, 6], [1, 2], [1, 2, 3, 4], [2, 3], [1, 5], [2, 5, 6, 7], [0, 1],
+          [1, 8, 3, 7], [2, 7], [0, 1, 8, 3, 4], [1, 2, 5, 6], [5, 7], [8, 6], [1, 7], [0, 2]]
+WIDE_RATES = [(44100, 44100), (32000, 32000), (16000, 16000), (48000, 16000), (48000, 32000), (48000, 24000), (48000, 8000),
+              (48000, 12000), (44100, 32000), (96000, 44100), (16000, 44100), (32000, 16000)] + RATES
 SCENE = ["zoa", "foa", "soa", "toa", "toa_projection"]
 
 
@@ -68,6 +75,35 @@ def case(seed, variant="default"):
         c["limiter"] = False
     elif rng.random() < 0.3:
         c["threshold"] = float(pick([-3.0, -6.0, -0.5]))
+    if variant == "wide":
+        kinds2 = KINDS + ["scalable"] * 4 + ["dmx:%d" % l for l in (2, 3, 4, 5, 6, 7, 8, 1)]
+        pair = tuple(pick(kinds2) for _ in pair)
+        c["pair"] = pair
+        for k in ("1", "2"):
+            st = pick(STACKS)
+            c["scalable_layers" + k] = st
+            c["scalable_gains" + k] = {int(li): (int(rng.integers(1, 64)), int(rng.integers(-1200, 600)))
+                                       for li in range(len(st)) if rng.random() < 0.4}
+            c["dmx_default" + k] = (pick(MODES), int(rng.integers(0, 11)))
+        if rng.random() < 0.25:
+            c["big_endian"] = True
+        c.pop("rate", None), c.pop("out_rate", None)
+        if rng.random() < 0.35:
+            c["rate"], c["out_rate"] = pick(WIDE_RATES)
+            if layout == ("ss", 7) and any(k in SCENE for k in pair):   # (slot 23 of H behind the resampler: see above)
+                c["out_rate"] = c["rate"] if c["rate"] in (16000, 32000, 44100, 48000) else 48000
+                c["rate"] = c["out_rate"]
+        if not any(k in ("scalable", "toa_projection") for k in pair) and rng.random() < 0.25:
+            c["fs"] = fs = pick([1000, 441, 250, 1023, 77, 2000])
+            c["frames"] = frames = int(rng.integers(4, 9)) if fs >= 441 else int(rng.integers(12, 30))
+            c.pop("trims", None)
+            trims = {}
+        if rng.random() < 0.2:   # a frame trimmed away completely, or all but one sample
+            f0 = int(rng.integers(0, frames))
+            a = int(rng.integers(0, fs + 1))
+            tr = dict(c.get("trims", {}))
+            tr[f0] = (a, fs - a) if rng.random() < 0.6 else (a, max(0, fs - a - 1))
+            c["trims"] = tr
     return c
 
 

@@ -90,6 +90,15 @@ int iamf_hip_batch_set_second_element(iamf_hip_batch *b, const iamf_hip_matrix *
   b->m2 = m->m;
   return 0;
 }
+int iamf_hip_batch_lfe_advance(iamf_hip_batch *b, const float *in, int64_t ss, int32_t n, void *st, int32_t s0, int32_t cnt) {
+  (void)st;
+  if (!b || !in || n <= 0 || n > b->cfg.frame_size || s0 < 0 || cnt <= 0 || s0 + cnt > b->cfg.n_streams) return IAMF_HIP_ERR_BAD_ARG;
+  float acc = 0;
+  for (int s = s0; s < s0 + cnt; ++s)
+    for (int i = 0; i < n; ++i) acc += ((const volatile float *)in)[(int64_t)s * ss + i];
+  (void)acc;
+  return IAMF_HIP_OK;
+}
 int iamf_hip_batch_share_lfe_state(iamf_hip_batch *b, iamf_hip_batch *o) {
   return b && o && b != o && b->cfg.lfe_hoa && o->cfg.lfe_hoa && b->cfg.n_streams == o->cfg.n_streams ? 0 : IAMF_HIP_ERR_BAD_ARG;
 }

@@ -202,8 +202,13 @@ def demixing_block(pid, mode):
     return obu(OBU_PARAMETER_BLOCK, leb128(pid) + bytes([(mode & 7) << 5]))
 
 
-def lpcm_bytes(x, sample_size=16, little_endian=True):
+LE_DEFAULT = True   # the byte order lpcm_bytes writes when the caller does not say (tests/e2e_cases.py build() sets it per stream)
+
+
+def lpcm_bytes(x, sample_size=16, little_endian=None):
     """x: [channels_in_substream(1 or 2)][n] float in [-1, 1) -> sample-interleaved bytes"""
+    if little_endian is None:
+        little_endian = LE_DEFAULT
     inter = np.ascontiguousarray(x.T)
     e = "<" if little_endian else ">"
     if sample_size == 16:

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 _G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLD = json.load(open(os.path.join(_G, "fuzz.json")))
-GOLD_V = dict(lfe=json.load(open(os.path.join(_G, "fuzz_lfe.json"))), tv=json.load(open(os.path.join(_G, "fuzz_tv.json"))))
+GOLD_V = {v: json.load(open(os.path.join(_G, "fuzz_%s.json" % v))) for v in ("lfe", "tv", "wide")}
 
 
 from test_gpu_group import group_decode_all, lib  # noqa: E402,F401  (the fixture that declares the group entry points)
@@ -69,15 +69,19 @@ class _Variant:
         return open_
 
 
-@pytest.mark.parametrize("variant,seed", [(v, s) for v in ("lfe", "tv") for s in range(F.VARIANTS[v][1])])
+@pytest.mark.parametrize("variant,seed", [(v, s) for v in ("lfe", "tv", "wide") for s in range(F.VARIANTS[v][1])])
 def test_random_stream_matches_the_other_builds_of_the_reference(lib, variant, seed):
     """the same generator against the reference built -DDISABLE_LFE_HOA=0 (scene-based elements three times as likely: one or
     two of them through the LFE generator, beside channel-based ones, behind the resampler) and -DSAMSUNG_TV (its own layout
-    -> layout tables, 12-channel PCM stride)"""
+    -> layout tables, 12-channel PCM stride); and "wide": the default build with what the first generator held fixed —
+    twenty scalable layer stacks with random output gains, any layout with demixing info, the demixing defaults, big-endian
+    samples, seventeen stream / output rate pairs with and without conversion, units trimmed away completely, frame sizes
+    that are not multiples of 4"""
     want = GOLD_V[variant][str(seed)]
     assert "sha256" in want, want
     stream, c = F.build(seed, variant)
-    pcm, rets = decode_stream(_Variant(lib, variant), stream, c["layout"], **F.decode_kwargs(c, variant))
+    dlib = lib if variant == "wide" else _Variant(lib, variant)
+    pcm, rets = decode_stream(dlib, stream, c["layout"], **F.decode_kwargs(c, variant))
     desc = {k: v for k, v in c.items() if not k.endswith(("modes", "modes1", "modes2"))}
     assert [int(r) for r in rets] == want["rets"], (variant, seed, desc)
     assert list(pcm.shape) == want["shape"], (variant, seed, desc)
@@ -92,6 +96,23 @@ def test_random_lfe_stream_through_a_group_of_handles(lib, seed):
     stream, c = F.build(seed, "lfe")
     case = dict(c, lfe_hoa=True)
     rc, outs = group_decode_all(lib, case, stream, 5, 2, starve=lambda r, i: (r + 2 * i) % 3 == 0 and i % 2 == 1)
+    assert rc == 0, (seed, rc)
+    for i, (pcm, rets) in enumerate(outs):
+        assert [int(r) for r in rets] == want["rets"], (seed, i)
+        assert F.digest(pcm) == want["sha256"], (seed, i)
+
+
+@pytest.mark.parametrize("seed", range(0, F.VARIANTS["wide"][1], 4))
+def test_random_wide_stream_through_a_group_of_handles(lib, seed):
+    """every fourth stream of the wide set through a group: stacks of layers, units trimmed away (the demixers' and
+    down-mixers' states move on, nothing is launched), new rate pairs.  Frame sizes that are not a multiple of 4 are a
+    single-handle matter: the group says so at create (IAMF_ERR_INTERNAL from its unpack layout)."""
+    want = GOLD_V["wide"][str(seed)]
+    stream, c = F.build(seed, "wide")
+    rc, outs = group_decode_all(lib, dict(c), stream, 4, 2, starve=lambda r, i: (r + i) % 3 == 0 and i % 2 == 1)
+    if c["fs"] & 3:
+        assert rc != 0
+        return
     assert rc == 0, (seed, rc)
     for i, (pcm, rets) in enumerate(outs):
         assert [int(r) for r in rets] == want["rets"], (seed, i)

@@ -14,13 +14,19 @@ import iac_amd  # noqa: E402
 from decoder_driver import decode_stream  # noqa: E402
 
 lib = C.CDLL(iac_amd.lib_path())
-gold = json.load(open(os.path.join(ROOT, "tests", "golden_tmp", "fuzz_more.json")))
+variant = sys.argv[1] if len(sys.argv) > 1 else "default"
+gold = json.load(open(os.path.join(ROOT, "tests", "golden_tmp", "fuzz_more_%s.json" % variant)))["gold"]
+from test_gpu_fuzz_facade import _Variant  # noqa: E402
+dlib = lib if variant in ("default", "wide") else _Variant(lib, variant)
 bad = []
 for k in sorted(gold, key=int):
     seed = int(k)
-    stream, c = F.build(seed)
+    if "sha256" not in gold[k]:
+        print(seed, "reference:", gold[k])
+        continue
+    stream, c = F.build(seed, variant)
     try:
-        pcm, rets = decode_stream(lib, stream, c["layout"], **F.decode_kwargs(c))
+        pcm, rets = decode_stream(dlib, stream, c["layout"], **F.decode_kwargs(c, variant))
         ok = [int(r) for r in rets] == gold[k]["rets"] and F.digest(pcm) == gold[k]["sha256"]
         why = "" if ok else ("rets" if [int(r) for r in rets] != gold[k]["rets"] else "pcm")
     except AssertionError as e:
