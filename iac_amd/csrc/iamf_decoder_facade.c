@@ -559,10 +559,7 @@ static int parse_element(struct IAMF_Decoder *d, const Obu *o) { /* IAMF_OBU.c:3
   }
   if (r.err) return IAMF_ERR_INVALID_PACKET;
   for (int i = 0; i < d->nel; ++i)
-    if (d->el[i].id == e.id) {
-      d->el[i] = e;
-      return IAMF_OK;
-    }
+    if (d->el[i].id == e.id) return IAMF_OK; /* "already in database": the first one stays (iamf_database_element_add, :1136-1140) */
   if (d->nel >= MAX_ELEMENTS) return IAMF_ERR_UNIMPLEMENTED;
   d->el[d->nel++] = e;
   return IAMF_OK;
@@ -615,11 +612,8 @@ static int parse_presentation(struct IAMF_Decoder *d, const Obu *o) { /* IAMF_OB
     if (p.loud[i].info_type & ~3) rd_skip(&r, rd_leb128(&r));
   }
   if (r.err) return IAMF_ERR_INVALID_PACKET;
-  for (int i = 0; i < d->npr; ++i)
-    if (d->pr[i].id == p.id) {
-      d->pr[i] = p;
-      return IAMF_OK;
-    }
+  /* every mix presentation OBU is kept, whatever its id (iamf_object_set_add, :1215): a lookup by id finds the first, the
+   * matching score is taken over all of them (setup_pipeline) */
   if (d->npr >= MAX_PRESENTATIONS) return IAMF_ERR_UNIMPLEMENTED;
   d->pr[d->npr++] = p;
   return IAMF_OK;
@@ -1119,6 +1113,21 @@ static int dropped_unit_advance(struct IAMF_Decoder *d, int ns, iamf_hip_dmx_fra
   return rendered;
 }
 
+/* iamf_target_layout_matching_calculation, IAMF_decoder.c:2997-3028: 100 for the output layout itself, else 50 plus / minus
+ * the difference in channel count (a target the reference knows no channel count for counts as 0 channels) */
+static int layout_match_score(const struct IAMF_Decoder *d, int type, int ss) {
+  const int out_ch = d->out_type == IAMF_LAYOUT_TYPE_BINAURAL ? 2 : k_ss_channels[d->out_ss];
+  int chs = 0;
+  if (type == d->out_type && (type == IAMF_LAYOUT_TYPE_BINAURAL ||
+                              (type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION && ss == (int)d->out_ss)))
+    return 100;
+  if (type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION)
+    chs = ss >= 0 && ss < (int)(sizeof(k_ss_channels) / sizeof(k_ss_channels[0])) ? k_ss_channels[ss] : 0;
+  else if (type == IAMF_LAYOUT_TYPE_BINAURAL)
+    chs = 2;
+  return out_ch < chs ? 50 + (chs - out_ch) : 50 - (out_ch - chs);
+}
+
 static int setup_pipeline(struct IAMF_Decoder *d) {
   iamf_hip_batch_config cfg;
   Presentation *p = 0;
@@ -1127,26 +1136,40 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   d->pre[1].use_dmx = d->pre[1].use_demix = 0;
   if (!d->have_header || !d->have_codec || !d->nel || !d->npr) return IAMF_ERR_BUFFER_TOO_SMALL;
   if (d->out_type == IAMF_LAYOUT_TYPE_NOT_DEFINED) return IAMF_ERR_BAD_ARG;
-  /* iamf_decoder_get_best_mix_presentation, IAMF_decoder.c:3083-3111 */
+  /* iamf_decoder_get_best_mix_presentation, IAMF_decoder.c:3083-3111: the only one; else the one the caller named; else the
+   * FIRST one with the highest matching score over its layouts (iamf_mix_presentation_matching_calculation, :3059-3081) */
   if (d->npr == 1) {
     p = &d->pr[0];
   } else {
-    for (int i = 0; i < d->npr && d->mix_id >= 0; ++i)
+    int best = 0;
+    for (int i = 0; i < d->npr && d->mix_id >= 0 && !p; ++i)   /* iamf_database_get_mix_presentation: the first with that id */
       if (d->pr[i].id == (uint64_t)d->mix_id) p = &d->pr[i];
-    for (int i = 0; i < d->npr && !p; ++i)
-      for (int l = 0; l < d->pr[i].nlayouts; ++l)
-        if (d->pr[i].layout_type[l] == d->out_type &&
-            (d->out_type == IAMF_LAYOUT_TYPE_BINAURAL || d->pr[i].layout_ss[l] == (int)d->out_ss))
-          p = &d->pr[i];
-    if (!p) p = &d->pr[0];
+    const int named = p != 0;
+    for (int i = 0; i < d->npr && !named; ++i) {
+      int score = 0;
+      for (int l = 0; l < d->pr[i].nlayouts; ++l) {
+        const int s = layout_match_score(d, d->pr[i].layout_type[l], d->pr[i].layout_ss[l]);
+        if (s > score) score = s;
+      }
+      if (score > best) {
+        best = score;
+        p = &d->pr[i];
+      }
+    }
+    if (!p) return IAMF_ERR_INTERNAL; /* (the reference: no presentation, IAMF_ERR_INTERNAL from configure) */
   }
   d->sel = p;
+  /* iamf_mix_presentation_get_best_loudness, :3030-3057: the loudness of the FIRST layout with the highest score, 0 without one */
   d->mix_loudness = 0.f;
-  for (int l = p->nlayouts - 1; l >= 0; --l) {
-    int match = p->layout_type[l] == d->out_type &&
-                (d->out_type == IAMF_LAYOUT_TYPE_BINAURAL || p->layout_ss[l] == (int)d->out_ss);
-    if (match || l == 0) d->mix_loudness = q_to_float(p->loud[l].integrated_loudness, 8);
-    if (match) break;
+  {
+    int best = 0;
+    for (int l = 0; l < p->nlayouts; ++l) {
+      const int s = layout_match_score(d, p->layout_type[l], p->layout_ss[l]);
+      if (s > best) {
+        best = s;
+        d->mix_loudness = q_to_float(p->loud[l].integrated_loudness, 8);
+      }
+    }
   }
   for (int i = 0; i < p->nel; ++i) {
     d->sel_el[i] = find_element(d, p->el_id[i]);
@@ -1398,6 +1421,11 @@ int IAMF_decoder_configure(IAMF_DecoderHandle d, const uint8_t *data, uint32_t s
     uint32_t n = obu_split(data + pos, size - pos, &o);
     if (!n) break;
     rc = IAMF_OK;
+    /* a redundant copy of a descriptor is skipped once all four kinds have been seen (:2800-2803) */
+    if (o.redundant && d->have_header && d->have_codec && d->nel && d->npr) {
+      pos += n;
+      continue;
+    }
     switch (o.type) {
       case 31:
         if (o.payload_size < 6 || memcmp(o.payload, "iamf", 4) || o.payload[4] > 1) return IAMF_ERR_INVALID_PACKET;

@@ -61,7 +61,7 @@ def last_metadata(ref, d, owns_anchors):
 
 
 def decode_stream(ref, stream_bytes, layout, bit_depth=16, out_rate=0, loudness=0.0, limiter=True,
-               threshold=-1.0, pcm_channels=None, metadata=None, pts=(0, 90000)):
+               threshold=-1.0, pcm_channels=None, metadata=None, pts=(0, 90000), mix_id=None):
     # pcm_channels: channel stride of the PCM the decoder writes (a -DSAMSUNG_TV build: always 12)
     """layout: ('ss', IAMF_SoundSystem enum value) or ('binaural',). Returns (pcm ndarray
     [n][ch] (24-bit: [n][ch][3] bytes), list of per-call return values)."""
@@ -100,6 +100,9 @@ def decode_stream(ref, stream_bytes, layout, bit_depth=16, out_rate=0, loudness=
     # metadata: dict(rows=[], owns_anchors=bool) — a row (last_metadata) after configure and after every decode call
     # that delivered a frame or flushed
     ref.IAMF_decoder_set_pts(d, pts[0], pts[1])
+    if mix_id is not None:
+        ref.IAMF_decoder_set_mix_presentation_id.argtypes = [C.c_void_p, C.c_uint64]
+        assert ref.IAMF_decoder_set_mix_presentation_id(d, mix_id) == 0
     rsize = C.c_uint32(0)
     r = ref.IAMF_decoder_configure(d, stream_bytes, len(stream_bytes), C.byref(rsize))
     assert r == 0, "configure failed: %d" % r

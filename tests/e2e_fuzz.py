@@ -22,7 +22,11 @@ N_SEEDS = 240
 # "wide": the default build again with the dimensions the first generator held fixed — scalable layer stacks, any layout
 # with demixing info, the demixing defaults, big-endian samples, more stream / output rates (with and without conversion),
 # frames trimmed away completely, frame sizes that are not multiples of 4
-VARIANTS = dict(default=(0, N_SEEDS), lfe=(100000, 120), tv=(200000, 120), wide=(300000, 240))
+# "multi": three elements in the stream, two or three mix presentations of one or two of them each (own gains, one to three
+# layouts with their own loudness), the caller naming one (IAMF_decoder_set_mix_presentation_id), a wrong one, or none — the
+# reference then takes the FIRST presentation with the best layout score (IAMF_decoder.c:2997-3111) and the loudness of the
+# best-scoring layout; sub-streams and parameter blocks of elements outside the chosen presentation are skipped
+VARIANTS = dict(default=(0, N_SEEDS), lfe=(100000, 120), tv=(200000, 120), wide=(300000, 240), multi=(400000, 160))
 STACKS = [[1, 3, 7], [0, 1, 2, 5], [1, 8], [2, 4], [3, 4], [8, 3, 6], [1, 2], [1, 2, 3, 4], [2, 3], [1, 5], [2, 5, 6, 7], [0, 1],
           [1, 8, 3, 7], [2, 7], [0, 1, 8, 3, 4], [1, 2, 5, 6], [5, 7], [8, 6], [1, 7], [0, 2]]
 WIDE_RATES = [(44100, 44100), (32000, 32000), (16000, 16000), (48000, 16000), (48000, 32000), (48000, 24000), (48000, 8000),
@@ -107,7 +111,76 @@ def case(seed, variant="default"):
     return c
 
 
+def case_multi(seed):
+    c = case(seed, "wide")
+    rng = np.random.default_rng(905000 + VARIANTS["multi"][0] + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
+    c.pop("pair_ramps", None)
+    if any(k in ("scalable", "toa_projection") for k in c["pair"]) and c["fs"] < 512:
+        c["fs"] = 1024
+    c["elements"] = [pick(KINDS + ["scalable", "dmx:7", "dmx:4", "dmx:3"]) for _ in range(3)]
+    if c["fs"] & 3 or c["fs"] < 240:
+        c["fs"], c["frames"] = 1024, int(rng.integers(4, 8))
+        c.pop("trims", None)
+    pres = []
+    for i in range(int(rng.integers(2, 4))):
+        els = list(rng.permutation(3)[:int(rng.integers(1, 3))])
+        lays = []
+        for _ in range(int(rng.integers(1, 4))):
+            k = int(rng.integers(0, 14))
+            lay = ("binaural",) if k == 13 else ("ss", k)
+            if lay not in lays:
+                lays.append(lay)
+        pres.append(dict(id=int(pick([11, 22, 33, 44, 7])) if rng.random() < 0.2 else 10 * (i + 1) + i, elements=[int(e) for e in els],
+                         gains=[int(rng.integers(-1200, 300)) for _ in els], out_gain=int(rng.integers(-500, 300)), layouts=lays,
+                         loudness=[int(rng.integers(-30, -10)) * 256 for _ in lays]))
+    c["presentations"] = pres
+    r = rng.random()
+    c["mix_id"] = -1 if r < 0.45 else (int(pick(pres)["id"]) if r < 0.9 else 999)
+    if "loudness" not in c and rng.random() < 0.5:
+        c["loudness"] = float(pick([-16.0, -24.0]))
+    # (H from a scene-based element behind the resampler: see above — with several presentations any element may be chosen)
+    if c["layout"] == ("ss", 7) and c.get("out_rate") and c.get("rate") != c.get("out_rate"):
+        c["out_rate"] = c["rate"] = 48000
+    return c
+
+
+def build_multi(seed):
+    import iamf_writer as W
+    c = case_multi(seed)
+    fs, F, ss, rate = c["fs"], c["frames"], c["sample_size"], c.get("rate", 48000)
+    le = not c.get("big_endian", False)
+    n = fs * F
+    W.LE_DEFAULT = le
+    try:
+        stream = E._descriptor_prefix(fs, ss, rate, le)
+        frames, sid = [], 0
+        for k, kind in enumerate(c["elements"]):
+            d, fr, _, ns = E._pair_element(kind, k + 1, sid, 200 + 10 * k, c["seed"] + k, n, fs, ss, rate, c)
+            stream += d
+            frames.append(fr)
+            sid += ns
+        for i, p in enumerate(c["presentations"]):
+            els = [dict(eid=e + 1, pdef=E._pdef_static(100 + 10 * i + 2 * j, rate), default_q78=g)
+                   for j, (e, g) in enumerate(zip(p["elements"], p["gains"]))]
+            stream += W.mix_presentation(p["id"], els, dict(pdef=E._pdef_static(101 + 10 * i, rate), default_q78=p["out_gain"]), p["layouts"],
+                                         loudness_infos=[dict(integrated=q, peak=0) for q in p["loudness"]])
+        for f in range(F):
+            stream += W.temporal_delimiter()
+            subs = []
+            for fr in frames:
+                blocks, s_ = fr(f)
+                stream += blocks
+                subs += s_
+            stream += W.audio_frames(subs, trim=c.get("trims", {}).get(f))
+    finally:
+        W.LE_DEFAULT = True
+    return stream, c
+
+
 def build(seed, variant="default"):
+    if variant == "multi":
+        return build_multi(seed)
     name = "fuzz_%s_%d" % (variant, seed)
     E.CASES[name] = case(seed, variant)
     try:
@@ -121,6 +194,8 @@ def decode_kwargs(c, variant="default"):
               limiter=c.get("limiter", True), threshold=c.get("threshold", -1.0))
     if variant == "tv":
         kw["pcm_channels"] = 12   # IAMF_decoder.c:3492-3495
+    if "mix_id" in c and c["mix_id"] >= 0:
+        kw["mix_id"] = c["mix_id"]
     return kw
 
 

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 _G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLD = json.load(open(os.path.join(_G, "fuzz.json")))
-GOLD_V = {v: json.load(open(os.path.join(_G, "fuzz_%s.json" % v))) for v in ("lfe", "tv", "wide")}
+GOLD_V = {v: json.load(open(os.path.join(_G, "fuzz_%s.json" % v))) for v in ("lfe", "tv", "wide", "multi")}
 
 
 from test_gpu_group import group_decode_all, lib  # noqa: E402,F401  (the fixture that declares the group entry points)
@@ -69,18 +69,20 @@ class _Variant:
         return open_
 
 
-@pytest.mark.parametrize("variant,seed", [(v, s) for v in ("lfe", "tv", "wide") for s in range(F.VARIANTS[v][1])])
+@pytest.mark.parametrize("variant,seed", [(v, s) for v in ("lfe", "tv", "wide", "multi") for s in range(F.VARIANTS[v][1])])
 def test_random_stream_matches_the_other_builds_of_the_reference(lib, variant, seed):
     """the same generator against the reference built -DDISABLE_LFE_HOA=0 (scene-based elements three times as likely: one or
     two of them through the LFE generator, beside channel-based ones, behind the resampler) and -DSAMSUNG_TV (its own layout
     -> layout tables, 12-channel PCM stride); and "wide": the default build with what the first generator held fixed —
     twenty scalable layer stacks with random output gains, any layout with demixing info, the demixing defaults, big-endian
     samples, seventeen stream / output rate pairs with and without conversion, units trimmed away completely, frame sizes
-    that are not multiples of 4"""
+    that are not multiples of 4; and "multi": three elements in the stream, two or three mix presentations (ids may repeat) of
+    one or two of them, the caller naming one, a wrong one or none (IAMF_decoder_set_mix_presentation_id; the reference's
+    matching score over the layouts, IAMF_decoder.c:2997-3111)"""
     want = GOLD_V[variant][str(seed)]
     assert "sha256" in want, want
     stream, c = F.build(seed, variant)
-    dlib = lib if variant == "wide" else _Variant(lib, variant)
+    dlib = lib if variant in ("wide", "multi") else _Variant(lib, variant)
     pcm, rets = decode_stream(dlib, stream, c["layout"], **F.decode_kwargs(c, variant))
     desc = {k: v for k, v in c.items() if not k.endswith(("modes", "modes1", "modes2"))}
     assert [int(r) for r in rets] == want["rets"], (variant, seed, desc)

@@ -17,7 +17,7 @@ lib = C.CDLL(iac_amd.lib_path())
 variant = sys.argv[1] if len(sys.argv) > 1 else "default"
 gold = json.load(open(os.path.join(ROOT, "tests", "golden_tmp", "fuzz_more_%s.json" % variant)))["gold"]
 from test_gpu_fuzz_facade import _Variant  # noqa: E402
-dlib = lib if variant in ("default", "wide") else _Variant(lib, variant)
+dlib = lib if variant in ("default", "wide", "multi") else _Variant(lib, variant)
 bad = []
 for k in sorted(gold, key=int):
     seed = int(k)
@@ -33,5 +33,5 @@ for k in sorted(gold, key=int):
         ok, why = False, str(e)
     if not ok:
         bad.append(seed)
-        print(seed, why, {x: c[x] for x in ("pair", "layout", "fs", "frames", "bit_depth", "sample_size", "trims", "rate", "out_rate", "loudness", "limiter", "threshold", "pair_ramps") if x in c}, flush=True)
+        print(seed, why, {x: c[x] for x in ("elements", "presentations", "mix_id", "pair", "layout", "fs", "frames", "bit_depth", "sample_size", "trims", "rate", "out_rate", "loudness", "limiter", "threshold", "pair_ramps") if x in c}, flush=True)
 print("checked", len(gold), "bad", bad)
