@@ -33,7 +33,20 @@ def one(seed, variant):
     return dict(sha256=F.digest(pcm), shape=list(pcm.shape), rets=[int(r) for r in rets])
 
 
+def one_blocks(seed):
+    from decoder_driver import decode_stream_blocks
+    variant, vs, block = F.blocks_case(seed)
+    ref = C.CDLL(os.path.join(HERE, *REF[variant]))
+    stream, c = F.build(vs, variant)
+    pcm, events = decode_stream_blocks(ref, stream, c["layout"], block, **F.decode_kwargs(c, variant))
+    return dict(sha256=F.digest(pcm), shape=list(pcm.shape), events=F.events_digest(events), calls=len(events),
+                last=[list(e) for e in events[-2:]])
+
+
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--blocks":
+        print(json.dumps(one_blocks(int(sys.argv[2]))))
+        return
     if len(sys.argv) >= 3 and sys.argv[1] == "--one":
         print(json.dumps(one(int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else "default")))
         return
@@ -53,6 +66,15 @@ def main():
             json.dump(out, f, indent=0, sort_keys=True)
         print("fuzz goldens (%s) written:" % variant, sum("sha256" in v for v in out.values()), "decoded,",
               sum("error" in v for v in out.values()), "refused,", sum("crash" in v for v in out.values()), "crashed")
+    out = {}
+    for seed in range(F.N_BLOCKS):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--blocks", str(seed)], capture_output=True, text=True)
+        out[str(seed)] = dict(crash=r.returncode) if r.returncode else json.loads(r.stdout.strip().splitlines()[-1])
+        print("  fuzz blocks %3d %s -> %s" % (seed, F.blocks_case(seed), out[str(seed)].get("shape") or out[str(seed)]))
+    with open(os.path.join(ROOT, "tests", "golden", "fuzz_blocks.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("fuzz goldens (blocks) written:", sum("sha256" in v for v in out.values()), "decoded,",
+          sum("crash" in v for v in out.values()), "crashed")
 
 
 if __name__ == "__main__":

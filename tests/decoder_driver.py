@@ -214,3 +214,109 @@ def decode_stream_switching(ref, stream_bytes, layouts, switch_after, bit_depth=
     rets.append(n)
     ref.IAMF_decoder_close(d)
     return chunks, rets
+
+
+def decode_stream_blocks(ref, stream_bytes, layout, block, bit_depth=16, out_rate=0, loudness=0.0, limiter=True, threshold=-1.0,
+                         pcm_channels=None, mix_id=None, max_calls=100000):
+    """The reference player's own loop (test/tools/iamfplayer/player/iamfplayer.c:529-662, bs_input_wav_output) with a block
+    buffer of `block` bytes instead of its 184 320: the file is read block by block, IAMF_decoder_configure is fed until it
+    stops answering IAMF_ERR_BUFFER_TOO_SMALL, IAMF_decoder_decode is called while it consumes something, what is left of
+    a block moves to the front of the next, the end of the file flushes.  Returns (pcm, events): events = every call's
+    ('c' | 'd', return value, rsize) — the incremental-parsing protocol itself is compared, not only the samples."""
+    ref.IAMF_decoder_open.restype = C.c_void_p
+    ref.IAMF_decoder_close.argtypes = [C.c_void_p]
+    ref.IAMF_decoder_configure.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    ref.IAMF_decoder_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_uint32), C.c_void_p]
+    ref.IAMF_decoder_output_layout_set_sound_system.argtypes = [C.c_void_p, C.c_int]
+    ref.IAMF_decoder_output_layout_set_binaural.argtypes = [C.c_void_p]
+    ref.IAMF_decoder_set_normalization_loudness.argtypes = [C.c_void_p, C.c_float]
+    ref.IAMF_decoder_set_bit_depth.argtypes = [C.c_void_p, C.c_uint32]
+    ref.IAMF_decoder_peak_limiter_enable.argtypes = [C.c_void_p, C.c_uint32]
+    ref.IAMF_decoder_peak_limiter_set_threshold.argtypes = [C.c_void_p, C.c_float]
+    ref.IAMF_decoder_set_sampling_rate.argtypes = [C.c_void_p, C.c_uint32]
+    ref.IAMF_decoder_set_pts.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
+    ref.IAMF_decoder_set_mix_presentation_id.argtypes = [C.c_void_p, C.c_uint64]
+    ref.IAMF_layout_sound_system_channels_count.argtypes = [C.c_int]
+    d = ref.IAMF_decoder_open()
+    if not limiter:
+        ref.IAMF_decoder_peak_limiter_enable(d, 0)
+    else:
+        ref.IAMF_decoder_peak_limiter_set_threshold(d, threshold)
+    ref.IAMF_decoder_set_normalization_loudness(d, loudness)
+    ref.IAMF_decoder_set_bit_depth(d, bit_depth)
+    if out_rate:
+        assert ref.IAMF_decoder_set_sampling_rate(d, out_rate) == 0
+    if layout[0] == "ss":
+        ref.IAMF_decoder_output_layout_set_sound_system(d, layout[1])
+        ch = ref.IAMF_layout_sound_system_channels_count(layout[1])
+    else:
+        ref.IAMF_decoder_output_layout_set_binaural(d)
+        ch = 2
+    ch_layout = ch
+    if pcm_channels:
+        ch = pcm_channels
+    bps = bit_depth // 8
+    pcm = C.create_string_buffer(bps * 6144 * 6 * max(ch, ch_layout))
+    events, chunks = [], []
+    left, pos, end, state, calls = b"", 0, False, 0, 0
+    rsize = C.c_uint32(0)
+    while calls < max_calls:
+        if len(left) != block:
+            got = stream_bytes[pos:pos + block - len(left)]
+            pos += len(got)
+            if not got:
+                end = True
+        else:
+            got = b""
+        data = left + got
+        size, used, ret = len(data), 0, 0
+        if state <= 0:
+            if end:
+                break
+            rsize.value = 0
+            if state == 0:
+                ref.IAMF_decoder_set_pts(d, 0, 90000)
+            if mix_id is not None:
+                ref.IAMF_decoder_set_mix_presentation_id(d, mix_id)
+            ret = ref.IAMF_decoder_configure(d, data, size, C.byref(rsize))
+            calls += 1
+            events.append(("c", ret, rsize.value))
+            if ret == 0:
+                state = 1
+            elif ret != -2 or not rsize.value:
+                break
+            used += rsize.value
+        if state > 0:
+            while calls < max_calls:
+                rsize.value = 0
+                if not end:
+                    rest = data[used:]
+                    ret = ref.IAMF_decoder_decode(d, rest, len(rest), C.byref(rsize), pcm)
+                else:
+                    ret = ref.IAMF_decoder_decode(d, None, 0, C.byref(rsize), pcm)
+                calls += 1
+                events.append(("d", ret, rsize.value))
+                if ret > 0:
+                    chunks.append(pcm.raw[:ret * ch * bps])
+                if end:
+                    break
+                used += rsize.value
+                if ret == -5:
+                    state = ret
+                if ret < 0 or used >= size or not rsize.value:
+                    break
+        if end:
+            break
+        if len(data) - used == block and not got:   # a full block nothing is consumed from: the player would spin for ever
+            events.append(("stuck", 0, 0))
+            break
+        left = data[used:]
+    ref.IAMF_decoder_close(d)
+    raw = np.frombuffer(b"".join(chunks), dtype=np.uint8)
+    if bit_depth == 16:
+        out = raw.view(np.int16).reshape(-1, ch)
+    elif bit_depth == 32:
+        out = raw.view(np.int32).reshape(-1, ch)
+    else:
+        out = raw.reshape(-1, ch, 3)
+    return out.copy(), events

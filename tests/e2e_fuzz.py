@@ -201,3 +201,21 @@ def decode_kwargs(c, variant="default"):
 
 def digest(pcm):
     return hashlib.sha256(np.ascontiguousarray(pcm).tobytes()).hexdigest()
+
+
+# The streams above through the reference PLAYER's loop (decoder_driver.decode_stream_blocks: iamfplayer.c:529-662 with a block
+# buffer of `block` bytes): configure until it stops asking for more, decode while it consumes something, the rest of a
+# block in front of the next.  Compared: the PCM and every call's (return value, rsize).
+N_BLOCKS = 200
+
+
+def blocks_case(seed):
+    """-> (variant, seed of that variant, block size)"""
+    rng = np.random.default_rng(955000 + seed)
+    variant = ["wide", "multi", "default"][seed % 3]
+    block = int([184320, 65536, 30000, 20000, 12345, 9000, 6000, int(rng.integers(3000, 9000)), 2500, 777][int(rng.integers(0, 10))])
+    return variant, int(rng.integers(0, VARIANTS[variant][1])), block
+
+
+def events_digest(events):
+    return hashlib.sha256(repr([(k, int(r), int(n)) for k, r, n in events]).encode()).hexdigest()

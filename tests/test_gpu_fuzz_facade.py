@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import e2e_fuzz as F
-from decoder_driver import decode_stream
+from decoder_driver import decode_stream, decode_stream_blocks
 
 pytestmark = pytest.mark.gpu
 
@@ -119,3 +119,21 @@ def test_random_wide_stream_through_a_group_of_handles(lib, seed):
     for i, (pcm, rets) in enumerate(outs):
         assert [int(r) for r in rets] == want["rets"], (seed, i)
         assert F.digest(pcm) == want["sha256"], (seed, i)
+
+
+GOLD_B = json.load(open(os.path.join(_G, "fuzz_blocks.json")))
+
+
+@pytest.mark.parametrize("seed", range(F.N_BLOCKS))
+def test_random_stream_through_the_players_block_loop(lib, seed):
+    """the reference player's own loop (iamfplayer.c:529-662) with block buffers from 777 bytes to its 184 320: configure fed
+    until it stops answering IAMF_ERR_BUFFER_TOO_SMALL, decode while it consumes something, the rest of a block in front of
+    the next one, a block too small for an OBU leaves both stuck at the same call.  The PCM and EVERY call's return value and
+    rsize must be the reference's (tests/golden/fuzz_blocks.json: hashes of both)."""
+    want = GOLD_B[str(seed)]
+    variant, vs, block = F.blocks_case(seed)
+    stream, c = F.build(vs, variant)
+    pcm, events = decode_stream_blocks(lib, stream, c["layout"], block, **F.decode_kwargs(c, variant))
+    assert len(events) == want["calls"] and [list(e) for e in events[-2:]] == want["last"], (seed, variant, vs, block, events[-3:], want)
+    assert F.events_digest(events) == want["events"], (seed, variant, vs, block)
+    assert list(pcm.shape) == want["shape"] and F.digest(pcm) == want["sha256"], (seed, variant, vs, block)
