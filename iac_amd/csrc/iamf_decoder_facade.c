@@ -813,6 +813,12 @@ static int mix_gain_unit(const Param *p, float default_gain, uint64_t pt, int du
           start = sgd;
           left -= d2;
         }
+        /* The reference counts what is `left` of the frame only in this branch: behind a STEP sub-block that filled part of
+         * the frame it still takes the whole frame for what is left and writes past its gains[duration] (IAMF_decoder.c:
+         * 921-960; found by tests/e2e_fuzz.py "params": it dies of heap corruption on such streams, or goes on with a
+         * damaged heap).  Here the ramp ends where the frame ends. */
+        if (d2 > duration - count) d2 = duration - count;
+        if (d2 <= 0) break;
         if (seg->anim == ANIMATION_TYPE_LINEAR)
           gain_linear(seg->start, seg->end, (int)minterval, off, d2, g + count);
         else

@@ -351,14 +351,16 @@ def build(name):
         kb = c["pair"][1] if len(c["pair"]) > 1 else None
         da, fa, ia, na = _pair_element(ka, 1, 0, 200, c["seed"], n, fs, ss, rate, c)
         stream += da
-        els = [dict(eid=1, pdef=_pdef_static(100, rate), default_q78=eg)]
+        gs = c.get("gain_sched", {})   # pid -> dict(pdef, blocks[frame]): a case's own mix-gain parameter timelines
+        pdef_of = lambda pid: gs[pid]["pdef"] if pid in gs else _pdef_static(pid, rate)
+        els = [dict(eid=1, pdef=pdef_of(100), default_q78=eg)]
         if kb:
             db, fb, ib, nb = _pair_element(kb, 2, na, 210, c["seed"] + 1, n, fs, ss, rate, c)
             stream += db
-            els.append(dict(eid=2, pdef=_pdef_static(102, rate), default_q78=c.get("element2_gain_q78", 0)))
+            els.append(dict(eid=2, pdef=pdef_of(102), default_q78=c.get("element2_gain_q78", 0)))
         else:
             fb, ib = (lambda f: (b"", [])), None
-        stream += W.mix_presentation(1, els, dict(pdef=_pdef_static(101, rate), default_q78=og), layouts_field,
+        stream += W.mix_presentation(1, els, dict(pdef=pdef_of(101), default_q78=og), layouts_field,
                                      loudness_q78=c.get("mix_loudness_q78", 0))
         info["elements"] += [ia, ib] if kb else [ia]
         m1 = dict(duration=fs, constant_interval=fs)
@@ -376,6 +378,9 @@ def build(name):
                     stream += W.mix_gain_block(101, [dict(anim=W.ANIM_LINEAR, start=100 - 40 * f, end=60 - 40 * f),
                                                      dict(anim=W.ANIM_STEP, start=60 - 40 * f)],
                                                mode1=dict(duration=fs, constant_interval=0, intervals=[fs // 4, fs - fs // 4]))
+            for pid in sorted(gs):
+                if pid != 102 or kb:
+                    stream += gs[pid]["blocks"][f]
             stream += ba + bb + W.audio_frames(sa + sb, trim=c.get("trims", {}).get(f))
         W.LE_DEFAULT = True
         return stream, info

@@ -26,7 +26,8 @@ N_SEEDS = 240
 # layouts with their own loudness), the caller naming one (IAMF_decoder_set_mix_presentation_id), a wrong one, or none — the
 # reference then takes the FIRST presentation with the best layout score (IAMF_decoder.c:2997-3111) and the loudness of the
 # best-scoring layout; sub-streams and parameter blocks of elements outside the chosen presentation are skipped
-VARIANTS = dict(default=(0, N_SEEDS), lfe=(100000, 120), tv=(200000, 120), wide=(300000, 240), multi=(400000, 160))
+VARIANTS = dict(default=(0, N_SEEDS), lfe=(100000, 120), tv=(200000, 120), wide=(300000, 240), multi=(400000, 160),
+                params=(500000, 200))
 STACKS = [[1, 3, 7], [0, 1, 2, 5], [1, 8], [2, 4], [3, 4], [8, 3, 6], [1, 2], [1, 2, 3, 4], [2, 3], [1, 5], [2, 5, 6, 7], [0, 1],
           [1, 8, 3, 7], [2, 7], [0, 1, 8, 3, 4], [1, 2, 5, 6], [5, 7], [8, 6], [1, 7], [0, 2]]
 WIDE_RATES = [(44100, 44100), (32000, 32000), (16000, 16000), (48000, 16000), (48000, 32000), (48000, 24000), (48000, 8000),
@@ -178,9 +179,67 @@ def build_multi(seed):
     return stream, c
 
 
+def case_params(seed):
+    """the default generator's stream with mix-gain parameter timelines of its own on the element gains and the output gain:
+    definitions of mode 0 or 1, a parameter rate that is or is not the stream's, one to three sub-blocks per block with a
+    constant or explicit intervals, every animation type, the odd block missing"""
+    import iamf_writer as W
+    c = case(seed, "default")
+    c.pop("pair_ramps", None)
+    rng = np.random.default_rng(907000 + VARIANTS["params"][0] + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
+    fs, F, rate = c["fs"], c["frames"], c.get("rate", 48000)
+    sched = {}
+    for pid in (100, 101, 102):
+        if rng.random() < 0.25:
+            continue
+        prate = int(pick([rate, rate, rate, rate // 2, rate * 2, 48000, 44100, 90000, 16000]))
+        D = max(1, int(round(fs * prate / rate)))
+        mode = int(pick([0, 1]))
+        nsub = int(pick([1, 1, 2, 3]))
+        if nsub > D:
+            nsub = 1
+        ci, iv = 0, None
+        if nsub == 1:
+            ci = D
+        elif D % nsub == 0 and rng.random() < 0.5:
+            ci = D // nsub
+        else:
+            cuts = sorted(int(v) for v in rng.choice(np.arange(1, D), size=nsub - 1, replace=False))
+            iv = [b - a for a, b in zip([0] + cuts, cuts + [D])]
+        pdef = W.param_definition(pid, prate, mode=mode, duration=D, constant_interval=ci, intervals=iv)
+        blocks = []
+        for f in range(F):
+            if rng.random() < 0.1:
+                blocks.append(b"")
+                continue
+            segs = []
+            for _ in range(nsub):
+                anim = int(pick([W.ANIM_STEP, W.ANIM_LINEAR, W.ANIM_BEZIER]))
+                a, b = int(rng.integers(-1500, 500)), int(rng.integers(-1500, 500))
+                sg = dict(anim=anim, start=a)
+                if anim != W.ANIM_STEP:
+                    sg["end"] = b
+                if anim == W.ANIM_BEZIER:
+                    sg["control"] = int(rng.integers(-1500, 500))
+                    sg["rel_time"] = int(rng.integers(0, 256))
+                segs.append(sg)
+            blocks.append(W.mix_gain_block(pid, segs, mode1=None if mode == 0 else dict(duration=D, constant_interval=ci, intervals=iv)))
+        sched[pid] = dict(pdef=pdef, blocks=blocks)
+    c["gain_sched"] = sched
+    return c
+
+
 def build(seed, variant="default"):
     if variant == "multi":
         return build_multi(seed)
+    if variant == "params":
+        name = "fuzz_params_%d" % seed
+        E.CASES[name] = case_params(seed)
+        try:
+            return E.build(name)[0], E.CASES[name]
+        finally:
+            del E.CASES[name]
     name = "fuzz_%s_%d" % (variant, seed)
     E.CASES[name] = case(seed, variant)
     try:

@@ -268,3 +268,16 @@ def test_group_of_handles_with_a_batch_per_element(driver, group_driver, tmp_pat
     out = run_group(group_driver, tmp_path, stream, n, threads, layout=lay, bits=case["bit_depth"])
     assert "group_create 0" in out
     assert [int(l.split()[2]) for l in out if l.startswith("total h")] == [want] * n
+
+
+def test_parameter_timelines_the_reference_dies_on(driver, tmp_path):
+    """tests/e2e_fuzz.py "params": random mix-gain parameter timelines.  Behind a STEP sub-block that fills part of a frame
+    the reference still takes the whole frame for the animated sub-block that follows and writes past its gains[duration]
+    (IAMF_decoder.c:921-960) — heap corruption, on a few of these streams fatal.  The facade's mirror of that function once
+    did the same to its pinned ramp buffer; here the first 120 streams of the set run under ASan / UBSan."""
+    import e2e_fuzz as F
+    for seed in range(120):
+        stream, c = F.build(seed, "params")
+        lay = "b" if c["layout"][0] == "binaural" else str(c["layout"][1])
+        out = run(driver, tmp_path, stream, layout=lay, bits=c["bit_depth"])
+        assert out[0].startswith("configure 0"), (seed, out[:2])

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 _G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLD = json.load(open(os.path.join(_G, "fuzz.json")))
-GOLD_V = {v: json.load(open(os.path.join(_G, "fuzz_%s.json" % v))) for v in ("lfe", "tv", "wide", "multi")}
+GOLD_V = {v: json.load(open(os.path.join(_G, "fuzz_%s.json" % v))) for v in ("lfe", "tv", "wide", "multi", "params")}
 
 
 from test_gpu_group import group_decode_all, lib  # noqa: E402,F401  (the fixture that declares the group entry points)
@@ -69,7 +69,7 @@ class _Variant:
         return open_
 
 
-@pytest.mark.parametrize("variant,seed", [(v, s) for v in ("lfe", "tv", "wide", "multi") for s in range(F.VARIANTS[v][1])])
+@pytest.mark.parametrize("variant,seed", [(v, s) for v in ("lfe", "tv", "wide", "multi", "params") for s in range(F.VARIANTS[v][1])])
 def test_random_stream_matches_the_other_builds_of_the_reference(lib, variant, seed):
     """the same generator against the reference built -DDISABLE_LFE_HOA=0 (scene-based elements three times as likely: one or
     two of them through the LFE generator, beside channel-based ones, behind the resampler) and -DSAMSUNG_TV (its own layout
@@ -78,12 +78,19 @@ def test_random_stream_matches_the_other_builds_of_the_reference(lib, variant, s
     samples, seventeen stream / output rate pairs with and without conversion, units trimmed away completely, frame sizes
     that are not multiples of 4; and "multi": three elements in the stream, two or three mix presentations (ids may repeat) of
     one or two of them, the caller naming one, a wrong one or none (IAMF_decoder_set_mix_presentation_id; the reference's
-    matching score over the layouts, IAMF_decoder.c:2997-3111)"""
+    matching score over the layouts, IAMF_decoder.c:2997-3111); and "params": mix-gain parameter timelines on the element and
+    output gains — definitions of mode 0 or 1, a parameter rate that is or is not the stream's, one to three sub-blocks
+    per block, every animation type, blocks missing.  On a few of those the REFERENCE dies of heap corruption (it writes
+    past its gains[] behind a STEP sub-block, IAMF_decoder.c:921-960): this library must decode them without a fault
+    (the same streams run under ASan in tests/test_facade_malformed.py), there is nothing to compare."""
     want = GOLD_V[variant][str(seed)]
-    assert "sha256" in want, want
     stream, c = F.build(seed, variant)
-    dlib = lib if variant in ("wide", "multi") else _Variant(lib, variant)
+    dlib = lib if variant in ("wide", "multi", "params") else _Variant(lib, variant)
     pcm, rets = decode_stream(dlib, stream, c["layout"], **F.decode_kwargs(c, variant))
+    if "crash" in want:
+        assert len(pcm) > 0
+        return
+    assert "sha256" in want, want
     desc = {k: v for k, v in c.items() if not k.endswith(("modes", "modes1", "modes2"))}
     assert [int(r) for r in rets] == want["rets"], (variant, seed, desc)
     assert list(pcm.shape) == want["shape"], (variant, seed, desc)
