@@ -1110,7 +1110,11 @@ static void pre_frame(struct IAMF_Decoder *d, int ei, iamf_hip_dmx_frame *fr, ia
  * IAMF_decoder.c:3347) — and, unless the start or the end trim alone covers the whole frame (:3354-3357), rendered it: the
  * parametric down-mixer has stepped its weight (:2574-2583) and the HOA LFE generator's filter has run over the frame
  * (:2625-2636).  Returns 1 if the unit was rendered in the reference (the caller then advances the LFE generator). */
+static int64_t time_transform(int64_t t1, int s1, int s2);
 static int dropped_unit_advance(struct IAMF_Decoder *d, int ns, iamf_hip_dmx_frame *fr[2], iamf_hip_demix_frame *dm[2]) {
+  /* the caller's clock moves on by the samples trimmed from the start, kept frame or not (IAMF_decoder.c:3410-3415 stands
+   * in front of the "nothing left" exit :3417-3422) */
+  if (d->tu_trim_start > 0) d->pts += time_transform((int64_t)d->tu_trim_start, (int)d->rate, (int)d->pts_base);
   const int rendered = !(d->tu_trim_start == (uint64_t)d->frame_size || d->tu_trim_end == (uint64_t)d->frame_size) && ns > 0;
   for (int k = 0; k < d->sel->nel; ++k) {
     const int e = d->sel->swapped ? d->sel->nel - 1 - k : k;

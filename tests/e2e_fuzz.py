@@ -278,3 +278,9 @@ def blocks_case(seed):
 
 def events_digest(events):
     return hashlib.sha256(repr([(k, int(r), int(n)) for k, r, n in events]).encode()).hexdigest()
+
+
+def meta_digest(rows):
+    """the rows decoder_driver.last_metadata collected (pts, sound system, samples, bit depth, rate, sound mode, loudness
+    records, the DEMIXING record)"""
+    return hashlib.sha256(repr([[int(v) for v in r] for r in rows]).encode()).hexdigest()

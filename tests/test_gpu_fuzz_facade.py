@@ -26,11 +26,13 @@ def test_random_stream_matches_the_reference_decoder(lib, seed):
     want = GOLD[str(seed)]
     assert "sha256" in want, want   # (the reference decoded every stream of the committed set)
     stream, c = F.build(seed)
-    pcm, rets = decode_stream(lib, stream, c["layout"], **F.decode_kwargs(c))
+    md = dict(rows=[], owns_anchors=True)
+    pcm, rets = decode_stream(lib, stream, c["layout"], metadata=md, **F.decode_kwargs(c))
     desc = {k: v for k, v in c.items() if not k.endswith(("modes", "modes1", "modes2"))}
-    assert [int(r) for r in rets] == want["rets"], (seed, desc)
+    assert [int(r) for r in rets][:len(want["rets"])] == want["rets"], (seed, desc)   # (+ the metadata run's second flush)
     assert list(pcm.shape) == want["shape"], (seed, desc)
     assert F.digest(pcm) == want["sha256"], (seed, desc)
+    assert F.meta_digest(md["rows"]) == want["meta"], (seed, desc, "IAMF_decoder_get_last_metadata rows")
 
 
 @pytest.mark.parametrize("seed", range(0, F.N_SEEDS, 5))
@@ -86,15 +88,17 @@ def test_random_stream_matches_the_other_builds_of_the_reference(lib, variant, s
     want = GOLD_V[variant][str(seed)]
     stream, c = F.build(seed, variant)
     dlib = lib if variant in ("wide", "multi", "params") else _Variant(lib, variant)
-    pcm, rets = decode_stream(dlib, stream, c["layout"], **F.decode_kwargs(c, variant))
+    md = dict(rows=[], owns_anchors=True)
+    pcm, rets = decode_stream(dlib, stream, c["layout"], metadata=md, **F.decode_kwargs(c, variant))
     if "crash" in want:
         assert len(pcm) > 0
         return
     assert "sha256" in want, want
     desc = {k: v for k, v in c.items() if not k.endswith(("modes", "modes1", "modes2"))}
-    assert [int(r) for r in rets] == want["rets"], (variant, seed, desc)
+    assert [int(r) for r in rets][:len(want["rets"])] == want["rets"], (variant, seed, desc)
     assert list(pcm.shape) == want["shape"], (variant, seed, desc)
     assert F.digest(pcm) == want["sha256"], (variant, seed, desc)
+    assert F.meta_digest(md["rows"]) == want["meta"], (variant, seed, desc, "IAMF_decoder_get_last_metadata rows")
 
 
 @pytest.mark.parametrize("seed", range(0, F.VARIANTS["lfe"][1], 3))

@@ -21,7 +21,17 @@ for k in sorted([x for x in d.files if x != "variant"], key=lambda s: int(s.spli
         continue
     seed = int(k[4:])
     stream, c = F.build(seed, variant)
-    want, rets = decode_stream(ref, stream, c["layout"], **F.decode_kwargs(c, variant))
+    mdr = dict(rows=[], owns_anchors=False)
+    want, rets = decode_stream(ref, stream, c["layout"], metadata=mdr, **F.decode_kwargs(c, variant))
+    if "meta_%d" % seed in d.files:
+        mg, mw = d["meta_%d" % seed], np.array(mdr["rows"], dtype=np.int64)
+        if mg.shape != mw.shape or not np.array_equal(mg, mw):
+            print("   META shapes", mg.shape, mw.shape)
+            for i in range(min(len(mg), len(mw))):
+                if not np.array_equal(mg[i], mw[i]):
+                    print("   row", i, "got ", [int(v) for v in mg[i] if v != -9999])
+                    print("   row", i, "want", [int(v) for v in mw[i] if v != -9999])
+                    break
     got = d[k]
     desc = {x: c[x] for x in ("pair", "layout", "fs", "frames", "bit_depth", "sample_size") if x in c}
     desc.update({x: c[x] for x in ("trims", "rate", "out_rate", "loudness", "limiter", "threshold", "pair_ramps") if x in c})

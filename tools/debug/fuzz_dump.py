@@ -24,7 +24,9 @@ out = {"variant": np.array(variant)}
 for seed in [int(a) for a in sys.argv[1:]]:
     stream, c = F.build(seed, variant)
     try:
-        pcm, rets = decode_stream(dlib, stream, c["layout"], **F.decode_kwargs(c, variant))
+        md = dict(rows=[], owns_anchors=True)
+        pcm, rets = decode_stream(dlib, stream, c["layout"], metadata=md, **F.decode_kwargs(c, variant))
+        out["meta_%d" % seed] = np.array(md["rows"], dtype=np.int64)
         out["pcm_%d" % seed] = pcm
         out["rets_%d" % seed] = np.array(rets, dtype=np.int64)
     except AssertionError as e:
