@@ -148,3 +148,22 @@ def test_random_stream_through_the_players_block_loop(lib, seed):
     assert len(events) == want["calls"] and [list(e) for e in events[-2:]] == want["last"], (seed, variant, vs, block, events[-3:], want)
     assert F.events_digest(events) == want["events"], (seed, variant, vs, block)
     assert list(pcm.shape) == want["shape"] and F.digest(pcm) == want["sha256"], (seed, variant, vs, block)
+
+
+@pytest.mark.parametrize("variant,seed", [(v, s) for v in ("multi", "params") for s in range(0, F.VARIANTS[v][1], 5)])
+def test_random_multi_and_params_streams_through_a_group_of_handles(lib, variant, seed):
+    """every fifth stream of the sets with several mix presentations and with parameter timelines through four out-of-step
+    handles of a group (the presentation is chosen per handle at configure; ramps of some streams of a round and constants
+    of others share a launch)"""
+    want = GOLD_V[variant][str(seed)]
+    if "crash" in want:
+        pytest.skip("the reference dies on this stream")
+    stream, c = F.build(seed, variant)
+    rc, outs = group_decode_all(lib, dict(c), stream, 4, 2, starve=lambda r, i: (r + 3 * i) % 4 == 0 and i % 2 == 0)
+    if c["fs"] & 3:
+        assert rc != 0
+        return
+    assert rc == 0, (variant, seed, rc)
+    for i, (pcm, rets) in enumerate(outs):
+        assert [int(r) for r in rets] == want["rets"], (variant, seed, i)
+        assert F.digest(pcm) == want["sha256"], (variant, seed, i)

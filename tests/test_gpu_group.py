@@ -66,6 +66,9 @@ def open_handle(L, case, stream):
         L.IAMF_decoder_output_layout_set_binaural(d)
         ch = 2
     L.IAMF_decoder_set_pts(d, 0, 90000)
+    if case.get("mix_id", -1) >= 0:
+        L.IAMF_decoder_set_mix_presentation_id.argtypes = [C.c_void_p, C.c_uint64]
+        assert L.IAMF_decoder_set_mix_presentation_id(d, case["mix_id"]) == 0
     rs = C.c_uint32(0)
     assert L.IAMF_decoder_configure(d, stream, len(stream), C.byref(rs)) == 0
     return d, ch, rs.value
