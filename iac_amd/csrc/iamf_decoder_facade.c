@@ -229,6 +229,7 @@ struct IAMF_Decoder {
   float mix_loudness;
   iamf_hip_batch *batch, *batch3; /* batch3: limiter stage behind the resampler */
   iamf_hip_resampler *rs;
+  int rs_channels, reopen_rs; /* the channels `rs` was opened for; the next setup_pipeline re-opens it (TV layout switch) */
   Pre pre[2]; /* [0]: the stage in front of element 0 of `batch`; [1]: of element 1, in front of `aux` */
   /* Both elements need a stage: element 1 is rendered (stage, matrix, its mix gain) by a batch of its own into f32 and
    * handed to `batch` as a second element with the identity matrix and gain 1 (setup_pipeline) */
@@ -860,9 +861,7 @@ static void free_runtime(struct IAMF_Decoder *d) {
   d->aux = 0;
   if (d->batch) iamf_hip_batch_destroy(d->batch);
   if (d->batch3) iamf_hip_batch_destroy(d->batch3);
-  if (d->rs) iamf_hip_resampler_destroy(d->rs);
-  d->batch = d->batch3 = 0;
-  d->rs = 0;
+  d->batch = d->batch3 = 0; /* (the resampler stays: setup_pipeline decides what becomes of it) */
   if (d->h_raw) (void)hipHostFree(d->h_raw);
   d->h_raw = 0;
   d->lp_ok = 0;
@@ -932,6 +931,7 @@ int IAMF_decoder_close(IAMF_DecoderHandle d) {
   if (!d) return IAMF_ERR_BAD_ARG;
   if (d->group) return IAMF_ERR_INVALID_STATE; /* destroy the group first: it renders for this handle */
   free_runtime(d);
+  if (d->rs) iamf_hip_resampler_destroy(d->rs);
   for (int i = 0; i < d->nparam; ++i) free(d->param[i].rq);
   free(d);
   return IAMF_OK;
@@ -1188,7 +1188,18 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   }
   d->out_gain_p = param_get(d, &p->out_gain_def, IAMF_PARAMETER_TYPE_MIX_GAIN);
   d->out_channels = d->out_type == IAMF_LAYOUT_TYPE_BINAURAL ? 2 : k_ss_channels[d->out_ss];
-  resample = d->out_rate != d->rate; /* IAMF_decoder.c:3193-3199 */
+  /* IAMF_decoder.c:3189-3199: a new presentation TAKES the resampler of the one before it (iamf_presentation_take_resampler)
+   * — its rates, its history, its phase — and opens one only if there was none and the rates differ.  A second IA sequence
+   * on a handle that resampled the first one therefore goes on through the SAME resampler: no latency is skipped again,
+   * and the first sequence's ratio stays even if the new stream's rate is another (a reference quirk; its buffer sized
+   * for the first sequence's frames is why it dies on some such streams).  Kept as long as the channel count is the same;
+   * the -DSAMSUNG_TV layout switch closes and re-opens it (:3872-3876, reopen_rs). */
+  if (d->rs && (d->reopen_rs || d->rs_channels != d->out_channels)) {
+    iamf_hip_resampler_destroy(d->rs);
+    d->rs = 0;
+  }
+  d->reopen_rs = 0;
+  resample = d->rs != 0 || d->out_rate != d->rate;
   d->info.max_frame_size = d->frame_size <= 1024 ? 6144 : 6 * d->frame_size; /* :1628-1630 */
 
   memset(&cfg, 0, sizeof(cfg));
@@ -1340,7 +1351,10 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
     iamf_hip_batch_config c3;
     for (int i = 0; i < d->out_channels; ++i)
       for (int j = 0; j < d->out_channels; ++j) eye[i * d->out_channels + j] = i == j ? 1.f : 0.f;
-    if (iamf_hip_resampler_create(1, d->out_channels, (int)d->rate, (int)d->out_rate, &d->rs)) return IAMF_ERR_INTERNAL;
+    if (!d->rs) {
+      if (iamf_hip_resampler_create(1, d->out_channels, (int)d->rate, (int)d->out_rate, &d->rs)) return IAMF_ERR_INTERNAL;
+      d->rs_channels = d->out_channels;
+    }
     memset(&c3, 0, sizeof(c3));
     c3.n_streams = 1;
     c3.frame_size = 1; /* interleaved f32 in */
@@ -1464,6 +1478,7 @@ int IAMF_decoder_configure(IAMF_DecoderHandle d, const uint8_t *data, uint32_t s
     const int had_limiter = d->limiter_on && d->configured;
     Pre was[2]; /* (values only: the pinned records they point to go with the old pipeline) */
     memcpy(was, d->pre, sizeof(was));
+    d->reopen_rs = 1;
     rc = setup_pipeline(d);
     if (rc == IAMF_OK) {
       d->timestamp = ts;
@@ -1843,12 +1858,12 @@ static int render_tu(struct IAMF_Decoder *d, void *pcm) {
 static int flush_tail(struct IAMF_Decoder *d, void *pcm) { /* iamf_delay_buffer_handle, IAMF_decoder.c:3250-3301 */
   const int bytes = (int)d->bit_depth / 8;
   int n = 0;
-  if (d->flushed) {
+  if (d->flushed && !d->rs) {
     /* Every further flush call of the reference pushes another 240 zeros through the limiter and hands out what they
      * displace (iamf_delay_buffer_handle, :3284-3299): the zeros of the flush before, times a positive gain — 240
-     * sample-frames of zero PCM.  (With a resampler it also drains 35-odd more samples of filter tail per call: not
-     * mirrored, 0.)  Either way the call ends at :3521-3522. */
-    n = (!d->rs && d->limiter_on) ? 240 : 0;
+     * sample-frames of zero PCM.  Behind a resampler every call also drains another output-latency's worth of its filter
+     * tail (:3271-3282: rest_flag = 2, NULL input): the path below, again.  Either way the call ends at :3521-3522. */
+    n = d->limiter_on ? 240 : 0;
     if (n) memset(pcm, 0, ((size_t)n * d->pcm_stride + d->pcm_extra) * bytes);
     meta_note_output(d, n);
     return n;

@@ -20,20 +20,19 @@ from decoder_driver import decode_stream  # noqa: E402
 
 
 REF = dict(default=("_ref", "libiamf_ref.so"), lfe=("_ref_lfe", "libiamf_ref_lfe.so"), tv=("_ref_tv", "libiamf_ref_tv.so"),
-           wide=("_ref", "libiamf_ref.so"), multi=("_ref", "libiamf_ref.so"), params=("_ref", "libiamf_ref.so"))
+           wide=("_ref", "libiamf_ref.so"), multi=("_ref", "libiamf_ref.so"), params=("_ref", "libiamf_ref.so"), concat=("_ref", "libiamf_ref.so"))
 
 
 def one(seed, variant):
     ref = C.CDLL(os.path.join(HERE, *REF[variant]))
     stream, c = F.build(seed, variant)
-    md = dict(rows=[], owns_anchors=False)   # IAMF_decoder_get_last_metadata after configure and after every delivered frame
+    md = dict(rows=[], owns_anchors=False, strict=False)   # IAMF_decoder_get_last_metadata after configure and after every delivered frame
     try:
         pcm, rets = decode_stream(ref, stream, c["layout"], metadata=md, **F.decode_kwargs(c, variant))
     except AssertionError as e:   # configure / decode refused the stream: what it said is the golden
         return dict(error=str(e))
-    if not F.decode_kwargs(c, variant).get("out_rate"):
-        rets = rets[:-1]   # (the metadata run flushes a second time: decoder_driver.decode_stream; `rets` is the plain run's)
-    return dict(sha256=F.digest(pcm), shape=list(pcm.shape), rets=[int(r) for r in rets], meta=F.meta_digest(md["rows"]))
+    rets = rets[:-1]   # (the metadata run flushes a second time: decoder_driver.decode_stream; `rets` is the plain run's)
+    return dict(sha256=F.digest(pcm), shape=list(pcm.shape), rets=[int(r) for r in rets], meta=F.meta_digest(md))
 
 
 def one_blocks(seed):

@@ -27,7 +27,7 @@ N_SEEDS = 240
 # reference then takes the FIRST presentation with the best layout score (IAMF_decoder.c:2997-3111) and the loudness of the
 # best-scoring layout; sub-streams and parameter blocks of elements outside the chosen presentation are skipped
 VARIANTS = dict(default=(0, N_SEEDS), lfe=(100000, 120), tv=(200000, 120), wide=(300000, 240), multi=(400000, 160),
-                params=(500000, 200))
+                params=(500000, 200), concat=(600000, 120))
 STACKS = [[1, 3, 7], [0, 1, 2, 5], [1, 8], [2, 4], [3, 4], [8, 3, 6], [1, 2], [1, 2, 3, 4], [2, 3], [1, 5], [2, 5, 6, 7], [0, 1],
           [1, 8, 3, 7], [2, 7], [0, 1, 8, 3, 4], [1, 2, 5, 6], [5, 7], [8, 6], [1, 7], [0, 2]]
 WIDE_RATES = [(44100, 44100), (32000, 32000), (16000, 16000), (48000, 16000), (48000, 32000), (48000, 24000), (48000, 8000),
@@ -231,6 +231,22 @@ def case_params(seed):
 
 
 def build(seed, variant="default"):
+    if variant == "concat":
+        # two or three IA sequences back to back: the decoder answers IAMF_ERR_INVALID_STATE at each new sequence header and is
+        # configured again (iamfplayer.c:569-588,622-625; IAMF_decoder.c:2918-2921,3796-3806); the handle's settings are the
+        # first stream's, the descriptors (elements, presentations, frame size, sample format, rate) change under it
+        rng = np.random.default_rng(909000 + seed)
+        parts = [build(int(rng.integers(0, VARIANTS["wide"][1])), "wide") for _ in range(int(rng.integers(2, 4)))]
+        c = dict(parts[0][1])
+        if c.get("out_rate") and any(p[1].get("rate", 48000) != c.get("rate", 48000) for p in parts):
+            pass   # (a fixed output rate over sequences of different stream rates: the resampler is re-opened per sequence)
+        # slot 23 of H behind a resampler is stale memory in the reference (see case()): no scene-based element into H when any
+        # sequence is resampled
+        outr = c.get("out_rate") or 48000
+        if c["layout"] == ("ss", 7) and any(p[1].get("rate", 48000) != outr for p in parts) and \
+                any(k in SCENE for p in parts for k in p[1]["pair"]):   # (the first sequence's resampler serves the later ones too)
+            c["layout"] = ("ss", 9)
+        return b"".join(p[0] for p in parts), c
     if variant == "multi":
         return build_multi(seed)
     if variant == "params":
@@ -280,7 +296,7 @@ def events_digest(events):
     return hashlib.sha256(repr([(k, int(r), int(n)) for k, r, n in events]).encode()).hexdigest()
 
 
-def meta_digest(rows):
+def meta_digest(md):
     """the rows decoder_driver.last_metadata collected (pts, sound system, samples, bit depth, rate, sound mode, loudness
-    records, the DEMIXING record)"""
-    return hashlib.sha256(repr([[int(v) for v in r] for r in rows]).encode()).hexdigest()
+    records, the DEMIXING record) and the PCM of the second flush call"""
+    return hashlib.sha256(repr([[int(v) for v in r] for r in md["rows"]]).encode() + bytes(md.get("flush2", b""))).hexdigest()

@@ -19,12 +19,12 @@ variant = "default"
 if sys.argv[1] in F.VARIANTS:   # tools/debug/fuzz_dump.py lfe 3 17 ...
     variant = sys.argv.pop(1)
 from test_gpu_fuzz_facade import _Variant  # noqa: E402
-dlib = lib if variant in ("default", "wide", "multi", "params") else _Variant(lib, variant)
+dlib = lib if variant in ("default", "wide", "multi", "params", "concat") else _Variant(lib, variant)
 out = {"variant": np.array(variant)}
 for seed in [int(a) for a in sys.argv[1:]]:
     stream, c = F.build(seed, variant)
     try:
-        md = dict(rows=[], owns_anchors=True)
+        md = dict(rows=[], owns_anchors=True, strict=False)
         pcm, rets = decode_stream(dlib, stream, c["layout"], metadata=md, **F.decode_kwargs(c, variant))
         out["meta_%d" % seed] = np.array(md["rows"], dtype=np.int64)
         out["pcm_%d" % seed] = pcm
