@@ -229,6 +229,8 @@ struct IAMF_Decoder {
   float mix_loudness;
   iamf_hip_batch *batch, *batch3; /* batch3: limiter stage behind the resampler */
   iamf_hip_resampler *rs;
+  int need_cfg;     /* ctx->need_configure: bit 0 the output layout, bit 1 the mix presentation changed since the last configure */
+  int frame_channels0; /* channels of the layout the presentation was enabled with: the mixed frame's (setup_pipeline) */
   int rs_channels, reopen_rs; /* the channels `rs` was opened for; the next setup_pipeline re-opens it (TV layout switch) */
   Pre pre[2]; /* [0]: the stage in front of element 0 of `batch`; [1]: of element 1, in front of `aux` */
   /* Both elements need a stage: element 1 is rendered (stage, matrix, its mix gain) by a batch of its own into f32 and
@@ -1188,6 +1190,10 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   }
   d->out_gain_p = param_get(d, &p->out_gain_def, IAMF_PARAMETER_TYPE_MIX_GAIN);
   d->out_channels = d->out_type == IAMF_LAYOUT_TYPE_BINAURAL ? 2 : k_ss_channels[d->out_ss];
+  /* The mixed frame keeps the channel count of the layout the presentation was ENABLED with (pst->frame.channels,
+   * IAMF_decoder.c:3171); the -DSAMSUNG_TV layout switch does not touch it, and iamf_frame_gain applies the output mix
+   * gain to that many channels (:1383-1408,3462-3469): after a switch to a wider layout the channels beyond it go without. */
+  if (!d->frame_channels0) d->frame_channels0 = d->out_channels;
   /* IAMF_decoder.c:3189-3199: a new presentation TAKES the resampler of the one before it (iamf_presentation_take_resampler)
    * — its rates, its history, its phase — and opens one only if there was none and the rates differ.  A second IA sequence
    * on a handle that resampled the first one therefore goes on through the SAME resampler: no latency is skipped again,
@@ -1207,6 +1213,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
   cfg.frame_size = (int32_t)d->frame_size;
   cfg.sample_rate = (int32_t)d->rate;
   cfg.out_channels = d->out_channels;
+  cfg.out_gain_channels = d->frame_channels0 < d->out_channels ? d->frame_channels0 : 0;
   /* -DSAMSUNG_TV: every PCM frame is written with a 12-channel stride (IAMF_decoder.c:3492-3495) */
   d->pcm_stride = d->tv ? 12 : d->out_channels;
   d->pcm_extra = d->out_channels > d->pcm_stride ? d->out_channels - d->pcm_stride : 0;
@@ -1466,7 +1473,10 @@ int IAMF_decoder_configure(IAMF_DecoderHandle d, const uint8_t *data, uint32_t s
   }
   if (rsize) *rsize = pos;
   if (data && rsize && !saw_data) return IAMF_ERR_BUFFER_TOO_SMALL; /* IAMF_decoder.c:2778,3923-3930 */
-  if (!(data && size > 0) && d->configured && d->tv && !d->need_reconf) {
+  if (!(data && size > 0) && d->configured && !d->need_reconf && !d->need_cfg)
+    return IAMF_ERR_BAD_ARG; /* "Decoder need configure with descriptor obus": nothing was changed (IAMF_decoder.c:3883-3886) */
+  if (!(data && size > 0) && d->configured && d->tv && !d->need_reconf && d->need_cfg == 1) {
+    d->need_cfg = 0;
     /* The -DSAMSUNG_TV build's run-time output-layout switch (IAMF_decoder.c:3837-3881): configure without descriptors
      * after IAMF_decoder_output_layout_set_*.  The reference re-opens the RENDERERS (and the resampler) for the new
      * layout and re-initialises the limiter — its 240 delayed samples are gone, the next frame withholds 240 again —
@@ -1510,7 +1520,9 @@ int IAMF_decoder_configure(IAMF_DecoderHandle d, const uint8_t *data, uint32_t s
     }
     return rc;
   }
+  d->frame_channels0 = 0; /* the presentation is enabled anew: its mixed frame takes the layout's channel count */
   rc = setup_pipeline(d);
+  if (rc == IAMF_OK) d->need_cfg = 0;
   return rc;
 }
 
@@ -1984,20 +1996,28 @@ int iamf_hip_decoder_set_variant(void *handle, int variant) {
 }
 
 /* ---- setters / getters (IAMF_decoder.c:3948-4168) ---- */
+/* the three setters note a CHANGE (ctx->need_configure, IAMF_decoder.c:3943-3996): configure without data has something to
+ * do only then */
 int IAMF_decoder_set_mix_presentation_id(IAMF_DecoderHandle d, uint64_t id) {
   if (!d) return IAMF_ERR_BAD_ARG;
+  if (d->mix_id == (int64_t)id) return IAMF_OK;
   d->mix_id = (int64_t)id;
+  d->need_cfg |= 2;
   return IAMF_OK;
 }
 int IAMF_decoder_output_layout_set_sound_system(IAMF_DecoderHandle d, IAMF_SoundSystem ss) {
   if (!d || ss <= SOUND_SYSTEM_INVALID || ss >= SOUND_SYSTEM_END) return IAMF_ERR_BAD_ARG;
+  if (d->out_type == IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION && d->out_ss == ss) return IAMF_OK;
   d->out_type = IAMF_LAYOUT_TYPE_LOUDSPEAKERS_SS_CONVENTION;
   d->out_ss = ss;
+  d->need_cfg |= 1;
   return IAMF_OK;
 }
 int IAMF_decoder_output_layout_set_binaural(IAMF_DecoderHandle d) {
   if (!d) return IAMF_ERR_BAD_ARG;
+  if (d->out_type == IAMF_LAYOUT_TYPE_BINAURAL) return IAMF_OK;
   d->out_type = IAMF_LAYOUT_TYPE_BINAURAL;
+  d->need_cfg |= 1;
   return IAMF_OK;
 }
 int IAMF_layout_sound_system_channels_count(IAMF_SoundSystem ss) {

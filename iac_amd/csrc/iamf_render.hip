@@ -402,7 +402,7 @@ void launch_wide_m(const RenderParams &p, dim3 grid, hipStream_t st) {
 // The fast kernel takes aligned, limiter-on calls into 1- or 2-channel layouts; everything else
 // (odd sizes, flush, limiter off, wide layouts) goes to the generic kernel.  Both are exact.
 bool fast_path_ok(const RenderParams &p, bool down_mixer = false) {
-  if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
+  if (getenv("IAMF_HIP_FORCE_GENERIC") || p.og_ch < p.out_ch) return false;
   if (!p.limiter_on || !p.in || p.out_ch > 2 || p.n_end < kFWin) return false;
   if (p.pre_matrix || p.demix_on) return false;
   if (p.dmx_on && !(down_mixer && p.dmx_frames)) return false;
@@ -428,7 +428,7 @@ bool fast_path_ok(const RenderParams &p, bool down_mixer = false) {
 
 // The wide kernel: 3..24 output channels, limiter on, aligned calls.
 bool wide_path_ok(const RenderParams &p, int m, bool with_stage = false) {
-  if (getenv("IAMF_HIP_FORCE_GENERIC")) return false;
+  if (getenv("IAMF_HIP_FORCE_GENERIC") || p.og_ch < p.out_ch) return false;
   if (!p.limiter_on || !p.in || p.out_ch <= 2 || p.out_ch > kMaxOut || p.n_end < kWWin) return false;
   if (p.pre_matrix) return false;
   const bool mixing = p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp;
@@ -664,6 +664,7 @@ int render_call(iamf_hip_batch *b, const iamf_hip_render_args &a, int total, int
   p.n_streams = b->cfg.n_streams;
   p.n_feeds = b->n_feeds;
   p.out_ch = b->cfg.out_channels;
+  p.og_ch = (b->cfg.out_gain_channels > 0 && b->cfg.out_gain_channels < b->cfg.out_channels) ? b->cfg.out_gain_channels : b->cfg.out_channels;
   p.out_format = b->cfg.out_format;
   p.limiter_on = b->cfg.limiter_enable ? 1 : 0;
   p.loudness_on = b->cfg.loudness_enable ? 1 : 0;
@@ -911,7 +912,7 @@ int iamf_hip_batch_create(const iamf_hip_batch_config *cfg, iamf_hip_batch **out
   if (cfg->n_streams <= 0 || cfg->frame_size <= 0 || cfg->sample_rate <= 0 || (!dmx && !mx.mat) ||
       mx.m <= 0 || mx.m > kMaxIn || mx.n <= 0 || mx.n > kMaxOut || cfg->out_channels <= 0 ||
       cfg->out_channels > kMaxOut || !iamf_hip_format_bytes(cfg->out_format) || cfg->projection < 0 ||
-      cfg->projection > IAMF_HIP_PROJ_MFMA || (dmx && cfg->out_channels != mx.n) || cfg->pcm_stride_channels < 0 ||
+      cfg->projection > IAMF_HIP_PROJ_MFMA || (dmx && cfg->out_channels != mx.n) || cfg->pcm_stride_channels < 0 || cfg->out_gain_channels < 0 ||
       cfg->pcm_stride_channels > 64)
     return IAMF_HIP_ERR_BAD_ARG;
   int ndev = 0;

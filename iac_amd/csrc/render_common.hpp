@@ -116,6 +116,7 @@ struct RenderParams {
   // ---- HOA LFE generator (render_lfe.hpp): raw low-pass output of this call or nullptr ----
   const float *lfe;         // device, transposed by blocks of 64 streams: element lfe_index(s, k, lfe_t4) (render_lfe.hpp)
   int32_t lfe_t4;           // quads per stream in that buffer
+  int32_t og_ch;            // output channels the OUTPUT gain multiplies (iamf_hip_batch_config::out_gain_channels; = out_ch: all)
   int32_t lfe_k0;           // the generator's output of the call's first sample sits at index lfe_k0 (trimmed frames: the
                             // filter also ran over the lfe_k0 samples cut off in front, iamf_hip_render_args)
   double lfe_div;           // sqrt(n) of h2m_rdr.c:1162; 0 = the `* 0.5` form (n <= 2)

@@ -247,10 +247,12 @@ __global__ __launch_bounds__(kChunk) void render_kernel(const RenderParams p) {
         }
         y = y + y2;
       }
-      if (p.out_ramp) {
-        y = y * orr;
-      } else if (og_on) {
-        y = y * og;
+      if (c < p.og_ch) {   // (all channels, unless the batch was told otherwise: RenderParams::og_ch)
+        if (p.out_ramp) {
+          y = y * orr;
+        } else if (og_on) {
+          y = y * og;
+        }
       }
       if (lg_on) y = y * lg;
       if (valid) ring_y[c * kRing + rp] = y;

@@ -36,7 +36,7 @@ class BatchConfig(C.Structure):
                 ("out_channels", C.c_int32), ("out_format", C.c_int32), ("matrix", Matrix),
                 ("limiter_enable", C.c_int32), ("limiter_threshold_db", C.c_float),
                 ("loudness_enable", C.c_int32), ("projection", C.c_int32), ("fir_taps", C.c_int32), ("lfe_hoa", C.c_int32),
-                ("pcm_stride_channels", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("pcm_stride_channels", C.c_int32), ("out_gain_channels", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class DmxState(C.Structure):

@@ -134,7 +134,12 @@ typedef struct {
                               channels overwrite the following sample-frame exactly as the reference's loop
                               does.  A stream then needs (n * stride + max(0, out_channels - stride)) samples
                               of room per call. */
-  int32_t reserved[3];
+  /* 0, or K < out_channels: the OUTPUT mix gain (constant or ramp) multiplies output channels 0 .. K-1 only.  What the
+   * reference's -DSAMSUNG_TV build does after a run-time switch to a layout of more channels: its mixed frame keeps the
+   * channel count of the layout the presentation was enabled with, and iamf_frame_gain loops over that
+   * (IAMF_decoder.c:1383-1408,3462-3469).  Such a batch renders through the general kernel. */
+  int32_t out_gain_channels;
+  int32_t reserved[2];
 } iamf_hip_batch_config;
 
 /* Creates device state for cfg->n_streams streams on the CURRENT HIP device.  Synchronous.

@@ -45,7 +45,25 @@ def one_blocks(seed):
                 last=[list(e) for e in events[-2:]])
 
 
+def one_switch(seed):
+    import numpy as np
+    from decoder_driver import decode_stream_switching
+    vs, lays, after = F.switch_case(seed)
+    ref = C.CDLL(os.path.join(HERE, *REF["tv"]))
+    stream, c = F.build(vs, "tv")
+    kw = F.decode_kwargs(c, "tv")
+    try:
+        chunks, rets = decode_stream_switching(ref, stream, lays, after, **kw)
+    except AssertionError as e:
+        return dict(error=str(e))
+    pcm = np.concatenate(chunks, axis=0) if chunks else np.zeros((0, 12), np.int16)
+    return dict(sha256=F.digest(pcm), shape=list(pcm.shape), rets=[list(r) if isinstance(r, tuple) else int(r) for r in rets])
+
+
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--switch":
+        print(json.dumps(one_switch(int(sys.argv[2]))))
+        return
     if len(sys.argv) >= 3 and sys.argv[1] == "--blocks":
         print(json.dumps(one_blocks(int(sys.argv[2]))))
         return
@@ -68,6 +86,15 @@ def main():
             json.dump(out, f, indent=0, sort_keys=True)
         print("fuzz goldens (%s) written:" % variant, sum("sha256" in v for v in out.values()), "decoded,",
               sum("error" in v for v in out.values()), "refused,", sum("crash" in v for v in out.values()), "crashed")
+    out = {}
+    for seed in range(F.N_SWITCH):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--switch", str(seed)], capture_output=True, text=True)
+        out[str(seed)] = dict(crash=r.returncode) if r.returncode else json.loads(r.stdout.strip().splitlines()[-1])
+        print("  fuzz switch %3d %s -> %s" % (seed, F.switch_case(seed), out[str(seed)].get("shape") or out[str(seed)]))
+    with open(os.path.join(ROOT, "tests", "golden", "fuzz_switch.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("fuzz goldens (switch) written:", sum("sha256" in v for v in out.values()), "decoded,",
+          sum("error" in v for v in out.values()), "refused,", sum("crash" in v for v in out.values()), "crashed")
     out = {}
     for seed in range(F.N_BLOCKS):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--blocks", str(seed)], capture_output=True, text=True)

@@ -164,7 +164,8 @@ def decode_stream(ref, stream_bytes, layout, bit_depth=16, out_rate=0, loudness=
     return out.copy(), rets
 
 
-def decode_stream_switching(ref, stream_bytes, layouts, switch_after, bit_depth=16, pcm_channels=12):
+def decode_stream_switching(ref, stream_bytes, layouts, switch_after, bit_depth=16, pcm_channels=12, out_rate=0, loudness=0.0,
+                            limiter=True, threshold=-1.0):
     """As decode_stream, but the output layout is changed while decoding: after `switch_after[i]` decode calls that
     returned a frame, IAMF_decoder_output_layout_set_* (layouts[i + 1]) + IAMF_decoder_configure(h, NULL, 0, NULL) — the
     run-time switch of the reference's -DSAMSUNG_TV build (IAMF_decoder.c:3819-3881).  Returns (list of per-call PCM
@@ -185,6 +186,18 @@ def decode_stream_switching(ref, stream_bytes, layouts, switch_after, bit_depth=
 
     d = ref.IAMF_decoder_open()
     ref.IAMF_decoder_set_bit_depth(d, bit_depth)
+    if out_rate or loudness != 0.0 or not limiter or threshold != -1.0:   # (the fuzz; the stored goldens use the defaults)
+        ref.IAMF_decoder_set_normalization_loudness.argtypes = [C.c_void_p, C.c_float]
+        ref.IAMF_decoder_peak_limiter_enable.argtypes = [C.c_void_p, C.c_uint32]
+        ref.IAMF_decoder_peak_limiter_set_threshold.argtypes = [C.c_void_p, C.c_float]
+        ref.IAMF_decoder_set_sampling_rate.argtypes = [C.c_void_p, C.c_uint32]
+        if not limiter:
+            ref.IAMF_decoder_peak_limiter_enable(d, 0)
+        else:
+            ref.IAMF_decoder_peak_limiter_set_threshold(d, threshold)
+        ref.IAMF_decoder_set_normalization_loudness(d, loudness)
+        if out_rate:
+            assert ref.IAMF_decoder_set_sampling_rate(d, out_rate) == 0
     set_layout(d, layouts[0])
     ref.IAMF_decoder_set_pts(d, 0, 90000)
     rsize = C.c_uint32(0)
@@ -194,7 +207,9 @@ def decode_stream_switching(ref, stream_bytes, layouts, switch_after, bit_depth=
     ch = pcm_channels
     pcm = C.create_string_buffer(bps * 6144 * 6 * 24)
     chunks, rets, frames, li = [], [], 0, 0
-    dt = {16: np.int16, 32: np.int32}[bit_depth]
+    dt = {16: np.int16, 32: np.int32, 24: np.uint8}[bit_depth]
+    if bit_depth == 24:
+        ch, bps = 3 * pcm_channels, 1   # bytes: [n][channels * 3]
     while used < len(stream_bytes):
         rsize.value = 0
         rest = stream_bytes[used:]

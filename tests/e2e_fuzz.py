@@ -300,3 +300,22 @@ def meta_digest(md):
     """the rows decoder_driver.last_metadata collected (pts, sound system, samples, bit depth, rate, sound mode, loudness
     records, the DEMIXING record) and the PCM of the second flush call"""
     return hashlib.sha256(repr([[int(v) for v in r] for r in md["rows"]]).encode() + bytes(md.get("flush2", b""))).hexdigest()
+
+
+# The -DSAMSUNG_TV build's run-time layout switch (IAMF_decoder.c:3819-3881) on the TV set's streams: one or two switches to
+# random layouts after random numbers of delivered frames (decoder_driver.decode_stream_switching)
+N_SWITCH = 120
+
+
+def switch_case(seed):
+    """-> (seed of the tv variant, layouts in turn, frames delivered before each switch)"""
+    rng = np.random.default_rng(957000 + seed)
+    vs = int(rng.integers(0, VARIANTS["tv"][1]))
+    c = case(vs, "tv")
+    lays = [c["layout"]]
+    for _ in range(int(rng.integers(1, 3))):
+        k = int(rng.integers(0, 14))
+        lays.append(("binaural",) if k == 13 else ("ss", k))
+    nfr = max(2, c["frames"] - 1)
+    after = sorted(int(v) for v in rng.choice(np.arange(1, nfr + 1), size=min(len(lays) - 1, nfr), replace=False))
+    return vs, lays[:len(after) + 1], after

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import e2e_fuzz as F
-from decoder_driver import decode_stream, decode_stream_blocks
+from decoder_driver import decode_stream, decode_stream_blocks, decode_stream_switching
 
 pytestmark = pytest.mark.gpu
 
@@ -173,3 +173,29 @@ def test_random_multi_and_params_streams_through_a_group_of_handles(lib, variant
     for i, (pcm, rets) in enumerate(outs):
         assert [int(r) for r in rets] == want["rets"], (variant, seed, i)
         assert F.digest(pcm) == want["sha256"], (variant, seed, i)
+
+
+GOLD_S = json.load(open(os.path.join(_G, "fuzz_switch.json")))
+
+
+@pytest.mark.parametrize("seed", range(F.N_SWITCH))
+def test_random_tv_stream_with_run_time_layout_switches(lib, seed):
+    """the -DSAMSUNG_TV build's run-time layout switch (IAMF_decoder_output_layout_set_* + IAMF_decoder_configure(h, NULL, 0,
+    NULL), IAMF_decoder.c:3819-3881) once or twice per stream, after random numbers of delivered frames, to random layouts:
+    renderers, limiter and resampler re-opened, decoders, demixers and parameter clocks living on.  PCM and every return
+    value (the configure calls' too) against the reference built that way; the streams it dies on are decoded only."""
+    import numpy as np
+    want = GOLD_S[str(seed)]
+    vs, lays, after = F.switch_case(seed)
+    stream, c = F.build(vs, "tv")
+    try:
+        chunks, rets = decode_stream_switching(_Variant(lib, "tv"), stream, lays, after, **F.decode_kwargs(c, "tv"))
+    except AssertionError as e:
+        assert want.get("error") == str(e), (seed, vs, lays, after, str(e), want)
+        return
+    if "sha256" not in want:
+        return
+    pcm = np.concatenate(chunks, axis=0) if chunks else np.zeros((0, 12), np.int16)
+    got = [list(r) if isinstance(r, tuple) else int(r) for r in rets]
+    assert got == want["rets"], (seed, vs, lays, after)
+    assert list(pcm.shape) == want["shape"] and F.digest(pcm) == want["sha256"], (seed, vs, lays, after)
