@@ -27,7 +27,7 @@ N_SEEDS = 240
 # reference then takes the FIRST presentation with the best layout score (IAMF_decoder.c:2997-3111) and the loudness of the
 # best-scoring layout; sub-streams and parameter blocks of elements outside the chosen presentation are skipped
 VARIANTS = dict(default=(0, N_SEEDS), lfe=(100000, 120), tv=(200000, 120), wide=(300000, 240), multi=(400000, 160),
-                params=(500000, 200), concat=(600000, 120))
+                params=(500000, 200), concat=(600000, 120), syntax=(700000, 200))
 STACKS = [[1, 3, 7], [0, 1, 2, 5], [1, 8], [2, 4], [3, 4], [8, 3, 6], [1, 2], [1, 2, 3, 4], [2, 3], [1, 5], [2, 5, 6, 7], [0, 1],
           [1, 8, 3, 7], [2, 7], [0, 1, 8, 3, 4], [1, 2, 5, 6], [5, 7], [8, 6], [1, 7], [0, 2]]
 WIDE_RATES = [(44100, 44100), (32000, 32000), (16000, 16000), (48000, 16000), (48000, 32000), (48000, 24000), (48000, 8000),
@@ -230,7 +230,113 @@ def case_params(seed):
     return c
 
 
+def _leb(v, pad=0):
+    """leb128 of v in len(minimal) + pad bytes (a non-minimal encoding is legal: bitstream.c:136-157 reads up to 8 bytes)"""
+    out = []
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            break
+    for _ in range(pad):
+        out[-1] |= 0x80
+        out.append(0)
+    return bytes(out)
+
+
+def _split_obus(stream):
+    """[(type, redundant, trimming, extension, payload incl. trim / extension fields)]"""
+    out, pos = [], 0
+    while pos < len(stream):
+        h = stream[pos]
+        pos += 1
+        size, shift = 0, 0
+        while True:
+            b = stream[pos]
+            pos += 1
+            size |= (b & 0x7F) << shift
+            shift += 7
+            if not b & 0x80:
+                break
+        out.append([h >> 3, (h >> 2) & 1, (h >> 1) & 1, h & 1, stream[pos:pos + size]])
+        pos += size
+    return out
+
+
+def build_syntax(seed):
+    """a stream of the default / wide sets rewritten OBU by OBU into other legal spellings of the same content: non-minimal
+    leb128 sizes, OBU extension headers, reserved OBU types and parameter blocks of unknown ids in between, temporal
+    delimiters dropped, the audio frames of a temporal unit in another order, redundant copies of descriptors in the
+    middle of the data, a redundant copy of the sequence header"""
+    rng = np.random.default_rng(911000 + seed)
+    src = ("default", "wide")[seed & 1]
+    stream, c = build(int(rng.integers(0, VARIANTS[src][1])), src)
+    obus = _split_obus(stream)
+    opts = dict(pad=rng.random() < 0.5, ext=rng.random() < 0.4, junk=rng.random() < 0.5, unknown_pb=rng.random() < 0.4,
+                drop_td=rng.random() < 0.3, shuffle=rng.random() < 0.5, redundant=rng.random() < 0.4)
+    descriptors = [o for o in obus if o[0] in (31, 0, 1, 2)]
+    out = bytearray()
+
+    def emit(t, red, trim, payload, allow_ext=True):
+        ext = 1 if (allow_ext and opts["ext"] and rng.random() < 0.3) else 0
+        body = bytes(payload)
+        if ext:   # obu_extension_flag: extension_header_size + bytes, behind the trimming fields (IAMF_OBU.c:99-123)
+            e = bytes(int(v) for v in rng.integers(0, 256, size=int(rng.integers(0, 6))))
+            if trim:   # the two trim leb128s come first
+                p = 0
+                for _ in range(2):
+                    while body[p] & 0x80:
+                        p += 1
+                    p += 1
+                body = body[:p] + _leb(len(e)) + e + body[p:]
+            else:
+                body = _leb(len(e)) + e + body
+        hdr = (t << 3) | (red << 2) | (trim << 1) | ext
+        out.extend(bytes([hdr]) + _leb(len(body), int(rng.integers(0, 3)) if opts["pad"] else 0) + body)
+
+    tu = []   # the audio frames of the temporal unit being collected
+
+    def flush_tu():
+        if opts["shuffle"] and len(tu) > 1:
+            order = rng.permutation(len(tu))
+            for i in order:
+                emit(*tu[int(i)])
+        else:
+            for o in tu:
+                emit(*o)
+        tu.clear()
+
+    in_data = False
+    for t, red, trim, ext, payload in obus:
+        is_frame = 5 <= t <= 23
+        if not is_frame:
+            flush_tu()
+        if t == 4:
+            in_data = True
+            if opts["redundant"] and rng.random() < 0.3:   # a redundant copy of every descriptor, and of the sequence header
+                for d in descriptors:
+                    emit(d[0], 1, 0, d[4], allow_ext=False)
+            if opts["drop_td"] and rng.random() < 0.5:
+                continue
+        if opts["junk"] and rng.random() < 0.2:
+            emit(int(rng.integers(24, 31)), 0, 0, bytes(int(v) for v in rng.integers(0, 256, size=int(rng.integers(0, 40)))), allow_ext=False)
+        if opts["unknown_pb"] and in_data and rng.random() < 0.15:
+            emit(3, 0, 0, _leb(int(rng.integers(5000, 6000))) + bytes(int(v) for v in rng.integers(0, 256, size=int(rng.integers(0, 12)))), allow_ext=False)
+        if is_frame:
+            tu.append((t, red, trim, payload))
+        else:
+            emit(t, red, trim, payload, allow_ext=t not in (31,))
+    flush_tu()
+    c = dict(c, syntax=opts, source=src)
+    return bytes(out), c
+
+
 def build(seed, variant="default"):
+    if variant == "syntax":
+        return build_syntax(seed)
     if variant == "concat":
         # two or three IA sequences back to back: the decoder answers IAMF_ERR_INVALID_STATE at each new sequence header and is
         # configured again (iamfplayer.c:569-588,622-625; IAMF_decoder.c:2918-2921,3796-3806); the handle's settings are the

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 _G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLD = json.load(open(os.path.join(_G, "fuzz.json")))
-GOLD_V = {v: json.load(open(os.path.join(_G, "fuzz_%s.json" % v))) for v in ("lfe", "tv", "wide", "multi", "params", "concat")}
+GOLD_V = {v: json.load(open(os.path.join(_G, "fuzz_%s.json" % v))) for v in ("lfe", "tv", "wide", "multi", "params", "concat", "syntax")}
 
 
 from test_gpu_group import group_decode_all, lib  # noqa: E402,F401  (the fixture that declares the group entry points)
@@ -71,7 +71,7 @@ class _Variant:
         return open_
 
 
-@pytest.mark.parametrize("variant,seed", [(v, s) for v in ("lfe", "tv", "wide", "multi", "params", "concat") for s in range(F.VARIANTS[v][1])])
+@pytest.mark.parametrize("variant,seed", [(v, s) for v in ("lfe", "tv", "wide", "multi", "params", "concat", "syntax") for s in range(F.VARIANTS[v][1])])
 def test_random_stream_matches_the_other_builds_of_the_reference(lib, variant, seed):
     """the same generator against the reference built -DDISABLE_LFE_HOA=0 (scene-based elements three times as likely: one or
     two of them through the LFE generator, beside channel-based ones, behind the resampler) and -DSAMSUNG_TV (its own layout
@@ -88,15 +88,28 @@ def test_random_stream_matches_the_other_builds_of_the_reference(lib, variant, s
     three IA sequences of the wide set back to back on one handle — IAMF_ERR_INVALID_STATE at each new sequence header,
     configured again (IAMF_decoder.c:2918-2921,3796-3806); the reference hands the FIRST sequence's resampler on to the
     later ones (iamf_presentation_take_resampler, :3189-3199: no latency skipped again, the first ratio stays) and dies on
-    one stream in nine (that resampler's buffer is sized for the first sequence's frames): those are decoded, not compared."""
+    one stream in nine (that resampler's buffer is sized for the first sequence's frames): those are decoded, not compared.
+    And "syntax": streams of the default and wide sets rewritten OBU by OBU — non-minimal leb128 sizes, OBU extension headers,
+    reserved OBU types and parameter blocks of unknown ids in between, temporal delimiters dropped, the audio frames of a
+    unit in another order, redundant copies of the descriptors in the middle of the data.  Where the reference refuses a
+    spelling (a reserved OBU or an extension inside the descriptors: IAMF_ERR_BUFFER_TOO_SMALL from configure), the facade
+    must refuse it with the same code."""
     want = GOLD_V[variant][str(seed)]
     stream, c = F.build(seed, variant)
-    dlib = lib if variant in ("wide", "multi", "params", "concat") else _Variant(lib, variant)
+    dlib = lib if variant in ("wide", "multi", "params", "concat", "syntax") else _Variant(lib, variant)
     md = dict(rows=[], owns_anchors=True, strict=False)
-    pcm, rets = decode_stream(dlib, stream, c["layout"], metadata=md, **F.decode_kwargs(c, variant))
-    if "crash" in want:
-        assert len(pcm) > 0
+    if "error" in want and variant == "syntax":   # the reference refused this spelling: so must the facade, with the same code
+        with pytest.raises(AssertionError) as ei:
+            decode_stream(dlib, stream, c["layout"], metadata=md, **F.decode_kwargs(c, variant))
+        assert str(ei.value) == want["error"], (variant, seed, c.get("syntax"))
         return
+    if "crash" in want:   # the reference dies on this stream: nothing to compare; here it is decoded or refused, not fatal
+        try:
+            decode_stream(dlib, stream, c["layout"], metadata=md, **F.decode_kwargs(c, variant))
+        except AssertionError:
+            pass
+        return
+    pcm, rets = decode_stream(dlib, stream, c["layout"], metadata=md, **F.decode_kwargs(c, variant))
     if "error" in want:   # (the reference refused the stream with a decode error after a reconfiguration)
         return
     assert "sha256" in want, want

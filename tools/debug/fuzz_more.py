@@ -17,12 +17,23 @@ lib = C.CDLL(iac_amd.lib_path())
 variant = sys.argv[1] if len(sys.argv) > 1 else "default"
 gold = json.load(open(os.path.join(ROOT, "tests", "golden_tmp", "fuzz_more_%s.json" % variant)))["gold"]
 from test_gpu_fuzz_facade import _Variant  # noqa: E402
-dlib = lib if variant in ("default", "wide", "multi", "params", "concat") else _Variant(lib, variant)
+dlib = lib if variant in ("default", "wide", "multi", "params", "concat", "syntax") else _Variant(lib, variant)
 bad = []
 for k in sorted(gold, key=int):
     seed = int(k)
     if "sha256" not in gold[k]:
-        print(seed, "reference:", gold[k])
+        if "error" in gold[k]:   # the reference refused the stream: the facade must refuse it the same way
+            stream, c = F.build(seed, variant)
+            try:
+                decode_stream(dlib, stream, c["layout"], **F.decode_kwargs(c, variant))
+                got = "decoded"
+            except AssertionError as e:
+                got = str(e)
+            if got != gold[k]["error"]:
+                bad.append(seed)
+                print(seed, "reference error:", gold[k]["error"], "| facade:", got, {x: c[x] for x in ("syntax",) if x in c}, flush=True)
+        else:
+            print(seed, "reference:", gold[k])
         continue
     stream, c = F.build(seed, variant)
     try:
@@ -33,5 +44,5 @@ for k in sorted(gold, key=int):
         ok, why = False, str(e)
     if not ok:
         bad.append(seed)
-        print(seed, why, {x: c[x] for x in ("elements", "presentations", "mix_id", "pair", "layout", "fs", "frames", "bit_depth", "sample_size", "trims", "rate", "out_rate", "loudness", "limiter", "threshold", "pair_ramps") if x in c}, flush=True)
+        print(seed, why, {x: c[x] for x in ("syntax", "elements", "presentations", "mix_id", "pair", "layout", "fs", "frames", "bit_depth", "sample_size", "trims", "rate", "out_rate", "loudness", "limiter", "threshold", "pair_ramps") if x in c}, flush=True)
 print("checked", len(gold), "bad", bad)
