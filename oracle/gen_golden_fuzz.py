@@ -20,7 +20,7 @@ from decoder_driver import decode_stream  # noqa: E402
 
 
 REF = dict(default=("_ref", "libiamf_ref.so"), lfe=("_ref_lfe", "libiamf_ref_lfe.so"), tv=("_ref_tv", "libiamf_ref_tv.so"),
-           wide=("_ref", "libiamf_ref.so"), multi=("_ref", "libiamf_ref.so"), params=("_ref", "libiamf_ref.so"), concat=("_ref", "libiamf_ref.so"), syntax=("_ref", "libiamf_ref.so"))
+           wide=("_ref", "libiamf_ref.so"), multi=("_ref", "libiamf_ref.so"), params=("_ref", "libiamf_ref.so"), concat=("_ref", "libiamf_ref.so"), syntax=("_ref", "libiamf_ref.so"), dparams=("_ref", "libiamf_ref.so"))
 
 
 def one(seed, variant):

@@ -231,6 +231,15 @@ def _toa_element(eid, x, first_sid, sample_size):
     return desc, xq
 
 
+def _block_keep(c, pid0):
+    """c["drop_blocks"] = (seed, probability): the demixing (k = 0) / recon-gain (k = 1) block of a frame is left out with
+    that probability (the decoder then goes on with the mode / the gains it has)"""
+    if not c.get("drop_blocks"):
+        return lambda f, k: True
+    sd, prob = c["drop_blocks"]
+    return lambda f, k: np.random.default_rng(sd * 1000003 + pid0 * 131 + f * 2 + k).random() >= prob
+
+
 # ---- one element of a two-element presentation: descriptor, per-frame (parameter blocks, sub-streams), what the renderer sees ----
 def _pair_element(kind, eid, sid0, pid0, seed, n, fs, ss, rate, c):
     """returns (descriptor obus, frame -> (parameter block obus, [(sub-stream id, bytes)]), info element, sub-streams used)"""
@@ -266,7 +275,8 @@ def _pair_element(kind, eid, sid0, pid0, seed, n, fs, ss, rate, c):
         nsub = W.LAYOUT_SUBSTREAMS[lay][0]
         desc = W.audio_element_channel(eid, 0, lay, list(range(sid0, sid0 + nsub)),
                                        demixing=dict(pid=pid0, rate=rate, frame=fs, mode=dmode, w=dw))
-        return (desc, lambda f: (W.demixing_block(pid0, dmx_modes[f]),
+        keep = _block_keep(c, pid0)
+        return (desc, lambda f: (W.demixing_block(pid0, dmx_modes[f]) if keep(f, 0) else b"",
                                  W.channel_element_substreams(lay, x_al[:, f * fs:(f + 1) * fs], sid0, ss)),
                 dict(kind="channel", layout=lay, x=xq), nsub)
     if kind == "scalable":
@@ -287,10 +297,13 @@ def _pair_element(kind, eid, sid0, pid0, seed, n, fs, ss, rate, c):
                                         demixing=dict(pid=pid0, rate=rate, frame=fs, mode=dmode, w=dw),
                                         recon=dict(pid=pid0 + 1, rate=rate, frame=fs))
 
+        keep = _block_keep(c, pid0)
+
         def frame(f):
-            blocks = W.demixing_block(pid0, sc_modes[f])
-            blocks += W.recon_gain_block(pid0 + 1, [(l["recon_flags"], scalable_recon_bytes(f, bin(l["recon_flags"]).count("1"), salt))
-                                                    for l in wl if l["recon"]])
+            blocks = W.demixing_block(pid0, sc_modes[f]) if keep(f, 0) else b""
+            if keep(f, 1):
+                blocks += W.recon_gain_block(pid0 + 1, [(l["recon_flags"], scalable_recon_bytes(f, bin(l["recon_flags"]).count("1"), salt))
+                                                        for l in wl if l["recon"]])
             subs, ch, sid = [], 0, sid0
             for l in wl:
                 for k in range(l["nsub"]):

@@ -27,7 +27,7 @@ N_SEEDS = 240
 # reference then takes the FIRST presentation with the best layout score (IAMF_decoder.c:2997-3111) and the loudness of the
 # best-scoring layout; sub-streams and parameter blocks of elements outside the chosen presentation are skipped
 VARIANTS = dict(default=(0, N_SEEDS), lfe=(100000, 120), tv=(200000, 120), wide=(300000, 240), multi=(400000, 160),
-                params=(500000, 200), concat=(600000, 120), syntax=(700000, 200))
+                params=(500000, 200), concat=(600000, 120), syntax=(700000, 200), dparams=(800000, 160))
 STACKS = [[1, 3, 7], [0, 1, 2, 5], [1, 8], [2, 4], [3, 4], [8, 3, 6], [1, 2], [1, 2, 3, 4], [2, 3], [1, 5], [2, 5, 6, 7], [0, 1],
           [1, 8, 3, 7], [2, 7], [0, 1, 8, 3, 4], [1, 2, 5, 6], [5, 7], [8, 6], [1, 7], [0, 2]]
 WIDE_RATES = [(44100, 44100), (32000, 32000), (16000, 16000), (48000, 16000), (48000, 32000), (48000, 24000), (48000, 8000),
@@ -80,6 +80,22 @@ def case(seed, variant="default"):
         c["limiter"] = False
     elif rng.random() < 0.3:
         c["threshold"] = float(pick([-3.0, -6.0, -0.5]))
+    if variant == "dparams":   # scalable / demixing-info elements whose demixing and recon-gain blocks are missing for some frames
+        kinds2 = ["scalable"] * 5 + ["dmx:%d" % l for l in (2, 3, 4, 5, 6, 7, 8)] + ["l714dmx"] * 2 + ["stereo", "toa"]
+        c["pair"] = pair = tuple(pick(kinds2) for _ in pair)
+        for k in ("1", "2"):
+            st = pick(STACKS)
+            c["scalable_layers" + k] = st
+            c["scalable_gains" + k] = {int(li): (int(rng.integers(1, 64)), int(rng.integers(-1200, 600)))
+                                       for li in range(len(st)) if rng.random() < 0.4}
+            c["dmx_default" + k] = (pick(MODES), int(rng.integers(0, 11)))
+        c["drop_blocks"] = (int(rng.integers(1, 1 << 30)), float(pick([0.15, 0.3, 0.6, 1.0])))
+        if layout == ("ss", 7) and any(k in SCENE for k in pair):   # (slot 23 of H behind the resampler: see above)
+            c.pop("rate", None), c.pop("out_rate", None)
+        if c["fs"] < 512:
+            c["fs"] = fs = 1024
+            c["frames"] = frames = int(rng.integers(4, 9))
+            c.pop("trims", None)
     if variant == "wide":
         kinds2 = KINDS + ["scalable"] * 4 + ["dmx:%d" % l for l in (2, 3, 4, 5, 6, 7, 8, 1)]
         pair = tuple(pick(kinds2) for _ in pair)

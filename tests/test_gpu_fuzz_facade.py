@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 _G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLD = json.load(open(os.path.join(_G, "fuzz.json")))
-GOLD_V = {v: json.load(open(os.path.join(_G, "fuzz_%s.json" % v))) for v in ("lfe", "tv", "wide", "multi", "params", "concat", "syntax")}
+GOLD_V = {v: json.load(open(os.path.join(_G, "fuzz_%s.json" % v))) for v in ("lfe", "tv", "wide", "multi", "params", "concat", "syntax", "dparams")}
 
 
 from test_gpu_group import group_decode_all, lib  # noqa: E402,F401  (the fixture that declares the group entry points)
@@ -71,7 +71,7 @@ class _Variant:
         return open_
 
 
-@pytest.mark.parametrize("variant,seed", [(v, s) for v in ("lfe", "tv", "wide", "multi", "params", "concat", "syntax") for s in range(F.VARIANTS[v][1])])
+@pytest.mark.parametrize("variant,seed", [(v, s) for v in ("lfe", "tv", "wide", "multi", "params", "concat", "syntax", "dparams") for s in range(F.VARIANTS[v][1])])
 def test_random_stream_matches_the_other_builds_of_the_reference(lib, variant, seed):
     """the same generator against the reference built -DDISABLE_LFE_HOA=0 (scene-based elements three times as likely: one or
     two of them through the LFE generator, beside channel-based ones, behind the resampler) and -DSAMSUNG_TV (its own layout
@@ -93,10 +93,11 @@ def test_random_stream_matches_the_other_builds_of_the_reference(lib, variant, s
     reserved OBU types and parameter blocks of unknown ids in between, temporal delimiters dropped, the audio frames of a
     unit in another order, redundant copies of the descriptors in the middle of the data.  Where the reference refuses a
     spelling (a reserved OBU or an extension inside the descriptors: IAMF_ERR_BUFFER_TOO_SMALL from configure), the facade
-    must refuse it with the same code."""
+    must refuse it with the same code.  And "dparams": scalable and demixing-info elements whose demixing and recon-gain
+    parameter blocks are missing for 15 % to all of the frames (the decoder goes on with the mode and gains it has)."""
     want = GOLD_V[variant][str(seed)]
     stream, c = F.build(seed, variant)
-    dlib = lib if variant in ("wide", "multi", "params", "concat", "syntax") else _Variant(lib, variant)
+    dlib = lib if variant in ("wide", "multi", "params", "concat", "syntax", "dparams") else _Variant(lib, variant)
     md = dict(rows=[], owns_anchors=True, strict=False)
     if "error" in want and variant == "syntax":   # the reference refused this spelling: so must the facade, with the same code
         with pytest.raises(AssertionError) as ei:

@@ -14,7 +14,7 @@ from decoder_driver import decode_stream  # noqa: E402
 d = np.load(os.path.join(ROOT, "gpurun_out", "fuzz_dump.npz"))
 variant = str(d["variant"]) if "variant" in d.files else "default"
 REF = dict(default=("_ref", "libiamf_ref.so"), lfe=("_ref_lfe", "libiamf_ref_lfe.so"), tv=("_ref_tv", "libiamf_ref_tv.so"),
-           wide=("_ref", "libiamf_ref.so"), multi=("_ref", "libiamf_ref.so"), params=("_ref", "libiamf_ref.so"), concat=("_ref", "libiamf_ref.so"), syntax=("_ref", "libiamf_ref.so"))
+           wide=("_ref", "libiamf_ref.so"), multi=("_ref", "libiamf_ref.so"), params=("_ref", "libiamf_ref.so"), concat=("_ref", "libiamf_ref.so"), syntax=("_ref", "libiamf_ref.so"), dparams=("_ref", "libiamf_ref.so"))
 ref = C.CDLL(os.path.join(ROOT, "oracle", *REF[variant]))
 for k in sorted([x for x in d.files if x != "variant"], key=lambda s: int(s.split("_")[1])):
     if not k.startswith("pcm_"):

@@ -19,7 +19,7 @@ variant = "default"
 if sys.argv[1] in F.VARIANTS:   # tools/debug/fuzz_dump.py lfe 3 17 ...
     variant = sys.argv.pop(1)
 from test_gpu_fuzz_facade import _Variant  # noqa: E402
-dlib = lib if variant in ("default", "wide", "multi", "params", "concat", "syntax") else _Variant(lib, variant)
+dlib = lib if variant in ("default", "wide", "multi", "params", "concat", "syntax", "dparams") else _Variant(lib, variant)
 out = {"variant": np.array(variant)}
 for seed in [int(a) for a in sys.argv[1:]]:
     stream, c = F.build(seed, variant)

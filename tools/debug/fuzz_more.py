@@ -17,7 +17,7 @@ lib = C.CDLL(iac_amd.lib_path())
 variant = sys.argv[1] if len(sys.argv) > 1 else "default"
 gold = json.load(open(os.path.join(ROOT, "tests", "golden_tmp", "fuzz_more_%s.json" % variant)))["gold"]
 from test_gpu_fuzz_facade import _Variant  # noqa: E402
-dlib = lib if variant in ("default", "wide", "multi", "params", "concat", "syntax") else _Variant(lib, variant)
+dlib = lib if variant in ("default", "wide", "multi", "params", "concat", "syntax", "dparams") else _Variant(lib, variant)
 bad = []
 for k in sorted(gold, key=int):
     seed = int(k)
