@@ -60,7 +60,18 @@ def one_switch(seed):
     return dict(sha256=F.digest(pcm), shape=list(pcm.shape), rets=[list(r) if isinstance(r, tuple) else int(r) for r in rets])
 
 
+def one_units(seed):
+    from decoder_driver import decode_stream_units
+    variant, vs, desc, units, c = F.units_case(seed)
+    ref = C.CDLL(os.path.join(HERE, *REF[variant]))
+    pcm, rets = decode_stream_units(ref, desc, units, c["layout"], **F.decode_kwargs(c, variant))
+    return dict(sha256=F.digest(pcm), shape=list(pcm.shape), rets=[int(r) for r in rets])
+
+
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--units":
+        print(json.dumps(one_units(int(sys.argv[2]))))
+        return
     if len(sys.argv) >= 3 and sys.argv[1] == "--switch":
         print(json.dumps(one_switch(int(sys.argv[2]))))
         return
@@ -95,6 +106,14 @@ def main():
         json.dump(out, f, indent=0, sort_keys=True)
     print("fuzz goldens (switch) written:", sum("sha256" in v for v in out.values()), "decoded,",
           sum("error" in v for v in out.values()), "refused,", sum("crash" in v for v in out.values()), "crashed")
+    out = {}
+    for seed in range(F.N_UNITS):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--units", str(seed)], capture_output=True, text=True)
+        out[str(seed)] = dict(crash=r.returncode) if r.returncode else json.loads(r.stdout.strip().splitlines()[-1])
+        print("  fuzz units %3d -> %s" % (seed, out[str(seed)].get("shape") or out[str(seed)]))
+    with open(os.path.join(ROOT, "tests", "golden", "fuzz_units.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("fuzz goldens (units) written:", sum("sha256" in v for v in out.values()), "decoded,", sum("crash" in v for v in out.values()), "crashed")
     out = {}
     for seed in range(F.N_BLOCKS):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--blocks", str(seed)], capture_output=True, text=True)

@@ -338,3 +338,67 @@ def decode_stream_blocks(ref, stream_bytes, layout, block, bit_depth=16, out_rat
     else:
         out = raw.reshape(-1, ch, 3)
     return out.copy(), events
+
+
+def decode_stream_units(ref, descriptors, units, layout, bit_depth=16, out_rate=0, loudness=0.0, limiter=True, threshold=-1.0,
+                        pcm_channels=None, mix_id=None):
+    """The reference player's OTHER loop (iamfplayer.c:664-789, mp4_input_wav_output2: what a demuxer does): the descriptors
+    in one IAMF_decoder_configure call with rsize == NULL, then ONE temporal unit per IAMF_decoder_decode call with
+    rsize == NULL (include/IAMF_decoder.h:91-95), a flush at the end.  Returns (pcm, [configure's value, every decode's])."""
+    ref.IAMF_decoder_open.restype = C.c_void_p
+    ref.IAMF_decoder_close.argtypes = [C.c_void_p]
+    ref.IAMF_decoder_configure.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    ref.IAMF_decoder_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_uint32), C.c_void_p]
+    ref.IAMF_decoder_output_layout_set_sound_system.argtypes = [C.c_void_p, C.c_int]
+    ref.IAMF_decoder_output_layout_set_binaural.argtypes = [C.c_void_p]
+    ref.IAMF_decoder_set_normalization_loudness.argtypes = [C.c_void_p, C.c_float]
+    ref.IAMF_decoder_set_bit_depth.argtypes = [C.c_void_p, C.c_uint32]
+    ref.IAMF_decoder_peak_limiter_enable.argtypes = [C.c_void_p, C.c_uint32]
+    ref.IAMF_decoder_peak_limiter_set_threshold.argtypes = [C.c_void_p, C.c_float]
+    ref.IAMF_decoder_set_sampling_rate.argtypes = [C.c_void_p, C.c_uint32]
+    ref.IAMF_decoder_set_pts.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
+    ref.IAMF_decoder_set_mix_presentation_id.argtypes = [C.c_void_p, C.c_uint64]
+    ref.IAMF_layout_sound_system_channels_count.argtypes = [C.c_int]
+    d = ref.IAMF_decoder_open()
+    if not limiter:
+        ref.IAMF_decoder_peak_limiter_enable(d, 0)
+    else:
+        ref.IAMF_decoder_peak_limiter_set_threshold(d, threshold)
+    ref.IAMF_decoder_set_normalization_loudness(d, loudness)
+    ref.IAMF_decoder_set_bit_depth(d, bit_depth)
+    if out_rate:
+        assert ref.IAMF_decoder_set_sampling_rate(d, out_rate) == 0
+    if layout[0] == "ss":
+        ref.IAMF_decoder_output_layout_set_sound_system(d, layout[1])
+        ch = ref.IAMF_layout_sound_system_channels_count(layout[1])
+    else:
+        ref.IAMF_decoder_output_layout_set_binaural(d)
+        ch = 2
+    ch_layout = ch
+    if pcm_channels:
+        ch = pcm_channels
+    ref.IAMF_decoder_set_pts(d, 0, 90000)
+    if mix_id is not None:
+        ref.IAMF_decoder_set_mix_presentation_id(d, mix_id)
+    bps = bit_depth // 8
+    pcm = C.create_string_buffer(bps * 6144 * 6 * max(ch, ch_layout))
+    rets, chunks = [ref.IAMF_decoder_configure(d, descriptors, len(descriptors), None)], []
+    if rets[0] == 0:
+        for u in units:
+            n = ref.IAMF_decoder_decode(d, u, len(u), None, pcm)
+            rets.append(n)
+            if n > 0:
+                chunks.append(pcm.raw[:n * ch * bps])
+        n = ref.IAMF_decoder_decode(d, None, 0, None, pcm)
+        rets.append(n)
+        if n > 0:
+            chunks.append(pcm.raw[:n * ch * bps])
+    ref.IAMF_decoder_close(d)
+    raw = np.frombuffer(b"".join(chunks), dtype=np.uint8)
+    if bit_depth == 16:
+        out = raw.view(np.int16).reshape(-1, ch)
+    elif bit_depth == 32:
+        out = raw.view(np.int32).reshape(-1, ch)
+    else:
+        out = raw.reshape(-1, ch, 3)
+    return out.copy(), rets

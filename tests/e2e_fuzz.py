@@ -441,3 +441,32 @@ def switch_case(seed):
     nfr = max(2, c["frames"] - 1)
     after = sorted(int(v) for v in rng.choice(np.arange(1, nfr + 1), size=min(len(lays) - 1, nfr), replace=False))
     return vs, lays[:len(after) + 1], after
+
+
+# The streams through the reference player's demuxer loop (decoder_driver.decode_stream_units): descriptors in one configure
+# call, one temporal unit per decode call, both with rsize == NULL.
+N_UNITS = 160
+
+
+def units_case(seed):
+    """-> (variant, seed of that variant, descriptors, [temporal units])"""
+    rng = np.random.default_rng(959000 + seed)
+    variant = ["wide", "multi", "default", "params"][seed % 4]
+    vs = int(rng.integers(0, VARIANTS[variant][1]))
+    stream, c = build(vs, variant)
+    obus = _split_obus(stream)
+    first = next(i for i, o in enumerate(obus) if o[0] == 4)
+
+    def pack(os_):
+        out = bytearray()
+        for t, red, trim, ext, payload in os_:
+            out.extend(bytes([(t << 3) | (red << 2) | (trim << 1) | ext]) + _leb(len(payload)) + payload)
+        return bytes(out)
+    units, cur = [], []
+    for o in obus[first:]:
+        if o[0] == 4 and cur:
+            units.append(pack(cur))
+            cur = []
+        cur.append(o)
+    units.append(pack(cur))
+    return variant, vs, pack(obus[:first]), units, c

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import e2e_fuzz as F
-from decoder_driver import decode_stream, decode_stream_blocks, decode_stream_switching
+from decoder_driver import decode_stream, decode_stream_blocks, decode_stream_switching, decode_stream_units
 
 pytestmark = pytest.mark.gpu
 
@@ -213,3 +213,18 @@ def test_random_tv_stream_with_run_time_layout_switches(lib, seed):
     got = [list(r) if isinstance(r, tuple) else int(r) for r in rets]
     assert got == want["rets"], (seed, vs, lays, after)
     assert list(pcm.shape) == want["shape"] and F.digest(pcm) == want["sha256"], (seed, vs, lays, after)
+
+
+GOLD_U = json.load(open(os.path.join(_G, "fuzz_units.json")))
+
+
+@pytest.mark.parametrize("seed", range(F.N_UNITS))
+def test_random_stream_one_temporal_unit_per_call(lib, seed):
+    """the reference player's demuxer loop (iamfplayer.c:664-789): the descriptors in one IAMF_decoder_configure call, ONE
+    temporal unit per IAMF_decoder_decode call, rsize == NULL in both (include/IAMF_decoder.h:91-95), a flush at the end.
+    Streams of four of the sets; every call's return value and the PCM against the reference."""
+    want = GOLD_U[str(seed)]
+    variant, vs, desc, units, c = F.units_case(seed)
+    pcm, rets = decode_stream_units(lib, desc, units, c["layout"], **F.decode_kwargs(c, variant))
+    assert [int(r) for r in rets] == want["rets"], (seed, variant, vs)
+    assert list(pcm.shape) == want["shape"] and F.digest(pcm) == want["sha256"], (seed, variant, vs)
