@@ -231,7 +231,7 @@ struct IAMF_Decoder {
   iamf_hip_resampler *rs;
   int need_cfg;     /* ctx->need_configure: bit 0 the output layout, bit 1 the mix presentation changed since the last configure */
   int frame_channels0; /* channels of the layout the presentation was enabled with: the mixed frame's (setup_pipeline) */
-  int rs_channels, reopen_rs; /* the channels `rs` was opened for; the next setup_pipeline re-opens it (TV layout switch) */
+  int rs_channels, reopen_rs, rs_inherited; /* the channels `rs` was opened for; the next setup_pipeline re-opens it (TV layout switch) */
   Pre pre[2]; /* [0]: the stage in front of element 0 of `batch`; [1]: of element 1, in front of `aux` */
   /* Both elements need a stage: element 1 is rendered (stage, matrix, its mix gain) by a batch of its own into f32 and
    * handed to `batch` as a second element with the identity matrix and gain 1 (setup_pipeline) */
@@ -1205,6 +1205,7 @@ static int setup_pipeline(struct IAMF_Decoder *d) {
     d->rs = 0;
   }
   d->reopen_rs = 0;
+  d->rs_inherited = d->rs != 0; /* (a group builds its own resampler: such a handle stays single, iamf_hip_decoder_group_create) */
   resample = d->rs != 0 || d->out_rate != d->rate;
   d->info.max_frame_size = d->frame_size <= 1024 ? 6144 : 6 * d->frame_size; /* :1628-1630 */
 

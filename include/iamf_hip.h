@@ -552,7 +552,7 @@ int iamf_hip_deinterleave_f32(const float *d_src, int64_t src_stream_stride, int
  * temporal unit, one download.  The handles need not advance in step.  While grouped, a handle refuses
  * IAMF_decoder_decode / _configure / _close with IAMF_ERR_INVALID_STATE; destroying the group releases the handles
  * (which are then closed with IAMF_decoder_close as usual).  Returns IAMF_OK, or for create: IAMF_ERR_BAD_ARG (handles
- * of different topologies), IAMF_ERR_INVALID_STATE (not configured / already decoding).  The group's own return value reports device failures only
+ * of different topologies), IAMF_ERR_INVALID_STATE (not configured / already decoding / a resampler inherited from an earlier IA sequence).  The group's own return value reports device failures only
  * (IAMF_ERR_INTERNAL): such a round is half applied — the library waits for what it had in flight, and every later
  * _decode of the group returns IAMF_ERR_INVALID_STATE; the valid call after a failure is _destroy.
  * ---------------------------------------------------------------------------------------- */
