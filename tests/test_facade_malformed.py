@@ -281,3 +281,19 @@ def test_parameter_timelines_the_reference_dies_on(driver, tmp_path):
         lay = "b" if c["layout"][0] == "binaural" else str(c["layout"][1])
         out = run(driver, tmp_path, stream, layout=lay, bits=c["bit_depth"])
         assert out[0].startswith("configure 0"), (seed, out[:2])
+
+
+@pytest.mark.parametrize("variant", ["wide", "multi", "concat", "syntax", "dparams"])
+def test_fuzz_streams_under_the_sanitizers(driver, tmp_path, variant):
+    """the host side of the facade (parser, parameter timelines, selection, reconfiguration, the two-batch pipelines) on 50
+    streams of each of the richer fuzz sets under ASan / UBSan against the device stand-ins: whatever the stream, no fault
+    (PCM and return values are compared on the GPU, tests/test_gpu_fuzz_facade.py)"""
+    import e2e_fuzz as F
+    for seed in range(50):
+        stream, c = F.build(seed, variant)
+        lay = "b" if c["layout"][0] == "binaural" else str(c["layout"][1])
+        p = os.path.join(str(tmp_path), "s.iamf")
+        open(p, "wb").write(stream)
+        r = subprocess.run([driver, p, lay, str(c["bit_depth"])], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0"))
+        assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, (variant, seed, r.stderr[-2500:])
