@@ -68,7 +68,20 @@ def one_units(seed):
     return dict(sha256=F.digest(pcm), shape=list(pcm.shape), rets=[int(r) for r in rets])
 
 
+def one_gmix(seed):
+    variant, cases, streams = F.gmix_build(seed)
+    ref = C.CDLL(os.path.join(HERE, *REF[variant]))
+    out = []
+    for c, st in zip(cases, streams):
+        pcm, rets = decode_stream(ref, st, c["layout"], **F.decode_kwargs(c, variant))
+        out.append(dict(sha256=F.digest(pcm), rets=[int(r) for r in rets]))
+    return dict(handles=out)
+
+
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--gmix":
+        print(json.dumps(one_gmix(int(sys.argv[2]))))
+        return
     if len(sys.argv) >= 3 and sys.argv[1] == "--units":
         print(json.dumps(one_units(int(sys.argv[2]))))
         return
@@ -106,6 +119,14 @@ def main():
         json.dump(out, f, indent=0, sort_keys=True)
     print("fuzz goldens (switch) written:", sum("sha256" in v for v in out.values()), "decoded,",
           sum("error" in v for v in out.values()), "refused,", sum("crash" in v for v in out.values()), "crashed")
+    out = {}
+    for seed in range(F.N_GMIX):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gmix", str(seed)], capture_output=True, text=True)
+        out[str(seed)] = dict(crash=r.returncode) if r.returncode else json.loads(r.stdout.strip().splitlines()[-1])
+        print("  fuzz gmix %3d -> %s handles" % (seed, len(out[str(seed)].get("handles", []))))
+    with open(os.path.join(ROOT, "tests", "golden", "fuzz_gmix.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("fuzz goldens (gmix) written:", sum("handles" in v for v in out.values()), "decoded,", sum("crash" in v for v in out.values()), "crashed")
     out = {}
     for seed in range(F.N_UNITS):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--units", str(seed)], capture_output=True, text=True)

@@ -470,3 +470,66 @@ def units_case(seed):
         cur.append(o)
     units.append(pack(cur))
     return variant, vs, pack(obus[:first]), units, c
+
+
+# A group whose handles decode DIFFERENT streams of one topology: the same descriptors' shape (elements, layers, layouts,
+# frame size, sample format, rates) but each stream its own audio, gains, ramps, demixing modes, recon gains and trims — a
+# group keeps all of that per stream (ramp rows, stage records, launch runs by trim).  Expected per handle: the reference's
+# decode of ITS stream.
+N_GMIX = 60
+
+
+def gmix_case(seed):
+    """-> (variant, [seed-specific case dicts of one topology])"""
+    rng = np.random.default_rng(961000 + seed)
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]
+    variant = ["wide", "dparams", "default"][seed % 3]
+    base = case(int(rng.integers(0, VARIANTS[variant][1])), variant)
+    if base["fs"] & 3:
+        base["fs"] = 1024
+        base["frames"] = int(rng.integers(4, 9))
+    base.pop("trims", None)
+    fs, frames = base["fs"], base["frames"]
+    out = []
+    for k in range(int(rng.integers(3, 7))):
+        c = dict(base)
+        c["seed"] = base["seed"] + 1000 * (k + 1)
+        c["element_gain_q78"] = int(rng.integers(-1500, 300))
+        c["element2_gain_q78"] = int(rng.integers(-1500, 300))
+        c["output_gain_q78"] = int(rng.integers(-600, 300))
+        c["dmx_modes"] = [pick(MODES) for _ in range(32)]
+        c["dmx_modes2"] = [pick(MODES) for _ in range(32)]
+        c["scalable_modes1"] = [pick(MODES) for _ in range(32)]
+        c["scalable_modes2"] = [pick(MODES) for _ in range(32)]
+        c["recon_salt2"] = int(rng.integers(1, 50))
+        if "drop_blocks" in base:
+            c["drop_blocks"] = (int(rng.integers(1, 1 << 30)), base["drop_blocks"][1])
+        if rng.random() < 0.5:
+            c["pair_ramps"] = True
+        else:
+            c.pop("pair_ramps", None)
+        trims = {}
+        if rng.random() < 0.4:
+            trims[0] = (int(rng.integers(1, fs)), 0)
+        if rng.random() < 0.4:
+            trims[frames - 1] = (0, int(rng.integers(1, fs)))
+        if rng.random() < 0.2:
+            a = int(rng.integers(1, fs))
+            trims[int(rng.integers(1, max(2, frames - 1)))] = (a, fs - a)
+        if trims:
+            c["trims"] = trims
+        out.append(c)
+    return variant, out
+
+
+def gmix_build(seed):
+    variant, cases = gmix_case(seed)
+    streams = []
+    for k, c in enumerate(cases):
+        name = "fuzz_gmix_%d_%d" % (seed, k)
+        E.CASES[name] = c
+        try:
+            streams.append(E.build(name)[0])
+        finally:
+            del E.CASES[name]
+    return variant, cases, streams

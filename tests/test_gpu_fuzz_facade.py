@@ -228,3 +228,27 @@ def test_random_stream_one_temporal_unit_per_call(lib, seed):
     pcm, rets = decode_stream_units(lib, desc, units, c["layout"], **F.decode_kwargs(c, variant))
     assert [int(r) for r in rets] == want["rets"], (seed, variant, vs)
     assert list(pcm.shape) == want["shape"] and F.digest(pcm) == want["sha256"], (seed, variant, vs)
+
+
+GOLD_G = json.load(open(os.path.join(_G, "fuzz_gmix.json")))
+
+
+@pytest.mark.parametrize("seed", range(F.N_GMIX))
+def test_group_whose_handles_decode_different_streams(lib, seed):
+    """three to six handles of ONE topology, each with a stream of its own — other audio, gains, ramps, demixing modes, recon
+    gains, missing blocks, trims (a unit trimmed away in one stream while the others render) — out of step through one group:
+    every handle's PCM and return values are the reference's decode of ITS stream.  (The other group tests feed every
+    handle the same bytes: a group that used stream 0's records for all would pass them.)"""
+    want = GOLD_G[str(seed)]
+    if "handles" not in want:
+        pytest.skip("the reference dies on one of these streams")
+    variant, cases, streams = F.gmix_build(seed)
+    n = len(streams)
+    rc, outs = group_decode_all(lib, dict(cases[0]), streams, n, 2, starve=lambda r, i: (r + 2 * i) % 5 == 0 and i % 2 == 1)
+    if "toa_projection" in cases[0]["pair"]:   # every stream brings a de-mapping matrix of its own: not one topology
+        assert rc == -1
+        return
+    assert rc == 0, (seed, rc)
+    for i, (pcm, rets) in enumerate(outs):
+        assert [int(r) for r in rets] == want["handles"][i]["rets"], (seed, variant, i)
+        assert F.digest(pcm) == want["handles"][i]["sha256"], (seed, variant, i)

@@ -75,12 +75,15 @@ def open_handle(L, case, stream):
 
 
 def group_decode_all(L, case, stream, n, threads, starve):
-    """-> per handle (pcm ndarray, rets) decoded through one group; starve(round, i) -> True: handle i gets no data this round"""
+    """-> per handle (pcm ndarray, rets) decoded through one group; starve(round, i) -> True: handle i gets no data this round.
+    `stream`: the bytes every handle decodes, or a list of n streams of one topology — one per handle"""
     bits = case.get("bit_depth", 16)
     bps = bits // 8
+    streams = list(stream) if isinstance(stream, (list, tuple)) else [stream] * n
+    assert len(streams) == n
     hs, used = [], []
-    for _ in range(n):
-        d, ch, u = open_handle(L, case, stream)
+    for i in range(n):
+        d, ch, u = open_handle(L, case, streams[i])
         hs.append(d)
         used.append(u)
     harr = (C.c_void_p * n)(*hs)
@@ -90,8 +93,8 @@ def group_decode_all(L, case, stream, n, threads, starve):
         for d in hs:
             L.IAMF_decoder_close(d)
         return rc, None
-    buf = C.create_string_buffer(stream, len(stream))
-    base = C.addressof(buf)
+    bufs = [C.create_string_buffer(st, len(st)) for st in streams]
+    bases = [C.addressof(b) for b in bufs]
     pcms = [C.create_string_buffer(bps * 6144 * 6 * ch) for _ in range(n)]
     parr = (C.c_void_p * n)(*[C.addressof(p) for p in pcms])
     data, sizes, rsz, res = (C.c_void_p * n)(), (C.c_int32 * n)(), (C.c_uint32 * n)(), (C.c_int32 * n)()
@@ -101,16 +104,16 @@ def group_decode_all(L, case, stream, n, threads, starve):
         kind = []
         for i in range(n):
             if done[i]:
-                data[i], sizes[i] = base, 1
+                data[i], sizes[i] = bases[i], 1
                 kind.append("idle")
-            elif used[i] >= len(stream):
+            elif used[i] >= len(streams[i]):
                 data[i], sizes[i] = None, 0
                 kind.append("flush")
             elif starve(rnd, i):
-                data[i], sizes[i] = base + used[i], 1     # one byte: no complete OBU, nothing is consumed
+                data[i], sizes[i] = bases[i] + used[i], 1     # one byte: no complete OBU, nothing is consumed
                 kind.append("starved")
             else:
-                data[i], sizes[i] = base + used[i], len(stream) - used[i]
+                data[i], sizes[i] = bases[i] + used[i], len(streams[i]) - used[i]
                 kind.append("feed")
         assert L.iamf_hip_decoder_group_decode(g, data, sizes, rsz, parr, res) == 0
         for i in range(n):
@@ -127,7 +130,7 @@ def group_decode_all(L, case, stream, n, threads, starve):
                     rets[i].append(r)
                 used[i] += rsz[i]
                 if not rsz[i]:
-                    used[i] = len(stream)
+                    used[i] = len(streams[i])
             else:
                 assert r == 0 and rsz[i] == 0
         rnd += 1
