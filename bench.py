@@ -623,13 +623,20 @@ class Workload:
         singles = list(self.pcm)
         rates = [rate(b) for b in singles]
         limit = 8 * max(1, tries)
+        need = self.S * self.stride_bytes
         while len(singles) < limit:
             fast = sorted(rates, reverse=True)
             if len(fast) >= 2 and fast[1] > 1.07 * min(rates):
                 break   # two buffers of the fast kind
             if len(rates) >= 12 and max(rates) < 1.04 * min(rates):
                 break   # a dozen allocations, one kind: on this card the output's placement is not what decides
-            singles.append(torch.zeros((self.S, self.stride_bytes), dtype=torch.uint8, device=dev))
+            free_b, _total_b = torch.cuda.mem_get_info(dev)
+            if need > free_b // 4 or (len(singles) + 1) * need > (32 << 30):
+                break   # bounded: the candidates stay alive while the search runs (cfg3's buffers are 6 GiB each)
+            try:
+                singles.append(torch.zeros((self.S, self.stride_bytes), dtype=torch.uint8, device=dev))
+            except torch.OutOfMemoryError:
+                break
             rates.append(rate(singles[-1]))
         order = list(np.argsort(rates)[::-1][:2])
         if sorted(order) != [0, 1]:
