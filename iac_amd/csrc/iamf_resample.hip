@@ -200,6 +200,143 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(const RsParams p) {
   }
 }
 
+// Register-blocked form of resample_tile_kernel for the INTERPOLATED mode (44.1 <-> 48 kHz ...) and layouts of up to 8
+// channels (round 4, second half).  In the tiled kernel a thread = one (output, channel) element reads, per tap, 16 bytes
+// of table and 4 bytes of input for 4 multiply-adds: 5 B of LDS traffic per MAC.  Here a thread owns R outputs of ONE
+// phase — k, k + den G, ..., k + (R - 1) den G: frac, hence the interpolation offset / the table row, repeats with period
+// den, and the window moves on by exactly num samples per den outputs — and ALL C channels of them, so a tap's four table
+// values are read once for 4 R C multiply-adds and the C channels of a sample are one contiguous read (stereo, R = 4: 1.5
+// B per MAC).  What bounds it then is the vector ALU: the reference rounds product and sum separately (no fma), a wave
+// issues v_pk_mul_f32 / v_pk_add_f32 every 6 cycles (tools/debug/pk_rate_probe.hip) = 26 T MAC/s chip-wide, of which this
+// kernel reaches 18 (stereo 44.1 -> 48 kHz: 25.6 -> 35.7 G output sample-frames/s, 6 channels 9.4 -> 10.4; 48 -> 44.1 kHz:
+// 25.9 -> 31.8 / 8.6 -> 10.6; tools/debug/resample_probe.py).  NOT used where it measured no better: 10 and more channels
+// (one output per thread: nothing shared but the table row), and the direct mode (2:1, 3:2, 1:3 ...: a lane's window
+// starts num / den * C floats behind its neighbour's — an even stride, 2- to 8-way LDS bank conflicts — 0.34-0.9 of the
+// tiled kernel).  Every (output, channel) still runs the reference's operations in the reference's order
+// (resample.c:372-400): bit-exact, and bit-equal to the two kernels above.
+// Workgroup = den * G threads (rounded up to whole waves), thread u taking outputs u + r * den * G of the tile of
+// den * R * G consecutive outputs of one stream: neighbouring lanes read neighbouring windows.
+template <int C, int R>
+__global__ __launch_bounds__(512) void resample_block_kernel(const RsParams p, int G) {
+  extern __shared__ float rs_lds[];
+  const int s = blockIdx.y + p.s0;
+  const int hist_len = p.N - 1;
+  const int N = p.N;
+  const int den = (int)p.den;
+  const int T = den * R * G;
+  const float *in = p.in ? p.in + (int64_t)s * p.in_stream_stride : nullptr;
+  const float *hist = p.hist + (int64_t)s * hist_len * C;
+  float *win = rs_lds;                                  // [win_cap][C]
+  float4 *tab = reinterpret_cast<float4 *>(rs_lds + (((size_t)p.win_cap * C + 3) & ~(size_t)3));
+
+  // history for the next call: [hist | in] shifted by the consumed samples (resample.c:801-809); workgroup 0 of the stream
+  if (blockIdx.x == 0) {
+    for (int e = threadIdx.x; e < hist_len * C; e += blockDim.x) {
+      const int j = e / C, c = e - j * C;
+      const int src = j + p.consumed;  // index into [hist | in]
+      float v = 0.f;
+      if (src < hist_len)
+        v = hist[src * C + c];
+      else if (in)
+        v = in[(int64_t)(src - hist_len) * C + c];
+      p.hist_next[((int64_t)s * hist_len + j) * C + c] = v;
+    }
+  }
+  const int64_t k_first = (int64_t)blockIdx.x * T;
+  const int base = p.ls0 + (int)(((uint64_t)p.fr0 + (uint64_t)k_first * p.num) / p.den);
+  for (int i = threadIdx.x; i < p.win_cap * C; i += blockDim.x) {
+    const int idx = base + i / C, c = i - (i / C) * C;
+    float v = 0.f;
+    if (idx < hist_len)
+      v = hist[idx * C + c];
+    else if (in && idx - hist_len < p.ns)
+      v = in[(int64_t)(idx - hist_len) * C + c];
+    win[i] = v;
+  }
+  {
+    const float4 *t4 = reinterpret_cast<const float4 *>(p.table4);
+    for (int i = threadIdx.x; i < p.oversample * N; i += blockDim.x) tab[i + i / N] = t4[i];
+  }
+  __syncthreads();
+  const int u = threadIdx.x;
+  if (u >= den * G) return;
+  const int64_t k0 = k_first + u;   // this thread's outputs: k0 + r * den * G (neighbouring lanes: neighbouring outputs)
+  if (k0 >= p.n_out) return;
+  const uint64_t tot = (uint64_t)p.fr0 + (uint64_t)k0 * p.num;
+  const int pos = p.ls0 + (int)(tot / p.den);
+  const uint32_t frac = (uint32_t)(tot % p.den);
+  const float *wp = win + (size_t)(pos - base) * C;
+  const int step = (int)p.num * G * C;   // floats between the windows of outputs k and k + den * G
+  float res[R][C];
+  {  // resample.c:372-400
+    const int offset = (int)(frac * (uint32_t)p.oversample / p.den);
+    const float fr = ((float)((frac * (uint32_t)p.oversample) % p.den)) / (float)p.den;
+    const float4 *tp = tab + (size_t)offset * (N + 1);
+    float4 acc[R][C];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc[r][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int j = 0; j < N; ++j) {
+      const float4 w = tp[j];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float *x = wp + r * step + (size_t)j * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float cur = x[c];
+          acc[r][c].x = acc[r][c].x + cur * w.x;
+          acc[r][c].y = acc[r][c].y + cur * w.y;
+          acc[r][c].z = acc[r][c].z + cur * w.z;
+          acc[r][c].w = acc[r][c].w + cur * w.w;
+        }
+      }
+    }
+    float interp[4];
+    cubic_coef(fr, interp);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        res[r][c] = interp[0] * acc[r][c].x + interp[1] * acc[r][c].y + interp[2] * acc[r][c].z + interp[3] * acc[r][c].w;
+  }
+  float *out = p.out + (int64_t)s * p.out_stream_stride;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t k = k0 + (int64_t)r * den * G;
+    if (k < p.n_out) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float sum = res[r][c];
+        sum = sum < -1.0f ? -1.0f : (sum > 1.0f ? 1.0f : sum);  // FLTADJUST, resample.c:84,959
+        out[k * C + c] = sum;
+      }
+    }
+  }
+}
+
+// R for a channel count: 4 R C accumulators per thread in interpolated mode
+constexpr int rs_block_r(int c) { return c <= 2 ? 4 : (c <= 8 ? 2 : 1); }
+template <int C, int R>
+void rs_block_launch_cr(const RsParams &p, int G, dim3 grid, unsigned block, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((resample_block_kernel<C, R>), grid, dim3(block), lds, st, p, G);
+}
+// mono, stereo / binaural, 5.1 / 3.1.2, 7.1 / 5.1.2; `r` is one of 1, 2, 4 and at most rs_block_r(ch).  false: no instantiation
+bool rs_block_launch(int ch, int r, const RsParams &p, int G, dim3 grid, unsigned block, size_t lds, hipStream_t st) {
+#define RS_CASE(C_)                                                                   \
+  case C_:                                                                            \
+    if (r >= 4 && rs_block_r(C_) >= 4) rs_block_launch_cr<C_, rs_block_r(C_) >= 4 ? 4 : 1>(p, G, grid, block, lds, st);      \
+    else if (r >= 2 && rs_block_r(C_) >= 2) rs_block_launch_cr<C_, rs_block_r(C_) >= 2 ? 2 : 1>(p, G, grid, block, lds, st); \
+    else rs_block_launch_cr<C_, 1>(p, G, grid, block, lds, st);                        \
+    return true;
+  switch (ch) {
+    RS_CASE(1) RS_CASE(2) RS_CASE(6) RS_CASE(8)
+    default: return false;
+  }
+#undef RS_CASE
+}
+
 // ---- filter design on the host: resample.c:194-231 (window, sinc) and :527-611 ----
 double window_at(float x) {
   float y, frac;
@@ -313,7 +450,42 @@ int rs_run(iamf_hip_resampler *r, const float *d_in, int64_t in_stride, int ns, 
   const int64_t win_cap = ((int64_t)outs * r->num + r->den - 1) / r->den + (int64_t)r->filt_len + 2;
   const size_t tab_floats = r->direct ? (size_t)r->den * (r->filt_len + 4) : (size_t)4 * r->oversample * (r->filt_len + 1);
   const size_t lds = sizeof(float) * ((((size_t)win_cap * r->ch + 3) & ~(size_t)3) + tab_floats);
-  if ((r->direct ? (r->filt_len & 7) == 0 : r->d_table4 != nullptr) && lds <= 48 * 1024 && !getenv("IAMF_HIP_RESAMPLE_PLAIN")) {
+  // the register-blocked kernel: a thread = R outputs of one phase x all channels (resample_block_kernel)
+  bool blocked = false;
+  if (!r->direct && r->d_table4 != nullptr && r->den <= 512 && rs_block_r(r->ch) >= 2 && !getenv("IAMF_HIP_RESAMPLE_PLAIN") &&
+      !getenv("IAMF_HIP_RESAMPLE_TILE")) {
+    // G groups of den threads: the fullest whole waves within 512 threads, nearest to 256 among equals
+    int G = 1, best_num = 0, best_blk = 64;
+    for (int g2 = 1; (int)r->den * g2 <= 512; ++g2) {
+      const int used = (int)r->den * g2, blk = (used + 63) & ~63;
+      if ((int64_t)used * best_blk > (int64_t)best_num * blk ||
+          ((int64_t)used * best_blk == (int64_t)best_num * blk && abs(blk - 256) < abs(best_blk - 256))) {
+        G = g2;
+        best_num = used;
+        best_blk = blk;
+      }
+    }
+    int R = cnt >= 256 ? 4 : (cnt >= 64 ? 2 : 1);   // few streams: more, smaller tiles
+    while (R > rs_block_r(r->ch)) R >>= 1;
+    for (;;) {
+      const int64_t T = (int64_t)r->den * R * G;
+      const int64_t wcap = (T * r->num + r->den - 1) / r->den + (int64_t)r->filt_len + 2;
+      const size_t blds = sizeof(float) * ((((size_t)wcap * r->ch + 3) & ~(size_t)3) + tab_floats);
+      if (blds <= 60 * 1024) {
+        p.table4 = r->d_table4;
+        p.win_cap = (int)wcap;
+        const unsigned blk = (unsigned)(((int)r->den * G + 63) & ~63);
+        dim3 bgrid((unsigned)(n_out > 0 ? (n_out + T - 1) / T : 1), (unsigned)cnt);
+        blocked = rs_block_launch(r->ch, R, p, G, bgrid, blk, blds, static_cast<hipStream_t>(stream));
+        break;
+      }
+      if (R > 1) R >>= 1;
+      else if (G > 1) --G;
+      else break;
+    }
+  }
+  if (blocked) {
+  } else if ((r->direct ? (r->filt_len & 7) == 0 : r->d_table4 != nullptr) && lds <= 48 * 1024 && !getenv("IAMF_HIP_RESAMPLE_PLAIN")) {
     p.table4 = r->d_table4;
     p.win_cap = (int)win_cap;
     dim3 tgrid((unsigned)((work + kRsTile - 1) / kRsTile), (unsigned)cnt);

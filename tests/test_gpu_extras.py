@@ -359,6 +359,51 @@ def test_resampler_streams_out_of_step_by_ranges(hip, rates):
         assert np.array_equal(np.concatenate(outs[s], axis=1).view(np.uint32), want.view(np.uint32)), s
 
 
+@pytest.mark.parametrize("rates", [(44100, 48000), (48000, 44100), (22050, 48000), (8000, 44100)])
+@pytest.mark.parametrize("ch,streams", [(1, 3), (2, 70), (2, 260), (6, 70), (8, 5), (6, 260), (1, 300)])
+def test_resampler_blocked_kernel_over_its_shapes(hip, rates, ch, streams, monkeypatch):
+    """resample_block_kernel<C, R> (interpolated mode, 1 / 2 / 6 / 8 channels; R = 1 / 2 / 4 by the launch's stream count;
+    den = 160, 147, 320, 441 threads' worth of phases): ragged calls incl. one that yields no output, then the drain.
+    Streams 0 and the last one against the oracle (the reference's arithmetic), every stream against the tiled kernel."""
+    A, G, torch = hip
+    sizes = [1024, 3, 1, 700, 1024, 64]
+    rng = np.random.default_rng(ch * 1000 + streams)
+    x = (rng.standard_normal((streams, sum(sizes), ch)) * 0.3).astype(np.float32)
+    x[:, 100:140] *= 4.0   # beyond +-1: the clamp
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        r = A.Resampler(streams, ch, rates[0], rates[1])
+        outs, pos = [], 0
+        for ns in sizes:
+            inter = torch.from_numpy(np.ascontiguousarray(x[:, pos:pos + ns])).cuda()
+            pos += ns
+            cap = max(r.out_capacity(ns), 1)
+            o = torch.full((streams, cap, ch), 9.0, dtype=torch.float32, device="cuda")
+            n = r.process(inter.data_ptr(), ns * ch, ns, o.data_ptr(), cap * ch, st)
+            torch.cuda.synchronize()
+            assert n >= 0, n
+            outs.append(o[:, :n].cpu().numpy())
+            assert bool((o[:, n:] == 9.0).all()), "nothing is written past the call's outputs"
+        cap = max(r.flush_capacity(), 1)
+        o = torch.zeros((streams, cap, ch), dtype=torch.float32, device="cuda")
+        n = r.flush(o.data_ptr(), cap * ch, st)
+        torch.cuda.synchronize()
+        outs.append(o[:, :n].cpu().numpy())
+        r.close()
+        return np.concatenate(outs, axis=1)
+
+    monkeypatch.delenv("IAMF_HIP_RESAMPLE_TILE", raising=False)
+    got = run()
+    monkeypatch.setenv("IAMF_HIP_RESAMPLE_TILE", "1")
+    tiled = run()
+    monkeypatch.delenv("IAMF_HIP_RESAMPLE_TILE", raising=False)
+    assert np.array_equal(got.view(np.uint32), tiled.view(np.uint32))
+    for s_ in (0, streams - 1):
+        want, _ = O.resample_run(np.ascontiguousarray(x[s_].T), rates[0], rates[1], sizes)
+        assert np.array_equal(np.ascontiguousarray(got[s_].T).view(np.uint32), want.view(np.uint32)), s_
+
+
 def test_stream_signal_writes_the_pinned_word_behind_the_queued_work(hip):
     """iamf_hip_stream_signal (what the single-handle facade waits on instead of hipStreamSynchronize)"""
     A, G, torch = hip
