@@ -21,9 +21,11 @@ using u4 = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int ROWS = 16;
 
-// MODE 0: no stores; 1: register burst; 2: burst by wave 0 through LDS
+// MODE 0: no stores; 1: register burst; 2: burst by wave 0 through LDS; 3: register burst released by the DEVICE-WIDE clock
+// (s_memrealtime, 100 MHz): every workgroup stores what it holds when (now % period) < window, or when its K slots are
+// full — all workgroups write in the same windows, the memory sees read phases and write phases
 template <int K, int MODE, bool FM, bool STAG>
-__global__ __launch_bounds__(256, 2) void probe(const v4 *in, u4 *out, int chunks, int spin) {
+__global__ __launch_bounds__(256, 2) void probe(const v4 *in, u4 *out, int chunks, int spin, unsigned period = 0, unsigned window = 0) {
   const int s = blockIdx.x, t = threadIdx.x, S = gridDim.x;
   const v4 *src = in + (long)s * chunks * ROWS * 256;   // [stream][row][chunk][256 lanes] x 16 B
   const long rstride = (long)chunks * 256;
@@ -55,10 +57,14 @@ __global__ __launch_bounds__(256, 2) void probe(const v4 *in, u4 *out, int chunk
     hold[K - 1] = w;
     if (held == 0) c_first = c;
     ++held;
-    const bool fire = held == K || c + 1 == chunks || (first_burst && held == phase);
+    bool fire = held == K || c + 1 == chunks || (first_burst && held == phase);
+    if (MODE == 3) {
+      const unsigned now = (unsigned)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_s_memrealtime() & 0xffffffffu));
+      fire = fire || (now % period) < window;
+    }
     if (!fire) continue;
     first_burst = false;
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 3) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int idx = k - (K - held);   // hold[K - held .. K - 1] are the `held` chunks c_first ..
@@ -154,6 +160,14 @@ int main(int argc, char **argv) {
     const char *name = pr ? "slow" : "fast";
     const v4 *ip = pr ? in[wi] : in[bi];
     u4 *op = pr ? out[wo] : out[bo];
+    for (int spin : {0, 300})
+      for (unsigned period : {1000u, 2000u, 4000u, 8000u})       // 10 / 20 / 40 / 80 us
+        for (unsigned window : {period / 16, period / 8, period / 4}) {
+          const float ms = T.best([&] { probe<8, 3, false, false><<<S, 256>>>(ip, op, chunks, spin, period, window); });
+          printf("%-5s spin %3d  K 8 clock period %5.0f us window %5.1f us  %.3f ms  %5.0f GB/s  %6.1f Gsamples/s\n", name, spin,
+                 period * 0.01, window * 0.01, ms, (double)S * chunks * 17 * 4096.0 / ms / 1e6, (double)S * chunks * 1024 / ms / 1e6);
+          fflush(stdout);
+        }
     for (int spin : {0, 300}) {
       one<1, 0, false, false>(T, name, ip, op, S, chunks, spin);
       allk<1>(T, name, ip, op, S, chunks, spin);
