@@ -370,25 +370,52 @@ __global__ __launch_bounds__(256) void render_wide_kernel(const RenderParams p) 
         *reinterpret_cast<uint4 *>(pcm + ((jc - out_base) * (int64_t)C + f0) * 2) = w;
       }
     } else {
-      const int64_t j = gk - kDelay;
-      if (valid && j >= 0) {
-        const int rd = (int)(j & (kWPos - 1));
-        const float gq = arr_g[t] * (1.0f / 32768.f);  // exact: undo the power-of-two scaling
-        uint8_t *dst = pcm + (j - out_base) * (int64_t)C * bytes;
-        if (p.out_format == IAMF_HIP_FMT_S24) {
-          for (int c = 0; c < C; ++c) {
-            const int v = (int)to_scaled(ring[rd * C + c] * gq, 8388608.f, -8388608.f, 8388607.f);
-            dst[c * 3 + 0] = (uint8_t)(v & 0xff);
-            dst[c * 3 + 1] = (uint8_t)((v >> 8) & 0xff);
-            dst[c * 3 + 2] = (uint8_t)(((v >> 16) & 0x7f) | ((v >> 24) & 0x80));
+      // s24 / s32 / f32: as above, a lane takes PIECES of the chunk's contiguous run — four elements: 12 or 16 bytes — so
+      // that a store instruction writes one contiguous stretch.  (Until round 4 a lane stored the C elements of its own
+      // sample-frame one by one, C * bytes apart from its neighbour's: 7.1.4 -> J 15 Gsamples/s in s24 and 34 in s32 where
+      // s16 runs at 65 on this kernel's sibling, tools/debug/format_cliff_probe.py.)  Same products, same roundings.
+      const int np = (cnt * C) >> 2;  // 4-element pieces (cnt % 64 == 0)
+      const int ring_flat = kWPos * C;
+      for (int q = t; q < np; q += 256) {
+        const int f0 = 4 * q;
+        int srel = (int)(((uint32_t)f0 * inv_c) >> 20);
+        int r = f0 - srel * C;
+        if (jc + srel < 0) continue;  // withheld look-ahead samples; 240*C is a multiple of 4
+        int rf = epos * C + f0;
+        rf = rf >= ring_flat ? rf - ring_flat : rf;
+        const float4 v0 = *reinterpret_cast<const float4 *>(&ring[rf]);
+        const float vv[4] = {v0.x, v0.y, v0.z, v0.w};
+        float xg[4];
+        float gq = arr_g[srel] * (1.0f / 32768.f);  // exact: undo the power-of-two scaling
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          xg[i] = vv[i] * gq;
+          ++r;
+          if (r == C) {  // next sample-frame: next gain
+            r = 0;
+            ++srel;
+            gq = arr_g[srel < kWChunk ? srel : kWChunk - 1] * (1.0f / 32768.f);
           }
+        }
+        uint8_t *dst = pcm + ((jc - out_base) * (int64_t)C + f0) * bytes;   // 12- or 16-byte pieces from a 16-byte aligned base
+        if (p.out_format == IAMF_HIP_FMT_S24) {
+          uint32_t u[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int v = (int)to_scaled(xg[i], 8388608.f, -8388608.f, 8388607.f);
+            u[i] = (uint32_t)(v & 0xffff) | ((uint32_t)(((v >> 16) & 0x7f) | ((v >> 24) & 0x80)) << 16);
+          }
+          using u3 = __attribute__((ext_vector_type(3))) unsigned;
+          *reinterpret_cast<u3 *>(dst) = u3{u[0] | (u[1] << 24), (u[1] >> 8) | (u[2] << 16), (u[2] >> 16) | (u[3] << 8)};
         } else if (p.out_format == IAMF_HIP_FMT_S32) {
-          int32_t *d32 = reinterpret_cast<int32_t *>(dst);
-          for (int c = 0; c < C; ++c)
-            d32[c] = (int32_t)(long long)to_scaled(ring[rd * C + c] * gq, 2147483648.f, -2147483648.f, 2147483647.f);
+          int4 w;
+          w.x = (int32_t)(long long)to_scaled(xg[0], 2147483648.f, -2147483648.f, 2147483647.f);
+          w.y = (int32_t)(long long)to_scaled(xg[1], 2147483648.f, -2147483648.f, 2147483647.f);
+          w.z = (int32_t)(long long)to_scaled(xg[2], 2147483648.f, -2147483648.f, 2147483647.f);
+          w.w = (int32_t)(long long)to_scaled(xg[3], 2147483648.f, -2147483648.f, 2147483647.f);
+          *reinterpret_cast<int4 *>(dst) = w;
         } else {
-          float *df = reinterpret_cast<float *>(dst);
-          for (int c = 0; c < C; ++c) df[c] = ring[rd * C + c] * gq;
+          *reinterpret_cast<float4 *>(dst) = make_float4(xg[0], xg[1], xg[2], xg[3]);
         }
       }
     }

@@ -92,6 +92,28 @@ def test_pipeline_toa_binaural_vs_oracle(hip, fmt_bits):
         assert np.array_equal(got[s], want), (s, fmt_bits)
 
 
+@pytest.mark.parametrize("fmt_bits", [24, 32])
+@pytest.mark.parametrize("lay,in_id,m", [("B", "L51", 6), ("J", "L714", 12), ("E", "L714", 12), ("G", "L714", 12), ("H", None, 16), ("L312", "L51", 6)])
+def test_wide_layouts_in_24_and_32_bit_vs_oracle(hip, fmt_bits, lay, in_id, m):
+    """s24 / s32 PCM of the layouts with more than two channels (render_wide_kernel: a lane stores 12- / 16-byte pieces of
+    the chunk's contiguous run; until round 4 its own sample-frame element by element): 6, 11, 12, 14, 24 channels, the
+    first call (240 withheld samples), calls of 1 / 3 / 2 frames, frame sizes 1024 and 960, the flush."""
+    A, G = hip
+    oc = {"B": 6, "J": 12, "E": 11, "G": 14, "H": 24, "L312": 6}[lay]
+    for fs in (1024, 960):
+        F, S = 6, 3
+        x = np.stack([synth.hot(4100 + 7 * s + oc, m, F * fs, sigma=0.3, burst_phase=500 + 90 * s, burst_period=3000) for s in range(S)])
+        mx = A.get_h2m_matrix(3, A.SS[lay]) if in_id is None else A.get_m2m_matrix(A.SS[in_id], A.SS[lay])
+        omx = O.get_h2m(3, O.SS[lay]) if in_id is None else O.get_m2m(O.SS[in_id], O.SS[lay])
+        fmt = {24: A.FMT_S24, 32: A.FMT_S32}[fmt_bits]
+        got = G.hip_render(mx, oc, x, frame_size=fs, fmt=fmt, limiter=True, flush=True, frames_per_call=[1, 3, 2],
+                           projection=A.PROJ_EXACT)
+        for s in range(S):
+            want = O.stream_run(omx, oc, x[s], fs, bit_depth=fmt_bits)
+            assert got[s].shape == want.shape
+            assert np.array_equal(got[s], want), (lay, fs, s, fmt_bits)
+
+
 def test_pipeline_gains_and_loudness_vs_oracle(hip):
     A, G = hip
     S, fs, F = 3, 960, 4
