@@ -200,20 +200,22 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(const RsParams p) {
   }
 }
 
-// Register-blocked form of resample_tile_kernel for the INTERPOLATED mode (44.1 <-> 48 kHz ...) and layouts of up to 8
-// channels (round 4, second half).  In the tiled kernel a thread = one (output, channel) element reads, per tap, 16 bytes
-// of table and 4 bytes of input for 4 multiply-adds: 5 B of LDS traffic per MAC.  Here a thread owns R outputs of ONE
+// floats between two samples of the staged window: C, padded so that CS / 2 is odd (8, 12, 16, 24 channels put the lanes'
+// 8-byte reads 8 / 4 / 16 / 8 bank pairs apart: 2- to 8-way conflicts; measured with 8 channels: 0.5 of the tiled kernel)
+__host__ __device__ constexpr int rs_cs(int c) { return c == 1 ? 1 : (((c / 2) & 1) ? c : c + 2); }
+
+// Register-blocked form of resample_tile_kernel for the INTERPOLATED mode (44.1 <-> 48 kHz ...; round 4, second half).
+// In the tiled kernel a thread = one (output, channel) element reads, per tap, 16 bytes of table and 4 bytes of input for 4 multiply-adds: 5 B of LDS traffic per MAC.  Here a thread owns R outputs of ONE
 // phase — k, k + den G, ..., k + (R - 1) den G: frac, hence the interpolation offset / the table row, repeats with period
 // den, and the window moves on by exactly num samples per den outputs — and ALL C channels of them, so a tap's four table
 // values are read once for 4 R C multiply-adds and the C channels of a sample are one contiguous read (stereo, R = 4: 1.5
 // B per MAC).  What bounds it then is the vector ALU: the reference rounds product and sum separately (no fma), a wave
 // issues v_pk_mul_f32 / v_pk_add_f32 every 6 cycles (tools/debug/pk_rate_probe.hip) = 26 T MAC/s chip-wide, of which this
-// kernel reaches 18 (stereo 44.1 -> 48 kHz: 25.6 -> 35.7 G output sample-frames/s, 6 channels 9.4 -> 10.4; 48 -> 44.1 kHz:
-// 25.9 -> 31.8 / 8.6 -> 10.6; tools/debug/resample_probe.py).  NOT used where it measured no better: 10 and more channels
-// (one output per thread: nothing shared but the table row), and the direct mode (2:1, 3:2, 1:3 ...: a lane's window
-// starts num / den * C floats behind its neighbour's — an even stride, 2- to 8-way LDS bank conflicts — 0.34-0.9 of the
-// tiled kernel).  Every (output, channel) still runs the reference's operations in the reference's order
-// (resample.c:372-400): bit-exact, and bit-equal to the two kernels above.
+// kernel reaches 18-19 (stereo 44.1 -> 48 kHz: 25.2 -> 37.0 G output sample-frames/s, 6 / 8 / 12 channels 9.3 -> 11.6 / 7.1 ->
+// 8.6 / 5.0 -> 7.1; tools/debug/resample_probe.py, profiles/r04_resample_probe.txt).  The staged window's sample stride is
+// padded (rs_cs): with 8 or 12 floats between samples the lanes' reads collide on LDS banks (8 channels unpadded: 0.57 of
+// the tiled kernel).  The direct mode has a kernel of its own below.  Every (output, channel) still runs the reference's
+// operations in the reference's order (resample.c:372-400): bit-exact, and bit-equal to the two kernels above.
 // Workgroup = den * G threads (rounded up to whole waves), thread u taking outputs u + r * den * G of the tile of
 // den * R * G consecutive outputs of one stream: neighbouring lanes read neighbouring windows.
 template <int C, int R>
@@ -226,8 +228,9 @@ __global__ __launch_bounds__(512) void resample_block_kernel(const RsParams p, i
   const int T = den * R * G;
   const float *in = p.in ? p.in + (int64_t)s * p.in_stream_stride : nullptr;
   const float *hist = p.hist + (int64_t)s * hist_len * C;
-  float *win = rs_lds;                                  // [win_cap][C]
-  float4 *tab = reinterpret_cast<float4 *>(rs_lds + (((size_t)p.win_cap * C + 3) & ~(size_t)3));
+  constexpr int CS = rs_cs(C);
+  float *win = rs_lds;                                  // [win_cap][CS]
+  float4 *tab = reinterpret_cast<float4 *>(rs_lds + (((size_t)p.win_cap * CS + 3) & ~(size_t)3));
 
   // history for the next call: [hist | in] shifted by the consumed samples (resample.c:801-809); workgroup 0 of the stream
   if (blockIdx.x == 0) {
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(512) void resample_block_kernel(const RsParams p, i
       v = hist[idx * C + c];
     else if (in && idx - hist_len < p.ns)
       v = in[(int64_t)(idx - hist_len) * C + c];
-    win[i] = v;
+    win[(i / C) * CS + c] = v;
   }
   {
     const float4 *t4 = reinterpret_cast<const float4 *>(p.table4);
@@ -265,8 +268,8 @@ __global__ __launch_bounds__(512) void resample_block_kernel(const RsParams p, i
   const uint64_t tot = (uint64_t)p.fr0 + (uint64_t)k0 * p.num;
   const int pos = p.ls0 + (int)(tot / p.den);
   const uint32_t frac = (uint32_t)(tot % p.den);
-  const float *wp = win + (size_t)(pos - base) * C;
-  const int step = (int)p.num * G * C;   // floats between the windows of outputs k and k + den * G
+  const float *wp = win + (size_t)(pos - base) * CS;
+  const int step = (int)p.num * G * CS;   // floats between the windows of outputs k and k + den * G
   float res[R][C];
   {  // resample.c:372-400
     const int offset = (int)(frac * (uint32_t)p.oversample / p.den);
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(512) void resample_block_kernel(const RsParams p, i
       const float4 w = tp[j];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float *x = wp + r * step + (size_t)j * C;
+        const float *x = wp + r * step + (size_t)j * CS;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           const float cur = x[c];
@@ -331,11 +334,162 @@ bool rs_block_launch(int ch, int r, const RsParams &p, int G, dim3 grid, unsigne
     else rs_block_launch_cr<C_, 1>(p, G, grid, block, lds, st);                        \
     return true;
   switch (ch) {
-    RS_CASE(1) RS_CASE(2) RS_CASE(6) RS_CASE(8)
+    RS_CASE(1) RS_CASE(2) RS_CASE(6) RS_CASE(8) RS_CASE(10) RS_CASE(12) RS_CASE(14) RS_CASE(24)
     default: return false;
   }
 #undef RS_CASE
 }
+
+// DIRECT mode (small denominators: 2:1, 3:1, 1:2, 1:3, 2:3, 3:2 ...; resample.c:273-281) with the phase's filter row in
+// REGISTERS.  The tiled kernel reads 8 B of LDS per multiply-add there (4 B of table + 4 B of input per tap), and its lanes'
+// windows start num / den * C floats apart — for 2:1 an even stride, 2-way bank conflicts on top.  Here a thread owns one
+// PHASE (outputs k, k + den G, ...: R of them, one after the other) and all C channels: the row's N taps are loaded once
+// into N registers, and a tap costs one contiguous read of the sample's C channels: 4 B per MAC, no table traffic.
+// Whole-ratio down-sampling (den == 1, NUMP = num): the staged window is de-interleaved by residue mod num — sample i at
+// plane i % num, slot i / num — so that the lanes, whose windows start num samples apart, read CONSECUTIVE slots of one
+// plane for a tap (the tile's first output sits at window position 0, so plane and slot offset of tap j are the
+// compile-time j % num, j / num).  Other ratios (NUMP = 1) keep the plain layout: their lanes advance by less than two
+// samples.  The same products and sums in the same order as resample_kernel: bit-exact.
+// acc + w * x for a pair of channels, w = half H of a register PAIR of taps: v_pk_mul_f32 takes the same half of its first
+// source for both results (op_sel / op_sel_hi), so the row stays N registers — written out by the compiler the broadcast
+// (w, w) is a register pair of its own per tap: 2 N registers.  Product and sum are rounded separately, as in the reference.
+using rs_v2 = float __attribute__((ext_vector_type(2)));
+template <int H>
+__device__ __forceinline__ rs_v2 rs_mac2(rs_v2 acc, rs_v2 wpair, rs_v2 x) {
+  rs_v2 t;
+  if constexpr (H == 0)
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1]\n\tv_pk_add_f32 %1, %1, %0" : "=&v"(t), "+v"(acc) : "v"(wpair), "v"(x));
+  else
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,0] op_sel_hi:[1,1]\n\tv_pk_add_f32 %1, %1, %0" : "=&v"(t), "+v"(acc) : "v"(wpair), "v"(x));
+  return acc;
+}
+
+template <int C, int N, int NUMP, int R>
+__global__ __launch_bounds__(256, 2) void resample_direct_kernel(const RsParams p, int G) {
+  extern __shared__ float rs_lds[];
+  constexpr int CS = rs_cs(C);
+  const int s = blockIdx.y + p.s0;
+  const int hist_len = N - 1;
+  const int den = (int)p.den;
+  const int T = den * R * G;
+  const float *in = p.in ? p.in + (int64_t)s * p.in_stream_stride : nullptr;
+  const float *hist = p.hist + (int64_t)s * hist_len * C;
+  const int slots = (p.win_cap + NUMP - 1) / NUMP + 1;   // per plane
+  float *win = rs_lds;                                  // [NUMP][slots][CS]
+  float *tab = rs_lds + (((size_t)NUMP * slots * CS + 3) & ~(size_t)3);   // [den][N]
+
+  if (blockIdx.x == 0) {  // history for the next call (resample.c:801-809)
+    for (int e = threadIdx.x; e < hist_len * C; e += blockDim.x) {
+      const int j = e / C, c = e - j * C;
+      const int src = j + p.consumed;
+      float v = 0.f;
+      if (src < hist_len)
+        v = hist[src * C + c];
+      else if (in)
+        v = in[(int64_t)(src - hist_len) * C + c];
+      p.hist_next[((int64_t)s * hist_len + j) * C + c] = v;
+    }
+  }
+  const int64_t k_first = (int64_t)blockIdx.x * T;
+  const int base = p.ls0 + (int)(((uint64_t)p.fr0 + (uint64_t)k_first * p.num) / p.den);
+  for (int i = threadIdx.x; i < p.win_cap * C; i += blockDim.x) {
+    const int w = i / C, c = i - w * C;
+    const int idx = base + w;
+    float v = 0.f;
+    if (idx < hist_len)
+      v = hist[idx * C + c];
+    else if (in && idx - hist_len < p.ns)
+      v = in[(int64_t)(idx - hist_len) * C + c];
+    win[((w % NUMP) * slots + w / NUMP) * CS + c] = v;
+  }
+  for (int i = threadIdx.x; i < den * N; i += blockDim.x) tab[i] = p.table[i];
+  __syncthreads();
+  const int u = threadIdx.x;
+  if (u >= den * G) return;
+  const int64_t k0 = k_first + u;   // this thread's outputs: k0 + r * den * G, their windows num * G samples apart
+  if (k0 >= p.n_out) return;
+  const uint64_t tot = (uint64_t)p.fr0 + (uint64_t)k0 * p.num;
+  const uint32_t frac = (uint32_t)(tot % p.den);
+  const int pos = p.ls0 + (int)(tot / p.den) - base;   // window position of output k0: a multiple of NUMP
+  rs_v2 w[N / 2];   // taps 2 i, 2 i + 1
+#pragma unroll
+  for (int j = 0; j < N; j += 4) {
+    const float4 t4 = *reinterpret_cast<const float4 *>(&tab[(size_t)frac * N + j]);
+    w[j / 2] = rs_v2{t4.x, t4.y};
+    w[j / 2 + 1] = rs_v2{t4.z, t4.w};
+  }
+  const float *wp = win + (size_t)(pos / NUMP) * CS;
+  const int step = ((int)p.num * G / NUMP) * CS;   // floats between the windows of outputs r and r + 1 (num * G is a multiple of NUMP)
+  // R outputs at once: R * C / 2 independent chains of (product, sum) per lane — one output's N dependent sums alone
+  // leave a wave waiting for its own previous instruction
+  rs_v2 acc2[R][(C + 1) / 2];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < (C + 1) / 2; ++c) acc2[r][c] = rs_v2{0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) {   // taps 2 i and 2 i + 1: the two halves of w[i]
+    // (fully unrolled for the register row; without this the scheduler issues all N reads first)
+    if ((i & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+    const int o0 = (((2 * i) % NUMP) * slots + (2 * i) / NUMP) * CS;
+    const int o1 = (((2 * i + 1) % NUMP) * slots + (2 * i + 1) / NUMP) * CS;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float *x0 = wp + r * step + o0;
+      const float *x1 = wp + r * step + o1;
+      if constexpr ((C & 1) == 0) {
+#pragma unroll
+        for (int c = 0; c < C; c += 2) acc2[r][c / 2] = rs_mac2<0>(acc2[r][c / 2], w[i], *reinterpret_cast<const rs_v2 *>(x0 + c));
+#pragma unroll
+        for (int c = 0; c < C; c += 2) acc2[r][c / 2] = rs_mac2<1>(acc2[r][c / 2], w[i], *reinterpret_cast<const rs_v2 *>(x1 + c));
+      } else {
+        static_assert(C == 1 || (C & 1) == 0, "one channel, or pairs");
+        acc2[r][0].x = acc2[r][0].x + w[i].x * x0[0];
+        acc2[r][0].x = acc2[r][0].x + w[i].y * x1[0];
+      }
+    }
+  }
+  float *out = p.out + (int64_t)s * p.out_stream_stride;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t k = k0 + (int64_t)r * den * G;
+    if (k < p.n_out) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float sum = (c & 1) ? acc2[r][c / 2].y : acc2[r][c / 2].x;
+        sum = sum < -1.0f ? -1.0f : (sum > 1.0f ? 1.0f : sum);  // FLTADJUST, resample.c:84,959
+        out[k * C + c] = sum;
+      }
+    }
+  }
+}
+
+// outputs a thread works on at once
+constexpr int rs_direct_r(int c) { return c <= 2 ? 4 : (c <= 8 ? 2 : 1); }
+template <int C>
+bool rs_direct_launch_c(int n, int nump, const RsParams &p, int G, dim3 grid, unsigned block, size_t lds, hipStream_t st) {
+  constexpr int R = rs_direct_r(C);
+  if (n == 64 && nump == 1) hipLaunchKernelGGL((resample_direct_kernel<C, 64, 1, R>), grid, dim3(block), lds, st, p, G);
+  else if (n == 96 && nump == 1) hipLaunchKernelGGL((resample_direct_kernel<C, 96, 1, R>), grid, dim3(block), lds, st, p, G);
+  else if (n == 128 && nump == 2) hipLaunchKernelGGL((resample_direct_kernel<C, 128, 2, R>), grid, dim3(block), lds, st, p, G);
+  else if (n == 192 && nump == 3 && (C == 6 || C >= 10))   // (192 taps + accumulators: two waves per SIMD; 1, 2 and 8 channels measured 0.8 of the tiled kernel)
+    hipLaunchKernelGGL((resample_direct_kernel<C, 192, 3, R>), grid, dim3(block), lds, st, p, G);
+  else return false;
+  return true;
+}
+// filter lengths of quality 4: 64 (up-sampling), 96 (3:2), 128 (2:1), 192 (3:1).  false: no instantiation
+bool rs_direct_launch(int ch, int n, int nump, const RsParams &p, int G, dim3 grid, unsigned block, size_t lds, hipStream_t st) {
+  switch (ch) {
+    case 1: return rs_direct_launch_c<1>(n, nump, p, G, grid, block, lds, st);
+    case 2: return rs_direct_launch_c<2>(n, nump, p, G, grid, block, lds, st);
+    case 6: return rs_direct_launch_c<6>(n, nump, p, G, grid, block, lds, st);
+    case 8: return rs_direct_launch_c<8>(n, nump, p, G, grid, block, lds, st);
+    case 10: return rs_direct_launch_c<10>(n, nump, p, G, grid, block, lds, st);
+    case 12: return rs_direct_launch_c<12>(n, nump, p, G, grid, block, lds, st);
+    default: return false;
+  }
+}
+int rs_direct_r_of(int ch) { return ch <= 2 ? 4 : (ch <= 8 ? 2 : 1); }
 
 // ---- filter design on the host: resample.c:194-231 (window, sinc) and :527-611 ----
 double window_at(float x) {
@@ -450,9 +604,29 @@ int rs_run(iamf_hip_resampler *r, const float *d_in, int64_t in_stride, int ns, 
   const int64_t win_cap = ((int64_t)outs * r->num + r->den - 1) / r->den + (int64_t)r->filt_len + 2;
   const size_t tab_floats = r->direct ? (size_t)r->den * (r->filt_len + 4) : (size_t)4 * r->oversample * (r->filt_len + 1);
   const size_t lds = sizeof(float) * ((((size_t)win_cap * r->ch + 3) & ~(size_t)3) + tab_floats);
-  // the register-blocked kernel: a thread = R outputs of one phase x all channels (resample_block_kernel)
   bool blocked = false;
-  if (!r->direct && r->d_table4 != nullptr && r->den <= 512 && rs_block_r(r->ch) >= 2 && !getenv("IAMF_HIP_RESAMPLE_PLAIN") &&
+  // direct mode: a thread = one phase with its filter row in registers (resample_direct_kernel)
+  if (r->direct && r->den <= 16 && !getenv("IAMF_HIP_RESAMPLE_PLAIN") && !getenv("IAMF_HIP_RESAMPLE_TILE")) {
+    const int nump = r->den == 1 ? (int)r->num : 1;
+    const int R = rs_direct_r_of(r->ch);
+    int G = 256 / (int)r->den;
+    if (cnt < 256) G = G > 4 ? G / (cnt < 64 ? 4 : 2) : G;   // few streams: more, smaller tiles
+    for (; G >= 1; G >>= 1) {
+      const int64_t T = (int64_t)r->den * R * G;
+      const int64_t wcap = (T * r->num + r->den - 1) / r->den + (int64_t)r->filt_len + 2;
+      const int64_t slots = (wcap + nump - 1) / nump + 1;
+      const size_t dlds = sizeof(float) * ((((size_t)nump * slots * rs_cs(r->ch) + 3) & ~(size_t)3) + (size_t)r->den * r->filt_len);
+      if (dlds <= 60 * 1024) {
+        p.win_cap = (int)wcap;
+        const unsigned blk = (unsigned)(((int)r->den * G + 63) & ~63);
+        dim3 dgrid((unsigned)(n_out > 0 ? (n_out + T - 1) / T : 1), (unsigned)cnt);
+        blocked = rs_direct_launch(r->ch, (int)r->filt_len, nump, p, G, dgrid, blk, dlds, static_cast<hipStream_t>(stream));
+        break;
+      }
+    }
+  }
+  // the register-blocked kernel: a thread = R outputs of one phase x all channels (resample_block_kernel)
+  if (!blocked && !r->direct && r->d_table4 != nullptr && r->den <= 512 && !getenv("IAMF_HIP_RESAMPLE_PLAIN") &&
       !getenv("IAMF_HIP_RESAMPLE_TILE")) {
     // G groups of den threads: the fullest whole waves within 512 threads, nearest to 256 among equals
     int G = 1, best_num = 0, best_blk = 64;
@@ -470,7 +644,7 @@ int rs_run(iamf_hip_resampler *r, const float *d_in, int64_t in_stride, int ns, 
     for (;;) {
       const int64_t T = (int64_t)r->den * R * G;
       const int64_t wcap = (T * r->num + r->den - 1) / r->den + (int64_t)r->filt_len + 2;
-      const size_t blds = sizeof(float) * ((((size_t)wcap * r->ch + 3) & ~(size_t)3) + tab_floats);
+      const size_t blds = sizeof(float) * ((((size_t)wcap * rs_cs(r->ch) + 3) & ~(size_t)3) + tab_floats);
       if (blds <= 60 * 1024) {
         p.table4 = r->d_table4;
         p.win_cap = (int)wcap;

@@ -359,11 +359,14 @@ def test_resampler_streams_out_of_step_by_ranges(hip, rates):
         assert np.array_equal(np.concatenate(outs[s], axis=1).view(np.uint32), want.view(np.uint32)), s
 
 
-@pytest.mark.parametrize("rates", [(44100, 48000), (48000, 44100), (22050, 48000), (8000, 44100)])
-@pytest.mark.parametrize("ch,streams", [(1, 3), (2, 70), (2, 260), (6, 70), (8, 5), (6, 260), (1, 300)])
+@pytest.mark.parametrize("rates", [(44100, 48000), (48000, 44100), (22050, 48000), (8000, 44100),
+                                   (96000, 48000), (48000, 16000), (16000, 48000), (32000, 48000), (48000, 32000), (24000, 48000)])
+@pytest.mark.parametrize("ch,streams", [(1, 3), (2, 70), (2, 260), (6, 70), (8, 5), (6, 260), (1, 300), (8, 260), (12, 70), (10, 3), (14, 5), (24, 3)])
 def test_resampler_blocked_kernel_over_its_shapes(hip, rates, ch, streams, monkeypatch):
     """resample_block_kernel<C, R> (interpolated mode, 1 / 2 / 6 / 8 channels; R = 1 / 2 / 4 by the launch's stream count;
-    den = 160, 147, 320, 441 threads' worth of phases): ragged calls incl. one that yields no output, then the drain.
+    den = 160, 147, 320, 441 threads' worth of phases) and resample_direct_kernel<C, N, NUMP> (direct mode: 2:1 and 3:1 with
+    the de-interleaved window, 1:3 / 2:3 / 3:2 / 1:2 with the plain one; filter rows of 64 / 96 / 128 / 192 taps in
+    registers): ragged calls incl. one that yields no output, then the drain.
     Streams 0 and the last one against the oracle (the reference's arithmetic), every stream against the tiled kernel."""
     A, G, torch = hip
     sizes = [1024, 3, 1, 700, 1024, 64]

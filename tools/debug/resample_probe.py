@@ -32,8 +32,8 @@ def rate(in_rate, out_rate, ch, S, ns=16384, reps=10):
 
 
 def main():
-    pairs = [(int(sys.argv[1]), int(sys.argv[2]))] if len(sys.argv) > 2 else [(44100, 48000), (48000, 44100), (96000, 48000), (32000, 48000), (16000, 48000)]
-    chans = [int(sys.argv[3])] if len(sys.argv) > 3 else [2, 6, 12]
+    pairs = [(int(sys.argv[1]), int(sys.argv[2]))] if len(sys.argv) > 2 else [(44100, 48000), (48000, 44100), (96000, 48000), (48000, 16000), (32000, 48000), (48000, 32000), (16000, 48000)]
+    chans = [int(sys.argv[3])] if len(sys.argv) > 3 else [2, 6, 8, 12]
     S = int(sys.argv[4]) if len(sys.argv) > 4 else 512
     for a, b in pairs:
         for ch in chans:
