@@ -1026,17 +1026,33 @@ static int pre_attach(struct IAMF_Decoder *d, int ei, iamf_hip_batch *batch) {
       dc.n_in += n;
       q->demix_nsub += L->nsub;
       last = L->layout;
-      if (L->out_gain_flag)
-        for (int c = 0; c < 6; ++c)
-          if (L->gain_flags & (1 << c)) {
-            int ch = output_gain_channel(L->layout, c);
-            if (ch != CH_INVALID) {
-              dc.gain_ch[dc.n_gain] = ch;
-              dc.gain[dc.n_gain++] = db2lin(q_to_float(L->gain_q, 8));
-            }
-          }
     }
     if (dc.n_in != k_layout_channels[e->layout]) return IAMF_ERR_INVALID_PACKET;
+    /* The layers' output gains, in layer order (iamf_stream_scale_demixer_configure, IAMF_decoder.c:2365-2380).  dmx_gainup
+     * (demixer.c:421-430) multiplies a channel only if it was DECODED, so entries naming a channel that is derived later
+     * are dropped here (the batch dropped them anyway): that bounds the list by what the layers carry, and more than 12
+     * entries that do name decoded channels are refused — until the second half of round 4 this loop wrote dc.gain_ch[] /
+     * dc.gain[] without a bound (six layers can name 24 channels).
+     * The reference collects all mapped entries in chs[12] / gains[12] on its stack, also without a bound, and stores the
+     * mapped channel BEFORE testing it: with exactly 12 entries collected and one more flag bit set, chs[12] =
+     * IA_CH_INVALID lands on its neighbour — gains[0] in the gcc build here: the first entry's gain becomes 0.  Found by
+     * tests/e2e_fuzz.py 'wide' seed 7214 (flags 43 / 63 / 27 / 27 over stereo, 3.1.2, 5.1.2, 7.1.4: one channel of the
+     * reference's PCM rendered from a zeroed Rtf); not reproduced: e2e_fuzz.reference_gain_list_overflows() names such
+     * streams, tools/debug/fuzz_bisect.py took this one apart. */
+    for (int l = 0; l <= q->demix_layer; ++l) {
+      const Layer *L = &e->layer[l];
+      if (!L->out_gain_flag) continue;
+      for (int c = 0; c < 6; ++c)
+        if (L->gain_flags & (1 << c)) {
+          int ch = output_gain_channel(L->layout, c), decoded = 0;
+          if (ch == CH_INVALID) continue;
+          for (int k = 0; k < dc.n_in; ++k) decoded |= dc.chs_in[k] == ch;
+          if (!decoded) continue;
+          if (dc.n_gain >= 12) return IAMF_ERR_UNIMPLEMENTED;
+          dc.gain_ch[dc.n_gain] = ch;
+          dc.gain[dc.n_gain++] = db2lin(q_to_float(L->gain_q, 8));
+        }
+    }
     q->demix_nch = dc.n_in;
     /* iamf_stream_scale_decoder_set_default_recon_gain, :2202-2236 */
     q->rec_flags = q->demix_layer > 0 ? recon_default_flags(e->layer[0].layout, e->layout) : 0;

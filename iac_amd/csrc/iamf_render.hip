@@ -72,6 +72,7 @@ namespace {
 #include "render_fir_fft.hpp"
 #include "render_fast.hpp"
 #include "render_generic.hpp"
+#include "render_nolim.hpp"
 #include "render_wide.hpp"
 #include "render_lfe.hpp"
 
@@ -298,6 +299,14 @@ int reset_state(iamf_hip_batch *b) {
 template <int M>
 void launch_m(const RenderParams &p, dim3 grid, size_t lds_bytes, hipStream_t st) {
   hipLaunchKernelGGL(render_kernel<M>, grid, dim3(kChunk), lds_bytes, st, p);
+}
+
+// limiter off, one matrix-rendered element, constant gains (render_nolim.hpp): (streams, chunks of 1024 sample-frames)
+template <int M>
+void launch_nolim_m(const RenderParams &p, hipStream_t st) {
+  const int bytes = p.out_format == IAMF_HIP_FMT_S16 ? 2 : (p.out_format == IAMF_HIP_FMT_S24 ? 3 : 4);
+  dim3 grid((unsigned)p.n_launch, (unsigned)((p.total + kNlChunk - 1) / kNlChunk));
+  hipLaunchKernelGGL(render_nolim_kernel<M>, grid, dim3(256), (size_t)kNlChunk * p.out_ch * bytes, st, p);
 }
 
 template <int M>
@@ -533,6 +542,17 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
   const bool mixing = p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp;
   if (!p.lfe && (wide || ((p.demix_on || p.dmx_on || mixing) && wide_path_ok(p, m, true))) && wide4_path_ok(p, m) &&
       (mixing ? iamf_hip_wide4_mix_launch(&p, m, st) : iamf_hip_wide4_launch(&p, m, st))) {
+    HIPCHK(hipGetLastError());
+    return IAMF_HIP_OK;
+  }
+  if (!p.limiter_on && p.in && !p.lfe && !p.pre_matrix && !p.demix_on && !p.dmx_on && !mixing && p.fir_taps == 0 &&
+      p.og_ch >= p.out_ch && !getenv("IAMF_HIP_FORCE_GENERIC") && nolim_shape_ok(p)) {
+    switch (m) {
+#define CASE_N(v) case v: launch_nolim_m<v>(p, st); break;
+      CASE_N(1) CASE_N(2) CASE_N(4) CASE_N(6) CASE_N(8) CASE_N(9) CASE_N(10) CASE_N(11) CASE_N(12) CASE_N(14) CASE_N(16) CASE_N(24)
+#undef CASE_N
+      default: return IAMF_HIP_ERR_UNIMPLEMENTED;
+    }
     HIPCHK(hipGetLastError());
     return IAMF_HIP_OK;
   }

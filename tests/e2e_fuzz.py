@@ -386,6 +386,32 @@ def build(seed, variant="default"):
         del E.CASES[name]
 
 
+def reference_gain_list_overflows(c):
+    """True if a scalable element of case `c` makes the reference write past its 12-entry output-gain arrays
+    (iamf_stream_scale_demixer_configure, IAMF_decoder.c:2365-2380: chs[count] is stored before it is tested, so the 13th
+    flagged bit — mapped or not — lands behind the array once 12 entries are collected).  Such streams are undefined behaviour
+    there (seed 7214 of 'wide': its first gain turns 0) and are named, not compared, by the hunting tools."""
+    surround = {0: 1, 1: 2, 2: 5, 3: 5, 4: 5, 5: 7, 6: 7, 7: 7, 8: 3}
+    for k in ("1", "2"):
+        layers, gains = c.get("scalable_layers" + k), c.get("scalable_gains" + k)
+        if not layers or not gains:
+            continue
+        count = 0
+        for li, lay in enumerate(layers):
+            if li not in gains:
+                continue
+            flags = gains[li][0]
+            for g in range(6):
+                if not flags & (1 << g):
+                    continue
+                if count >= 12:
+                    return True
+                s_ = surround[lay]
+                valid = {5: lay in (0, 1, 8), 4: lay in (1, 8), 3: s_ == 5, 2: s_ == 5, 1: True, 0: True}[g]
+                count += 1 if valid else 0
+    return False
+
+
 def decode_kwargs(c, variant="default"):
     kw = dict(bit_depth=c["bit_depth"], out_rate=c.get("out_rate", 0), loudness=c.get("loudness", 0.0),
               limiter=c.get("limiter", True), threshold=c.get("threshold", -1.0))

@@ -297,3 +297,28 @@ def test_fuzz_streams_under_the_sanitizers(driver, tmp_path, variant):
         r = subprocess.run([driver, p, lay, str(c["bit_depth"])], capture_output=True, text=True, timeout=120,
                            env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0"))
         assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, (variant, seed, r.stderr[-2500:])
+
+
+def test_layer_output_gain_lists_are_bounded(driver, tmp_path):
+    """tests/e2e_fuzz.py 'wide' seed 7214: a scalable element of four layers (stereo, 3.1.2, 5.1.2, 7.1.4) whose output-gain
+    flags (43, 63, 27, 27) map to exactly 12 channels with two more flag bits behind them — the reference stores the 13th
+    mapped value before testing it (IAMF_decoder.c:2371: chs[12] on a 12-entry stack array) and zeroes its first gain.  The
+    facade's own list had no bound either until this was looked into; now entries naming a channel no layer carries are
+    dropped, more than 12 of the rest refused.  This stream must configure and decode under ASan / UBSan; so must six
+    layers with every flag set (24 mapped entries: 10 name decoded channels)."""
+    import e2e_cases as E
+    import e2e_fuzz as F
+    stream, c = F.build(7214, "wide")
+    assert F.reference_gain_list_overflows(c)
+    out = run(driver, tmp_path, stream, layout=str(c["layout"][1]), bits=c["bit_depth"])
+    assert out[0].startswith("configure 0"), out[:3]
+    c6 = dict(c, pair=("scalable",), scalable_layers1=[0, 1, 8, 3, 4, 7], scalable_gains1={i: (63, -100 * i) for i in range(6)})
+    c6.pop("trims", None)
+    assert F.reference_gain_list_overflows(c6)
+    E.CASES["six_layers_tmp"] = c6
+    try:
+        stream6 = E.build("six_layers_tmp")[0]
+    finally:
+        del E.CASES["six_layers_tmp"]
+    out = run(driver, tmp_path, stream6, layout=str(c["layout"][1]), bits=c["bit_depth"])
+    assert out[0].startswith("configure 0"), out[:3]

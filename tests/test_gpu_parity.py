@@ -114,6 +114,31 @@ def test_wide_layouts_in_24_and_32_bit_vs_oracle(hip, fmt_bits, lay, in_id, m):
             assert np.array_equal(got[s], want), (lay, fs, s, fmt_bits)
 
 
+@pytest.mark.parametrize("fmt_bits", [16, 24, 32])
+@pytest.mark.parametrize("lay,in_id,m", [("A", "STEREO", 2), ("A", None, 16), ("B", "L51", 6), ("J", "L714", 12), ("E", "L714", 12), ("H", None, 16), ("MONO", "STEREO", 2)])
+def test_limiter_off_layouts_and_formats_vs_oracle(hip, fmt_bits, lay, in_id, m):
+    """the player's -disable_limiter (IAMF_decoder_peak_limiter_enable(h, 0)): render_nolim_kernel<M> where its shape fits
+    (4 samples per lane, the tile packed in LDS, one contiguous run of 16-byte pieces), the general kernel elsewhere (11
+    channels in 16 / 24 bit, 24 channels in 24 / 32 bit) — every sample is emitted at once, no delay; gains and loudness on,
+    calls of 1 / 3 / 2 frames, frame sizes 1024, 960 and 100 (a last chunk that is not full)."""
+    A, G = hip
+    oc = {"A": 2, "B": 6, "J": 12, "E": 11, "H": 24, "MONO": 1}[lay]
+    for fs in (1024, 960, 100):
+        F, S = 6, 3
+        x = np.stack([synth.hot(5200 + 11 * s + oc, m, F * fs, sigma=0.4, burst_phase=300 + 70 * s, burst_period=2000) for s in range(S)])
+        mx = A.get_h2m_matrix(3, A.SS[lay]) if in_id is None else A.get_m2m_matrix(A.SS[in_id], A.SS[lay])
+        omx = O.get_h2m(3, O.SS[lay]) if in_id is None else O.get_m2m(O.SS[in_id], O.SS[lay])
+        fmt = {16: A.FMT_S16, 24: A.FMT_S24, 32: A.FMT_S32}[fmt_bits]
+        eg, og, lg = [0.8, 1.0, 1.25], [1.0, 0.6, 1.0], [O.lib().orc_db2lin(-2.0), 1.0, O.lib().orc_db2lin(1.5)]
+        got = G.hip_render(mx, oc, x, frame_size=fs, fmt=fmt, limiter=False, flush=True, frames_per_call=[1, 3, 2], loudness=True,
+                           gains=dict(element=eg, output=og, loudness=lg), projection=A.PROJ_EXACT)
+        for s in range(S):
+            want = O.stream_run(omx, oc, x[s], fs, bit_depth=fmt_bits, limiter_on=0, element_gain=eg[s], output_gain=og[s],
+                                loudness_on=1, loudness_gain=lg[s])
+            assert got[s].shape == want.shape and want.shape[:2] == (F * fs, oc)
+            assert np.array_equal(got[s], want), (lay, fs, s, fmt_bits)
+
+
 def test_pipeline_gains_and_loudness_vs_oracle(hip):
     A, G = hip
     S, fs, F = 3, 960, 4
