@@ -424,7 +424,8 @@ bool fast_path_ok(const RenderParams &p, bool down_mixer = false) {
   if (p.in2 && (p.dmx_on || p.fir_taps > 0 || p.m2 > kFIn2 || (reinterpret_cast<uintptr_t>(p.in2) & 15) ||
                 (p.in2_stream_stride & 3) || (p.in2_frame_stride & 3)))
     return false;  // a second element of up to 4 channels rides along (render_fast_kernel<.., IN2>)
-  if ((p.pos0 & 15) || (p.total & 63) || (p.frame_size & 3)) return false;
+  // (a position that is not a multiple of 16 — a trimmed first frame — from 240 samples on: render_fast.hpp `base`)
+  if (((p.pos0 & 15) && p.pos0 < kDelay) || (p.total & 63) || (p.frame_size & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (p.in_stream_stride & 3) || (p.in_frame_stride & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
   {  // the kernel addresses a stream's input of one call with 32-bit byte offsets (buffer loads, render_fast.hpp)
@@ -436,7 +437,9 @@ bool fast_path_ok(const RenderParams &p, bool down_mixer = false) {
 }
 
 // The wide kernel: 3..24 output channels, limiter on, aligned calls.
-bool wide_path_ok(const RenderParams &p, int m, bool with_stage = false) {
+// any_pos: the caller will launch render_wide4_kernel, which (like render_fast_kernel) places its ring per call; the
+// 256-sample kernel of render_wide.hpp keeps absolute ring positions and needs the stream at a multiple of 16
+bool wide_path_ok(const RenderParams &p, int m, bool with_stage = false, bool any_pos = false) {
   if (getenv("IAMF_HIP_FORCE_GENERIC") || p.og_ch < p.out_ch) return false;
   if (!p.limiter_on || !p.in || p.out_ch <= 2 || p.out_ch > kMaxOut || p.n_end < kWWin) return false;
   if (p.pre_matrix) return false;
@@ -444,7 +447,7 @@ bool wide_path_ok(const RenderParams &p, int m, bool with_stage = false) {
   if (mixing && !with_stage) return false;
   if ((p.demix_on || p.dmx_on) && (!with_stage || mixing)) return false;  // demixer / down-mixer / mixer: wide4 variants only
   if (p.dmx_on && (!p.dmx_frames || p.demix_on)) return false;  // demixer AND down-mixer: generic kernel
-  if ((p.pos0 & 15) || (p.total & 63)) return false;
+  if (((p.pos0 & 15) && !(any_pos && p.pos0 >= kDelay)) || (p.total & 63)) return false;
   if ((reinterpret_cast<uintptr_t>(p.pcm) & 15) || (p.pcm_stream_stride & 15)) return false;
   return sizeof(float) * (size_t)wide_lds_floats(p.out_ch, m) <= 80 * 1024;
 }
@@ -540,7 +543,8 @@ int launch(const RenderParams &p, int m, size_t lds_bytes, hipStream_t st) {
   const bool fast = !p.lfe && fast_path_ok(p);
   const bool wide = !p.lfe && !fast && wide_path_ok(p, m);
   const bool mixing = p.in2 || p.elem_ramp || p.elem2_ramp || p.out_ramp;
-  if (!p.lfe && (wide || ((p.demix_on || p.dmx_on || mixing) && wide_path_ok(p, m, true))) && wide4_path_ok(p, m) &&
+  const bool wide_any = !p.lfe && !fast && wide_path_ok(p, m, false, true);
+  if (!p.lfe && (wide_any || ((p.demix_on || p.dmx_on || mixing) && wide_path_ok(p, m, true, true))) && wide4_path_ok(p, m) &&
       (mixing ? iamf_hip_wide4_mix_launch(&p, m, st) : iamf_hip_wide4_launch(&p, m, st))) {
     HIPCHK(hipGetLastError());
     return IAMF_HIP_OK;

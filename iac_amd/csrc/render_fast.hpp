@@ -245,7 +245,11 @@ __global__ __launch_bounds__(FIR == 1 ? 512 : 256, FIR >= 2 ? 2 : ((FIR || (M <=
   const int q = t & 3;
   const int fs = p.frame_size;
   const float thr = p.thr;
-  int base = (int)(p.pos0 % R);  // ring position of the chunk's first sample; multiple of 16
+  // ring position of the chunk's first sample: a multiple of 16 (the 16-blocks of maxima are aligned in the ring).  Where the
+  // ring starts is this call's choice — everything below is relative to `base`, the persisted state is "the last 256
+  // samples" — so a stream whose position is NOT a multiple of 16 (a first frame trimmed by 237 samples) runs here too,
+  // from 240 samples on (before that the withheld look-ahead ends inside a lane's four samples: the general kernel)
+  int base = (int)((p.pos0 & ~(int64_t)15) % R);
 
   // ---- stream state and constants -> LDS (persisted format is the generic kernel's) ----
   if (act) {

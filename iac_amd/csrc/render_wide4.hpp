@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, (M <= 12 && C <= 12 && !(DMX || DOWN || MIX)) 
   const int n_atk = p.n_atk, n_end = p.n_end;
   const bool is_tail = t >= kW4FirstTail;
   const int tl = is_tail ? t - kW4FirstTail : 0;
-  int base = (int)(p.pos0 % R);  // ring position of the chunk's first sample; multiple of 16
+  int base = (int)((p.pos0 & ~(int64_t)15) % R);  // ring position of the chunk's first sample: a multiple of 16 (render_fast.hpp)
 
   // ---- stream state and constants -> LDS (persisted format is the generic kernel's) ----
   {

@@ -78,3 +78,50 @@ def test_ranges_advance_independently(src, out, m):
         assert got.shape == want.shape, (s, got.shape, want.shape)
         assert np.array_equal(got, want), s
     b.close()
+
+
+@pytest.mark.parametrize("src,out,m", [("TOA", "A", 16), ("L714", "J", 12), ("TOA", "H", 16), ("STEREO", "MONO", 2), ("L51", "B", 6)])
+@pytest.mark.parametrize("trim", [237, 3, 1000])
+def test_streams_that_stand_off_the_16_sample_grid(src, out, m, trim):
+    """a first frame trimmed at its start by a number of samples that is not a multiple of 16 leaves the stream at a position
+    off the grid of the limiter's 16-blocks for the rest of its life.  Until the second half of round 4 every later call
+    then ran on the general kernel; render_fast_kernel / render_wide4_kernel place their ring per call and take such
+    streams from 240 samples on (trim 1000: the second call still starts below 240 and stays on the general kernel).
+    Calls: the trimmed frame, then 1 + 2 + 1 whole frames, the flush; against the oracle on the kept samples."""
+    import torch
+    import iac_amd as A
+    fs, F, S = 1024, 5, 3
+    ch = A.layout_channels(A.SS[out])
+    if src == "TOA":
+        mx, omx, proj = A.get_h2m_matrix(3, A.SS[out]), O.get_h2m(3, O.SS[out]), A.PROJ_EXACT
+    else:
+        mx, omx, proj = A.get_m2m_matrix(A.SS[src], A.SS[out]), O.get_m2m(O.SS[src], O.SS[out]), A.PROJ_AUTO
+    x = np.stack([synth.hot(8100 + s + trim, m, F * fs, burst_phase=200 + 31 * s, burst_period=1700) for s in range(S)])
+    xin = torch.from_numpy(np.ascontiguousarray(x.reshape(S, m, F, fs).transpose(0, 2, 1, 3))).cuda()   # [S][F][m][fs]
+    b = A.Batch(S, mx, ch, frame_size=fs, out_format=A.FMT_S16, limiter=True, projection=proj)
+    st = torch.cuda.current_stream().cuda_stream
+    cap = F * fs * ch * 2
+    outs = [[] for _ in range(S)]
+    f0 = 0
+    for nf, ns, skip in [(1, fs - trim, trim), (1, 0, 0), (2, 0, 0), (1, 0, 0)]:
+        pcm = torch.zeros((S, cap), dtype=torch.uint8, device="cuda")
+        a = A.RenderArgs()
+        a.d_in, a.in_stream_stride, a.in_frame_stride = xin.data_ptr() + 4 * (f0 * m * fs + skip), F * m * fs, m * fs
+        a.n_frames, a.n_samples, a.d_pcm, a.pcm_stream_stride_bytes, a.stream = nf, ns, pcm.data_ptr(), cap, st
+        n = b.render_ex(a)
+        torch.cuda.synchronize()
+        h = pcm.cpu().numpy()
+        for s in range(S):
+            outs[s].append(h[s][:n * ch * 2].view(np.int16).reshape(n, ch).copy())
+        f0 += nf
+    pcm = torch.zeros((S, cap), dtype=torch.uint8, device="cuda")
+    n = b.flush(pcm.data_ptr(), cap, st)
+    torch.cuda.synchronize()
+    h = pcm.cpu().numpy()
+    b.close()
+    for s in range(S):
+        outs[s].append(h[s][:n * ch * 2].view(np.int16).reshape(n, ch).copy())
+        want = O.stream_run(omx, ch, np.ascontiguousarray(x[s][:, trim:]), fs)
+        got = np.concatenate(outs[s], axis=0)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), (s, trim)
