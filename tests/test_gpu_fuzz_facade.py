@@ -152,10 +152,28 @@ def test_random_wide_stream_through_a_group_of_handles(lib, seed):
         assert F.digest(pcm) == want["sha256"], (seed, i)
 
 
-GOLD_B = json.load(open(os.path.join(_G, "fuzz_blocks.json")))
+# Hunting runs of the four sets below (tools/debug/fuzz_hunt_gen.py --sets ...): IAMF_FUZZ_HUNT=first:count takes the seeds
+# first .. first + count - 1 instead of the committed ones, their goldens from tests/golden_tmp/hunt_<set>.json.
+_HUNT = os.environ.get("IAMF_FUZZ_HUNT")
 
 
-@pytest.mark.parametrize("seed", range(F.N_BLOCKS))
+def _seeds(n):
+    if not _HUNT:
+        return range(n)
+    first, count = (int(v) for v in _HUNT.split(":"))
+    return range(first, first + count)
+
+
+def _gold(name):
+    if _HUNT:
+        return json.load(open(os.path.join(os.path.dirname(_G), "golden_tmp", "hunt_%s.json" % name)))
+    return json.load(open(os.path.join(_G, "fuzz_%s.json" % name)))
+
+
+GOLD_B = _gold("blocks")
+
+
+@pytest.mark.parametrize("seed", _seeds(F.N_BLOCKS))
 def test_random_stream_through_the_players_block_loop(lib, seed):
     """the reference player's own loop (iamfplayer.c:529-662) with block buffers from 777 bytes to its 184 320: configure fed
     until it stops answering IAMF_ERR_BUFFER_TOO_SMALL, decode while it consumes something, the rest of a block in front of
@@ -189,10 +207,10 @@ def test_random_multi_and_params_streams_through_a_group_of_handles(lib, variant
         assert F.digest(pcm) == want["sha256"], (variant, seed, i)
 
 
-GOLD_S = json.load(open(os.path.join(_G, "fuzz_switch.json")))
+GOLD_S = _gold("switch")
 
 
-@pytest.mark.parametrize("seed", range(F.N_SWITCH))
+@pytest.mark.parametrize("seed", _seeds(F.N_SWITCH))
 def test_random_tv_stream_with_run_time_layout_switches(lib, seed):
     """the -DSAMSUNG_TV build's run-time layout switch (IAMF_decoder_output_layout_set_* + IAMF_decoder_configure(h, NULL, 0,
     NULL), IAMF_decoder.c:3819-3881) once or twice per stream, after random numbers of delivered frames, to random layouts:
@@ -215,10 +233,10 @@ def test_random_tv_stream_with_run_time_layout_switches(lib, seed):
     assert list(pcm.shape) == want["shape"] and F.digest(pcm) == want["sha256"], (seed, vs, lays, after)
 
 
-GOLD_U = json.load(open(os.path.join(_G, "fuzz_units.json")))
+GOLD_U = _gold("units")
 
 
-@pytest.mark.parametrize("seed", range(F.N_UNITS))
+@pytest.mark.parametrize("seed", _seeds(F.N_UNITS))
 def test_random_stream_one_temporal_unit_per_call(lib, seed):
     """the reference player's demuxer loop (iamfplayer.c:664-789): the descriptors in one IAMF_decoder_configure call, ONE
     temporal unit per IAMF_decoder_decode call, rsize == NULL in both (include/IAMF_decoder.h:91-95), a flush at the end.
@@ -230,10 +248,10 @@ def test_random_stream_one_temporal_unit_per_call(lib, seed):
     assert list(pcm.shape) == want["shape"] and F.digest(pcm) == want["sha256"], (seed, variant, vs)
 
 
-GOLD_G = json.load(open(os.path.join(_G, "fuzz_gmix.json")))
+GOLD_G = _gold("gmix")
 
 
-@pytest.mark.parametrize("seed", range(F.N_GMIX))
+@pytest.mark.parametrize("seed", _seeds(F.N_GMIX))
 def test_group_whose_handles_decode_different_streams(lib, seed):
     """three to six handles of ONE topology, each with a stream of its own — other audio, gains, ramps, demixing modes, recon
     gains, missing blocks, trims (a unit trimmed away in one stream while the others render) — out of step through one group:

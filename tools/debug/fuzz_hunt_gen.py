@@ -21,8 +21,25 @@ def one(args):
     return seed, json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def one_set(args):
+    seed, name = args
+    r = subprocess.run([sys.executable, GEN, "--" + name, str(seed)], capture_output=True, text=True)
+    if r.returncode != 0:
+        return seed, dict(crash=r.returncode)
+    return seed, json.loads(r.stdout.strip().splitlines()[-1])
+
+
 def main():
     first, count = int(sys.argv[1]), int(sys.argv[2])
+    if len(sys.argv) > 3 and sys.argv[3] == "--sets":   # blocks / switch / units / gmix: tests/golden_tmp/hunt_<set>.json, read by
+        os.makedirs(os.path.join(ROOT, "tests", "golden_tmp"), exist_ok=True)   # tests/test_gpu_fuzz_facade.py under IAMF_FUZZ_HUNT=first:count
+        for name in sys.argv[4:] or ("blocks", "switch", "units", "gmix"):
+            with ThreadPoolExecutor(max_workers=7) as ex:
+                gold = {str(s): g for s, g in ex.map(one_set, [(s, name) for s in range(first, first + count)])}
+            with open(os.path.join(ROOT, "tests", "golden_tmp", "hunt_%s.json" % name), "w") as f:
+                json.dump(gold, f)
+            print(name, len(gold), "crashed", sum("crash" in g for g in gold.values()), flush=True)
+        return
     variants = sys.argv[3:] or ALL
     os.makedirs(os.path.join(ROOT, "tests", "golden_tmp"), exist_ok=True)
     for v in variants:
