@@ -386,6 +386,15 @@ def build(seed, variant="default"):
         del E.CASES[name]
 
 
+def reference_h_slot_23_is_stale(c, layouts):
+    """slot 23 of Sound System H from a scene-based element behind a resampler is stale frame-buffer content in the reference
+    (render_H2M never writes it for H; see case()): case() keeps that combination out of the sets, a run-time layout SWITCH to
+    H (switch_case) can still reach it — found by hunting the switch set (8 of 3000 seeds, all of this kind: the one PCM
+    column that carries slot 23).  Return values are compared, the PCM is not."""
+    outr = c.get("out_rate") or 48000
+    return ("ss", 7) in [tuple(l) for l in layouts] and c.get("rate", 48000) != outr and any(k in SCENE for k in c["pair"])
+
+
 def reference_gain_list_overflows(c):
     """True if a scalable element of case `c` makes the reference write past its 12-entry output-gain arrays
     (iamf_stream_scale_demixer_configure, IAMF_decoder.c:2365-2380: chs[count] is stored before it is tested, so the 13th
