@@ -489,7 +489,6 @@ bool rs_direct_launch(int ch, int n, int nump, const RsParams &p, int G, dim3 gr
     default: return false;
   }
 }
-int rs_direct_r_of(int ch) { return ch <= 2 ? 4 : (ch <= 8 ? 2 : 1); }
 
 // ---- filter design on the host: resample.c:194-231 (window, sinc) and :527-611 ----
 double window_at(float x) {
@@ -608,7 +607,7 @@ int rs_run(iamf_hip_resampler *r, const float *d_in, int64_t in_stride, int ns, 
   // direct mode: a thread = one phase with its filter row in registers (resample_direct_kernel)
   if (r->direct && r->den <= 16 && !getenv("IAMF_HIP_RESAMPLE_PLAIN") && !getenv("IAMF_HIP_RESAMPLE_TILE")) {
     const int nump = r->den == 1 ? (int)r->num : 1;
-    const int R = rs_direct_r_of(r->ch);
+    const int R = rs_direct_r(r->ch);
     int G = 256 / (int)r->den;
     if (cnt < 256) G = G > 4 ? G / (cnt < 64 ? 4 : 2) : G;   // few streams: more, smaller tiles
     for (; G >= 1; G >>= 1) {

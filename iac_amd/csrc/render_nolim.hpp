@@ -67,7 +67,6 @@ __global__ __launch_bounds__(256) void render_nolim_kernel(const RenderParams p)
         z = 0.f + z;  // iamf_mixer_mix: memset 0 then += (IAMF_decoder.c:2719-2730)
         if (og_on) z = z * og;
         if (lg_on) z = z * lg;
-        z = z * 1.0f;  // the general kernel's `ring_y * g` with the limiter off (g = 1): exact
         uint8_t *d = mine + (size_t)(q * oc + c) * bytes;
         if (p.out_format == IAMF_HIP_FMT_S16) {
           *reinterpret_cast<int16_t *>(d) = (int16_t)(int)to_scaled(z, 32768.f, -32768.f, 32767.f);
